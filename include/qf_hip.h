@@ -1,0 +1,242 @@
+/* qf_hip.h -- C ABI of libqf_hip.so, the MI355X (gfx950) implementation of the
+ * quadrature-field render hot path of ubc-vision/quadraturefields.
+ *
+ * The reference is pure Python and has no C ABI of its own: every entry
+ * point below names the Python call site(s), in /root/reference, whose arithmetic it replaces.
+ * Conventions (all entry points):
+ *   - plain pointers and sizes only; every data pointer is a DEVICE pointer owned by the caller
+ *     unless the parameter is documented "host";
+ *   - work is enqueued on `stream` (a hipStream_t passed as void*; NULL = the default stream),
+ *     with no implicit synchronisation and no hidden allocation except opaque handles;
+ *   - the return value is a status code (QF_OK == 0, negative on error); nothing throws across
+ *     the boundary; qf_status_string() maps a code to text;
+ *   - int64 sizes; per-sample ray / triangle ids are int64 at the Python surface (as in the
+ *     reference's LongTensors) and int32 inside the traversal.
+ */
+#ifndef QF_HIP_H
+#define QF_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QF_OK 0
+#define QF_ERR_INVALID_ARGUMENT (-1)
+#define QF_ERR_HIP (-2)
+#define QF_ERR_UNSUPPORTED (-3)
+#define QF_ERR_NO_DEVICE (-4)
+
+#define QF_ABI_VERSION 1
+#define QF_MAX_LEVELS 16
+#define QF_MAX_LOBES 8
+
+const char *qf_status_string(int status);
+int qf_abi_version(void);
+/* Number of compute units of the current device (host query); <0 on error. */
+int qf_device_cu_count(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Multi-resolution hash grid (tiny-cuda-nn "HashGrid", 3-D, F = 2, linear interpolation).
+ * Replaces tcnn.Encoding / the encoding half of tcnn.NetworkWithInputEncoding as configured at
+ * examples/radiance_fields/ngp.py:340-358,709-727 and examples/field.py:157-171.
+ * qf_grid_desc_init is a HOST computation of the level table.       */
+typedef struct qf_grid_desc {
+    uint32_t n_levels;             /* must be 16 for the field kernels */
+    uint32_t n_features;           /* must be 2 */
+    uint32_t log2_hashmap_size;
+    uint32_t base_resolution;
+    float per_level_scale;
+    uint32_t hashed_mask;          /* bit l set: level l uses the spatial hash */
+    uint32_t offset[QF_MAX_LEVELS + 1]; /* first table row of each level; offset[n_levels] = rows */
+    uint32_t resolution[QF_MAX_LEVELS];
+    float scale[QF_MAX_LEVELS];
+} qf_grid_desc;
+
+int qf_grid_desc_init(qf_grid_desc *desc /* host, out */, uint32_t n_levels,
+                      uint32_t log2_hashmap_size, uint32_t base_resolution,
+                      double per_level_scale);
+
+/* [n,3] positions already in grid space (nominally [0,1]) -> [n,32] features, level-major.
+ * Replaces tcnn.Encoding.forward (field.py:197-199).                                          */
+int qf_grid_encode(const qf_grid_desc *desc /* host */, const float *table /* [rows,2] */,
+                   const float *x01, int64_t n, float *out /* [n,32] */, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Radiance fields.  Replaces NGPRadianceField.query_density/_query_rgb/forward
+ * (ngp.py:757-809) and NGPRadianceFieldSGNew.query_density/_query_rgb/features/forward
+ * (ngp.py:404-470) including the tcnn FullyFusedMLP / SphericalHarmonics / BasicDecoder they
+ * call.  Weight pointers use the reference's state-dict layouts:
+ *   base_w : [64*32 | 16*64] row-major [out,in], no bias (tcnn mlp_base network params)
+ *   head NGP : [64*32 | 64*64 | 16*64] row-major, no bias; input = [SH16 | geo15 | 1.0]
+ *   head SG  : BasicDecoder 15->64->64->(3+7L): w1 [64,15], b1 [64], w2 [64,64], b2 [64],
+ *              wout [3+7L,64], bout [3+7L]                                                    */
+#define QF_HEAD_NONE 0   /* density (+ optional 15 geo features) only */
+#define QF_HEAD_NGP 1    /* SH4 + 2-hidden-layer tcnn head -> sigmoid rgb */
+#define QF_HEAD_SG 2     /* BasicDecoder + spherical-Gaussian mixture -> sigmoid rgb */
+#define QF_HEAD_SG_FEATURES 3 /* BasicDecoder output + density: [n, 3+7L+1] */
+
+typedef struct qf_field_desc {
+    qf_grid_desc grid;
+    float aabb[6];        /* xmin,ymin,zmin,xmax,ymax,zmax (ngp.py:677-678) */
+    int32_t head;         /* QF_HEAD_* */
+    int32_t n_lobes;      /* SG heads: 1..QF_MAX_LOBES */
+} qf_field_desc;
+
+typedef struct qf_sg_head {
+    const float *w1, *b1, *w2, *b2, *wout, *bout;
+} qf_sg_head;
+
+/* xyz [n,3] world positions, dirs [n,3] unit view directions (may be NULL for HEAD_NONE /
+ * HEAD_SG_FEATURES).  Outputs (any may be NULL when not produced by the head):
+ *   rgb [n,3]; sigma [n] (density after exp(x-1)*selector); geo [n,15]; features [n,3+7L+1]. */
+int qf_field_forward(const qf_field_desc *desc /* host */, const float *table,
+                     const float *base_w, const float *head_ngp_w, const qf_sg_head *head_sg /* host */,
+                     const float *xyz, const float *dirs, int64_t n,
+                     float *rgb, float *sigma, float *geo, float *features, void *stream);
+
+/* rgb = sigmoid(diffuse + sum_l c_l exp(|lambda_l| (a_l/|a_l| . d - 1))).
+ * Replaces NGPRadianceFieldSGNew.features_to_rgb (ngp.py:456-461, discretize=False).
+ * features [n, 3+7L] (row stride `feat_stride` floats), dirs [n,3] -> rgb [n,3].              */
+int qf_sg_features_to_rgb(const float *features, int64_t feat_stride, const float *dirs,
+                          int64_t n, int32_t n_lobes, float *rgb, void *stream);
+
+/* Deformation field: examples/field.py Field.density (:186-203) as used at utils.py:555-566:
+ * x01 = (x+scale)/(2 scale); cat[x01, grid(x01)] (35) -> hidden -> hidden -> 1, ReLU, biases.
+ * w1 [hidden,35], b1, w2 [hidden,hidden], b2, wout [1,hidden], bout [1]; hidden must be 32.   */
+int qf_deform_field_forward(const qf_grid_desc *grid /* host */, const float *table, float scale,
+                            int32_t hidden, const float *w1, const float *b1, const float *w2,
+                            const float *b2, const float *wout, const float *bout,
+                            const float *xyz, int64_t n, float *out /* [n] */, void *stream);
+
+/* xyz += (tanh(f)*scaling*(1,1,1) . dir) dir ; ts += same scalar.  utils.py:566-571.          */
+int qf_apply_deformation(const float *f /* [n] */, float scaling, const float *dirs,
+                         float *xyz /* in/out [n,3] */, float *ts /* in/out [n] */, int64_t n,
+                         void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Packed compositing.
+ * kaolin duck-types (kaolin.render.spc, called at utils.py:869-879, mesh_utils.py:407).      */
+int qf_mark_pack_boundaries(const int64_t *ridx, int64_t n, uint8_t *boundary /* [n] bool */,
+                            void *stream);
+/* Segment heads -> out[segment, c] = sum_seg w*feats, weights[n] = exp(-excl cumsum tau)(1-exp(-tau)).
+ * `seg_start` [n_seg] holds the index of the first sample of every segment (ascending),
+ * exclusive != 0 as at utils.py:872.                                                          */
+int qf_exponential_integration(const float *feats /* [n,c] */, int32_t c, const float *tau /* [n] */,
+                               const int64_t *seg_start, int64_t n_seg, int64_t n, int32_t exclusive,
+                               float *out /* [n_seg,c] */, float *weights /* [n] */, void *stream);
+int qf_sum_reduce(const float *feats /* [n,c] */, int32_t c, const int64_t *seg_start,
+                  int64_t n_seg, int64_t n, float *out /* [n_seg,c] */, void *stream);
+
+/* Fused derive_properties (utils.py:863-898) for samples sorted by (ray, depth):
+ * per ray tau = sigma*delta, w = exp(-excl cumsum tau)(1-exp(-tau)); writes the reference's
+ * full-image buffers rgb [n_rays,3], alpha [n_rays,1], depth [n_rays,1] (rays without samples:
+ * white unless bg_mode == black, alpha 0, depth 0) and weights [n].
+ * bg_mode: 0 white, 1 black, 2 "random" (uses bkgd[3]); the double-alpha quirk is reproduced. */
+#define QF_BG_WHITE 0
+#define QF_BG_BLACK 1
+#define QF_BG_CUSTOM 2
+int qf_derive_properties(const float *rgb_s /* [n,3] */, const float *sigma /* [n] */,
+                         const float *depth /* [n] */, const float *deltas /* [n] or NULL */,
+                         float delta_const, const int64_t *index_ray /* [n] */, int64_t n,
+                         int64_t n_rays, int32_t bg_mode, const float *bkgd /* [3] or NULL */,
+                         float *out_rgb, float *out_alpha, float *out_depth, float *weights,
+                         void *stream);
+
+/* nerfacc duck-types (nerfacc.pack / nerfacc.scan, imported at field_rendering.py:10-11).     */
+int qf_pack_info(const int64_t *ray_indices /* sorted, [n] */, int64_t n, int64_t n_rays,
+                 int64_t *packed_info /* [n_rays,2] = (start,count) */, void *stream);
+/* mode 0: exclusive sum, 1: exclusive product, per chunk of packed_info.                      */
+int qf_exclusive_scan(const float *x, const int64_t *packed_info, int64_t n_rays, int64_t n,
+                      int32_t mode, float *out, void *stream);
+/* out[ray, :] += w_i * values_i (values NULL: accumulate w).  field_rendering.py:483-573.
+ * Deterministic: per-ray sequential over packed_info, no atomics.                            */
+int qf_accumulate_along_rays(const float *weights, const float *values /* [n,c] or NULL */,
+                             int32_t c, const int64_t *packed_info, int64_t n_rays, int64_t n,
+                             float *out /* [n_rays,c], overwritten */, void *stream);
+/* Fused render_weight_from_density + the three accumulate_along_rays of `rendering`
+ * (field_rendering.py:100-156): trans/alphas/weights [n] and colors[n_rays,3],
+ * opacities[n_rays,1], depths[n_rays,1] (already divided by clamp_min(opacity, eps) and with
+ * bkgd*(1-opacity) added when bkgd != NULL).                                                  */
+int qf_render_from_density(const float *t_starts, const float *t_ends, const float *sigmas,
+                           const float *rgbs /* [n,3] */, const int64_t *packed_info,
+                           int64_t n_rays, int64_t n, const float *bkgd /* [3] or NULL */,
+                           float *weights, float *trans, float *alphas, float *colors,
+                           float *opacities, float *depths, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Ray / mesh quadrature points.
+ * Replaces trimesh RayMeshIntersector (mesh_utils.py:223,350-354), the OptiX module
+ * build.lib.intersector (mesh_utils.py:77-96: Intersector(vertices, max_hits, device),
+ * find_intersections, update_vertices) and the CPU sort of sampling_raytrace_numpy /
+ * sampling_indexing (mesh_utils.py:359-381,394-403).                                          */
+typedef struct qf_bvh qf_bvh; /* opaque; owns device memory */
+
+/* tri_verts: HOST pointer, [n_tri][3][3] fp32 (the layout of mesh.vertices[mesh.faces]).
+ * Builds a SAH BVH on the host and uploads it.                                                */
+int qf_bvh_create(const float *tri_verts /* host */, int64_t n_tri, qf_bvh **out);
+/* Same topology, new vertex positions (Intersector.update_vertices / train_finetune.py:716-718). */
+int qf_bvh_refit(qf_bvh *bvh, const float *tri_verts /* host */, int64_t n_tri);
+void qf_bvh_destroy(qf_bvh *bvh);
+int64_t qf_bvh_num_triangles(const qf_bvh *bvh);
+int64_t qf_bvh_num_nodes(const qf_bvh *bvh);
+/* Host copies for inspection/tests: nodes as 16 floats each, leaf triangle ids. */
+int qf_bvh_copy_nodes(const qf_bvh *bvh, float *nodes_host, int64_t capacity_nodes);
+int qf_bvh_copy_tri_ids(const qf_bvh *bvh, int32_t *ids_host, int64_t capacity);
+
+/* Up to max_hits nearest hits per ray, ascending by (t, triangle id).
+ * rays_o, rays_d [n_rays,3]; hit_tri/hit_t [n_rays,max_hits] (unused slots -1 / +inf);
+ * hit_count [n_rays].  image_width > 0: rays are a row-major image of that width and are
+ * traversed in 8x8 pixel tiles (speed only; results identical).
+ * Also the shape of Intersector.find_intersections (int[R*max_hits], -1 padded).             */
+int qf_bvh_intersect(const qf_bvh *bvh, const float *rays_o, const float *rays_d, int64_t n_rays,
+                     int32_t max_hits, int32_t image_width, int32_t *hit_tri, float *hit_t,
+                     int32_t *hit_count, void *stream);
+
+/* Packs the per-ray hit lists into the sample arrays sampling_raytrace_numpy returns
+ * (mesh_utils.py:359-387), already sorted by (ray, depth): location = o + t d in float64,
+ * dirs = d/(|d|+1e-7), depth = |location - o| (float64, rounded to fp32 at the end).
+ * ray_offset [n_rays] = exclusive prefix sum of hit_count.                                     */
+int qf_pack_samples(const float *rays_o, const float *rays_d, int64_t n_rays, int32_t max_hits,
+                    const int32_t *hit_tri, const float *hit_t, const int32_t *hit_count,
+                    const int64_t *ray_offset, float *xyz, float *dirs, int64_t *index_ray,
+                    float *depth, int64_t *index_tri, float *origins, void *stream);
+
+/* Stable per-ray re-sort by depth after deformation (sampling_indexing, mesh_utils.py:394-403):
+ * perm[i] = source index of the sample that lands at i.  index_ray must be grouped by ray.   */
+int qf_resort_by_depth(const int64_t *index_ray, const float *depth, int64_t n, int64_t *perm,
+                       void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Baked spherical-Gaussian textures.
+ * Replaces trimesh.triangles.points_to_barycentric + the UV lookup (utils.py:1055-1063) and
+ * FeatureCompression.get_features_from_texture_map (texture_utils.py:149-175) with the
+ * dequantisers of ngp.py:245-281 and texture_utils.py:61-65.                                 */
+typedef struct qf_texture_set {
+    const uint8_t *alpha;                    /* [T,T] */
+    const uint8_t *diffuse;                  /* [T,T,3] */
+    const uint8_t *colors[QF_MAX_LOBES];     /* [T,T,3] each */
+    const uint8_t *lambda_axis[QF_MAX_LOBES];/* [T,T,3] each: (lambda, azimuth, elevation) */
+    int32_t texture_size;
+    int32_t n_lobes;
+    int32_t sigmoid_codec;                   /* 1 only when compression_type == "sigma" (B-7) */
+    float lambda_thres;
+} qf_texture_set;
+
+/* vertices: float64 [V,3] (trimesh keeps float64); faces int64 [F,3]; uv fp32 [V,2] pre-scaled
+ * by T as at test_baking_texture_images.py:325-328.  texel [n,2] int64 (row, col).           */
+int qf_texel_indices(const double *vertices, const int64_t *faces, const float *uv,
+                     const float *points, const int64_t *index_tri, int64_t n,
+                     int32_t texture_size, int64_t *texel, void *stream);
+/* texel [n,2] -> features [n, 3+7L+1] = [diffuse3 | (axis3, lambda, colour3)*L | sigma].      */
+int qf_texture_fetch(const qf_texture_set *tex /* host */, const int64_t *texel, int64_t n,
+                     float *features, void *stream);
+/* Fused: texel fetch + dequantise + SG -> rgb [n,3], sigma [n] (no feature round trip).       */
+int qf_texture_shade(const qf_texture_set *tex /* host */, const int64_t *texel,
+                     const float *dirs, int64_t n, float *rgb, float *sigma, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QF_HIP_H */

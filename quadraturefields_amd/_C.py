@@ -1,0 +1,147 @@
+"""ctypes binding of libqf_hip.so (the C ABI declared in include/qf_hip.h).
+
+There is no CPU fallback: if the library is missing or a call fails, this raises.  torch is only
+used for device memory and streams; every tensor crosses the boundary as a raw device pointer.
+"""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_uint8, c_uint32, c_void_p
+
+import torch
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libqf_hip.so")
+
+QF_MAX_LEVELS = 16
+QF_MAX_LOBES = 8
+QF_BVH_MAX_HITS = 64
+HEAD_NONE, HEAD_NGP, HEAD_SG, HEAD_SG_FEATURES = 0, 1, 2, 3
+BG_WHITE, BG_BLACK, BG_CUSTOM = 0, 1, 2
+
+
+class GridDesc(Structure):
+    _fields_ = [
+        ("n_levels", c_uint32), ("n_features", c_uint32), ("log2_hashmap_size", c_uint32),
+        ("base_resolution", c_uint32), ("per_level_scale", c_float), ("hashed_mask", c_uint32),
+        ("offset", c_uint32 * (QF_MAX_LEVELS + 1)), ("resolution", c_uint32 * QF_MAX_LEVELS),
+        ("scale", c_float * QF_MAX_LEVELS),
+    ]
+
+
+class FieldDesc(Structure):
+    _fields_ = [("grid", GridDesc), ("aabb", c_float * 6), ("head", c_int32), ("n_lobes", c_int32)]
+
+
+class SGHead(Structure):
+    _fields_ = [("w1", c_void_p), ("b1", c_void_p), ("w2", c_void_p), ("b2", c_void_p),
+                ("wout", c_void_p), ("bout", c_void_p)]
+
+
+class TextureSet(Structure):
+    _fields_ = [("alpha", c_void_p), ("diffuse", c_void_p), ("colors", c_void_p * QF_MAX_LOBES),
+                ("lambda_axis", c_void_p * QF_MAX_LOBES), ("texture_size", c_int32), ("n_lobes", c_int32),
+                ("sigmoid_codec", c_int32), ("lambda_thres", c_float)]
+
+
+_P = c_void_p
+_SIGNATURES = {
+    "qf_status_string": (c_char_p, [c_int]),
+    "qf_abi_version": (c_int, []),
+    "qf_device_cu_count": (c_int, []),
+    "qf_grid_desc_init": (c_int, [POINTER(GridDesc), c_uint32, c_uint32, c_uint32, c_double]),
+    "qf_grid_encode": (c_int, [POINTER(GridDesc), _P, _P, c_int64, _P, _P]),
+    "qf_field_forward": (c_int, [POINTER(FieldDesc), _P, _P, _P, POINTER(SGHead), _P, _P, c_int64, _P, _P, _P, _P, _P]),
+    "qf_sg_features_to_rgb": (c_int, [_P, c_int64, _P, c_int64, c_int32, _P, _P]),
+    "qf_deform_field_forward": (c_int, [POINTER(GridDesc), _P, c_float, c_int32, _P, _P, _P, _P, _P, _P, _P, c_int64, _P, _P]),
+    "qf_apply_deformation": (c_int, [_P, c_float, _P, _P, _P, c_int64, _P]),
+    "qf_mark_pack_boundaries": (c_int, [_P, c_int64, _P, _P]),
+    "qf_exponential_integration": (c_int, [_P, c_int32, _P, _P, c_int64, c_int64, c_int32, _P, _P, _P]),
+    "qf_sum_reduce": (c_int, [_P, c_int32, _P, c_int64, c_int64, _P, _P]),
+    "qf_derive_properties": (c_int, [_P, _P, _P, _P, c_float, _P, c_int64, c_int64, c_int32, _P, _P, _P, _P, _P, _P]),
+    "qf_pack_info": (c_int, [_P, c_int64, c_int64, _P, _P]),
+    "qf_exclusive_scan": (c_int, [_P, _P, c_int64, c_int64, c_int32, _P, _P]),
+    "qf_accumulate_along_rays": (c_int, [_P, _P, c_int32, _P, c_int64, c_int64, _P, _P]),
+    "qf_render_from_density": (c_int, [_P, _P, _P, _P, _P, c_int64, c_int64, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "qf_bvh_create": (c_int, [_P, c_int64, POINTER(c_void_p)]),
+    "qf_bvh_refit": (c_int, [_P, _P, c_int64]),
+    "qf_bvh_destroy": (None, [_P]),
+    "qf_bvh_num_triangles": (c_int64, [_P]),
+    "qf_bvh_num_nodes": (c_int64, [_P]),
+    "qf_bvh_copy_nodes": (c_int, [_P, _P, c_int64]),
+    "qf_bvh_copy_tri_ids": (c_int, [_P, _P, c_int64]),
+    "qf_bvh_intersect": (c_int, [_P, _P, _P, c_int64, c_int32, c_int32, _P, _P, _P, _P]),
+    "qf_pack_samples": (c_int, [_P, _P, c_int64, c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "qf_resort_by_depth": (c_int, [_P, _P, c_int64, _P, _P]),
+    "qf_texel_indices": (c_int, [_P, _P, _P, _P, _P, c_int64, c_int32, _P, _P]),
+    "qf_texture_fetch": (c_int, [POINTER(TextureSet), _P, c_int64, _P, _P]),
+    "qf_texture_shade": (c_int, [POINTER(TextureSet), _P, _P, c_int64, _P, _P, _P]),
+}
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+_lib = None
+
+
+def lib() -> ctypes.CDLL:
+    """Load libqf_hip.so (once).  Raises if it has not been built -- there is no fallback path."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -m quadraturefields_amd.build` "
+                "(hipcc --offload-arch=gfx950).  quadraturefields_amd has no CPU fallback.")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (restype, argtypes) in _SIGNATURES.items():
+            fn = getattr(handle, name)   # AttributeError if the symbol is not exported
+            fn.restype = restype
+            fn.argtypes = argtypes
+        if handle.qf_abi_version() != 1:
+            raise RuntimeError("libqf_hip.so ABI version mismatch")
+        _lib = handle
+    return _lib
+
+
+class QFError(RuntimeError):
+    pass
+
+
+def check(status: int, what: str = "") -> None:
+    if status != 0:
+        msg = lib().qf_status_string(status).decode()
+        if status == -1:
+            raise ValueError(f"{what}: {msg}")
+        raise QFError(f"{what}: {msg} (status {status})")
+
+
+def ptr(t, dtype=None, device_required: bool = True):
+    """Raw pointer of a contiguous tensor (None -> NULL).  The HIP kernels only accept device memory."""
+    if t is None:
+        return None
+    if not isinstance(t, torch.Tensor):
+        raise TypeError("expected a torch.Tensor")
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError(f"expected dtype {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError("tensor must be contiguous")
+    if device_required and not t.is_cuda:
+        raise RuntimeError("quadraturefields_amd kernels need tensors on the HIP device (no CPU fallback)")
+    return c_void_p(t.data_ptr())
+
+
+def stream():
+    """The current torch HIP stream as a raw handle."""
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def f32c(t: torch.Tensor) -> torch.Tensor:
+    return t.to(torch.float32).contiguous()
+
+
+def i64c(t: torch.Tensor) -> torch.Tensor:
+    return t.to(torch.int64).contiguous()
+
+
+def make_grid_desc(n_levels: int, log2_hashmap_size: int, base_resolution: int, per_level_scale: float) -> GridDesc:
+    d = GridDesc()
+    check(lib().qf_grid_desc_init(ctypes.byref(d), n_levels, log2_hashmap_size, base_resolution,
+                                  float(per_level_scale)), "qf_grid_desc_init")
+    return d

@@ -1,0 +1,306 @@
+// Packed per-ray compositing for gfx950.
+//
+// Replaces kaolin.render.spc mark_pack_boundaries / exponential_integration / sum_reduce as called by
+// derive_properties (examples/utils.py:863-898), and nerfacc pack_info / exclusive_sum /
+// exclusive_prod + the index_add_ accumulations of examples/field_rendering.py:100-156,483-573.
+//
+// A ray of the mesh path carries at most max_hits (25) samples, so every segmented scan here is a
+// short sequential loop owned by one lane: deterministic summation order, no atomics, no
+// intermediate cumsum tensors.  The kernels are HBM-bound on 20 B/sample (sigma, rgb, t).
+#include "qf_common.h"
+
+namespace {
+
+__global__ void mark_boundaries_kernel(const int64_t *ridx, int64_t n, uint8_t *b)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        b[i] = (i == 0) || (ridx[i] != ridx[i - 1]);
+}
+
+__global__ void fill_background_kernel(int64_t n_rays, float bg, float *rgb, float *alpha, float *depth)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_rays; i += (int64_t)gridDim.x * blockDim.x) {
+        rgb[i * 3 + 0] = bg;
+        rgb[i * 3 + 1] = bg;
+        rgb[i * 3 + 2] = bg;
+        alpha[i] = 0.0f;
+        depth[i] = 0.0f;
+    }
+}
+
+// One lane per sample; the lane that sits on a ray's first sample integrates the whole ray.
+__global__ void derive_properties_kernel(const float *rgb_s, const float *sigma, const float *depth_s,
+                                         const float *deltas, float delta_const, const int64_t *index_ray,
+                                         int64_t n, int bg_mode, const float *bkgd, float *out_rgb,
+                                         float *out_alpha, float *out_depth, float *weights)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t ray = index_ray[i];
+        if (i != 0 && index_ray[i - 1] == ray) continue;
+        float cum = 0.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f, cd = 0.0f, ca = 0.0f;
+        for (int64_t j = i; j < n && index_ray[j] == ray; ++j) {
+            const float tau = sigma[j] * (deltas ? deltas[j] : delta_const);
+            const float w = expf(-cum) * (1.0f - expf(-tau));
+            cum += tau;
+            weights[j] = w;
+            cr += w * rgb_s[j * 3 + 0];
+            cg += w * rgb_s[j * 3 + 1];
+            cb += w * rgb_s[j * 3 + 2];
+            cd += w * depth_s[j];
+            ca += w;
+        }
+        float r, g, b;
+        if (bg_mode == QF_BG_WHITE) {          // (1 - a) + a * sum(w c): the double-alpha quirk (B-1)
+            r = (1.0f - ca) + ca * cr;
+            g = (1.0f - ca) + ca * cg;
+            b = (1.0f - ca) + ca * cb;
+        } else if (bg_mode == QF_BG_BLACK) {
+            r = ca * cr;
+            g = ca * cg;
+            b = ca * cb;
+        } else {
+            r = ca * cr + (1.0f - ca) * bkgd[0];
+            g = ca * cg + (1.0f - ca) * bkgd[1];
+            b = ca * cb + (1.0f - ca) * bkgd[2];
+        }
+        out_rgb[ray * 3 + 0] = r;
+        out_rgb[ray * 3 + 1] = g;
+        out_rgb[ray * 3 + 2] = b;
+        out_alpha[ray] = ca;
+        out_depth[ray] = cd;
+    }
+}
+
+__global__ void exp_integration_kernel(const float *feats, int c, const float *tau, const int64_t *seg_start,
+                                       int64_t n_seg, int64_t n, int exclusive, float *out, float *weights)
+{
+    const int64_t total = n_seg * c;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t s = e / c;
+        const int ch = (int)(e - s * c);
+        const int64_t b = seg_start[s], end = (s + 1 < n_seg) ? seg_start[s + 1] : n;
+        float cum = 0.0f, acc = 0.0f;
+        for (int64_t j = b; j < end; ++j) {
+            const float t = tau[j];
+            if (!exclusive) cum += t;
+            const float w = expf(-cum) * (1.0f - expf(-t));
+            if (exclusive) cum += t;
+            if (ch == 0) weights[j] = w;
+            acc += w * feats[j * c + ch];
+        }
+        out[e] = acc;
+    }
+}
+
+__global__ void sum_reduce_kernel(const float *feats, int c, const int64_t *seg_start, int64_t n_seg, int64_t n,
+                                  float *out)
+{
+    const int64_t total = n_seg * c;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t s = e / c;
+        const int ch = (int)(e - s * c);
+        const int64_t b = seg_start[s], end = (s + 1 < n_seg) ? seg_start[s + 1] : n;
+        float acc = 0.0f;
+        for (int64_t j = b; j < end; ++j) acc += feats[j * c + ch];
+        out[e] = acc;
+    }
+}
+
+// (start, count) per ray by binary search in the sorted ray ids.
+__global__ void pack_info_kernel(const int64_t *ridx, int64_t n, int64_t n_rays, int64_t *packed)
+{
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_rays; r += (int64_t)gridDim.x * blockDim.x) {
+        int64_t lo = 0, hi = n;
+        while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (ridx[mid] < r) lo = mid + 1; else hi = mid; }
+        const int64_t start = lo;
+        hi = n;
+        while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (ridx[mid] <= r) lo = mid + 1; else hi = mid; }
+        packed[2 * r] = start;
+        packed[2 * r + 1] = lo - start;
+    }
+}
+
+__global__ void exclusive_scan_kernel(const float *x, const int64_t *packed, int64_t n_rays, int mode, float *out)
+{
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_rays; r += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = packed[2 * r], cnt = packed[2 * r + 1];
+        float acc = mode ? 1.0f : 0.0f;
+        for (int64_t j = b; j < b + cnt; ++j) {
+            out[j] = acc;
+            acc = mode ? acc * x[j] : acc + x[j];
+        }
+    }
+}
+
+__global__ void accumulate_kernel(const float *w, const float *values, int c, const int64_t *packed, int64_t n_rays,
+                                  float *out)
+{
+    const int64_t total = n_rays * c;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = e / c;
+        const int ch = (int)(e - r * c);
+        const int64_t b = packed[2 * r], cnt = packed[2 * r + 1];
+        float acc = 0.0f;
+        for (int64_t j = b; j < b + cnt; ++j) acc += values ? w[j] * values[j * c + ch] : w[j];
+        out[e] = acc;
+    }
+}
+
+__global__ void render_from_density_kernel(const float *ts, const float *te, const float *sigmas, const float *rgbs,
+                                           const int64_t *packed, int64_t n_rays, const float *bkgd, float *weights, float *trans, float *alphas, float *colors,
+                                           float *opac, float *depths)
+{
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_rays; r += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = packed[2 * r], cnt = packed[2 * r + 1];
+        float cum = 0.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f, cd = 0.0f, ca = 0.0f;
+        for (int64_t j = b; j < b + cnt; ++j) {
+            const float sdt = sigmas[j] * (te[j] - ts[j]);
+            const float al = 1.0f - expf(-sdt);
+            const float T = expf(-cum);
+            const float w = T * al;
+            cum += sdt;
+            weights[j] = w;
+            trans[j] = T;
+            alphas[j] = al;
+            cr += w * rgbs[j * 3 + 0];
+            cg += w * rgbs[j * 3 + 1];
+            cb += w * rgbs[j * 3 + 2];
+            cd += w * ((ts[j] + te[j]) / 2.0f);
+            ca += w;
+        }
+        const float eps = 1.1920928955078125e-07f;   // torch.finfo(float32).eps
+        const float d = cd / fmaxf(ca, eps);
+        if (bkgd) {
+            cr += bkgd[0] * (1.0f - ca);
+            cg += bkgd[1] * (1.0f - ca);
+            cb += bkgd[2] * (1.0f - ca);
+        }
+        colors[r * 3 + 0] = cr;
+        colors[r * 3 + 1] = cg;
+        colors[r * 3 + 2] = cb;
+        opac[r] = ca;
+        depths[r] = d;
+    }
+}
+
+__global__ void apply_deformation_kernel(const float *f, float scaling, const float *dirs, float *xyz, float *ts, int64_t n)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float v = tanhf(f[i]) * scaling;
+        const float dx = dirs[i * 3], dy = dirs[i * 3 + 1], dz = dirs[i * 3 + 2];
+        const float dd = (v * dx + v * dy) + v * dz;     // (del_vector * dirs).sum(-1), utils.py:567
+        xyz[i * 3 + 0] += dd * dx;
+        xyz[i * 3 + 1] += dd * dy;
+        xyz[i * 3 + 2] += dd * dz;
+        ts[i] += dd;
+    }
+}
+
+}  // namespace
+
+#define QF_SIMPLE_LAUNCH(kernel, count, ...)                                                            \
+    hipLaunchKernelGGL(kernel, dim3(qf_grid_1d((count), 256)), dim3(256), 0, qf_stream(stream), __VA_ARGS__); \
+    QF_LAUNCH_CHECK();
+
+extern "C" int qf_mark_pack_boundaries(const int64_t *ridx, int64_t n, uint8_t *boundary, void *stream)
+{
+    if (n < 0) return QF_ERR_INVALID_ARGUMENT;
+    if (n == 0) return QF_OK;
+    if (!ridx || !boundary) return QF_ERR_INVALID_ARGUMENT;
+    QF_SIMPLE_LAUNCH(mark_boundaries_kernel, n, ridx, n, boundary);
+    return QF_OK;
+}
+
+extern "C" int qf_exponential_integration(const float *feats, int32_t c, const float *tau, const int64_t *seg_start,
+                                          int64_t n_seg, int64_t n, int32_t exclusive, float *out, float *weights,
+                                          void *stream)
+{
+    if (n < 0 || n_seg < 0 || c < 1) return QF_ERR_INVALID_ARGUMENT;
+    if (n_seg == 0) return QF_OK;
+    if (!feats || !tau || !seg_start || !out || !weights) return QF_ERR_INVALID_ARGUMENT;
+    QF_SIMPLE_LAUNCH(exp_integration_kernel, n_seg * c, feats, (int)c, tau, seg_start, n_seg, n, (int)exclusive, out,
+                     weights);
+    return QF_OK;
+}
+
+extern "C" int qf_sum_reduce(const float *feats, int32_t c, const int64_t *seg_start, int64_t n_seg, int64_t n,
+                             float *out, void *stream)
+{
+    if (n < 0 || n_seg < 0 || c < 1) return QF_ERR_INVALID_ARGUMENT;
+    if (n_seg == 0) return QF_OK;
+    if (!feats || !seg_start || !out) return QF_ERR_INVALID_ARGUMENT;
+    QF_SIMPLE_LAUNCH(sum_reduce_kernel, n_seg * c, feats, (int)c, seg_start, n_seg, n, out);
+    return QF_OK;
+}
+
+extern "C" int qf_derive_properties(const float *rgb_s, const float *sigma, const float *depth, const float *deltas,
+                                    float delta_const, const int64_t *index_ray, int64_t n, int64_t n_rays,
+                                    int32_t bg_mode, const float *bkgd, float *out_rgb, float *out_alpha,
+                                    float *out_depth, float *weights, void *stream)
+{
+    if (n < 0 || n_rays < 0 || bg_mode < 0 || bg_mode > 2) return QF_ERR_INVALID_ARGUMENT;
+    if (n_rays > 0 && (!out_rgb || !out_alpha || !out_depth)) return QF_ERR_INVALID_ARGUMENT;
+    if (bg_mode == QF_BG_CUSTOM && !bkgd) return QF_ERR_INVALID_ARGUMENT;
+    if (n_rays > 0) {
+        QF_SIMPLE_LAUNCH(fill_background_kernel, n_rays, n_rays, bg_mode == QF_BG_BLACK ? 0.0f : 1.0f, out_rgb,
+                         out_alpha, out_depth);
+    }
+    if (n == 0) return QF_OK;
+    if (!rgb_s || !sigma || !depth || !index_ray || !weights) return QF_ERR_INVALID_ARGUMENT;
+    QF_SIMPLE_LAUNCH(derive_properties_kernel, n, rgb_s, sigma, depth, deltas, delta_const, index_ray, n, (int)bg_mode,
+                     bkgd, out_rgb, out_alpha, out_depth, weights);
+    return QF_OK;
+}
+
+extern "C" int qf_pack_info(const int64_t *ray_indices, int64_t n, int64_t n_rays, int64_t *packed_info, void *stream)
+{
+    if (n < 0 || n_rays < 0) return QF_ERR_INVALID_ARGUMENT;
+    if (n_rays == 0) return QF_OK;
+    if ((n > 0 && !ray_indices) || !packed_info) return QF_ERR_INVALID_ARGUMENT;
+    QF_SIMPLE_LAUNCH(pack_info_kernel, n_rays, ray_indices, n, n_rays, packed_info);
+    return QF_OK;
+}
+
+extern "C" int qf_exclusive_scan(const float *x, const int64_t *packed_info, int64_t n_rays, int64_t n, int32_t mode,
+                                 float *out, void *stream)
+{
+    if (n < 0 || n_rays < 0 || (mode != 0 && mode != 1)) return QF_ERR_INVALID_ARGUMENT;
+    if (n == 0 || n_rays == 0) return QF_OK;
+    if (!x || !packed_info || !out) return QF_ERR_INVALID_ARGUMENT;
+    QF_SIMPLE_LAUNCH(exclusive_scan_kernel, n_rays, x, packed_info, n_rays, (int)mode, out);
+    return QF_OK;
+}
+
+extern "C" int qf_accumulate_along_rays(const float *weights, const float *values, int32_t c,
+                                        const int64_t *packed_info, int64_t n_rays, int64_t n, float *out, void *stream)
+{
+    if (n < 0 || n_rays < 0 || c < 1) return QF_ERR_INVALID_ARGUMENT;
+    if (n_rays == 0) return QF_OK;
+    if ((n > 0 && !weights) || !packed_info || !out) return QF_ERR_INVALID_ARGUMENT;
+    QF_SIMPLE_LAUNCH(accumulate_kernel, n_rays * c, weights, values, (int)c, packed_info, n_rays, out);
+    return QF_OK;
+}
+
+extern "C" int qf_render_from_density(const float *t_starts, const float *t_ends, const float *sigmas,
+                                      const float *rgbs, const int64_t *packed_info, int64_t n_rays, int64_t n,
+                                      const float *bkgd, float *weights, float *trans, float *alphas, float *colors,
+                                      float *opacities, float *depths, void *stream)
+{
+    if (n < 0 || n_rays < 0) return QF_ERR_INVALID_ARGUMENT;
+    if (n_rays == 0) return QF_OK;
+    if (!packed_info || !colors || !opacities || !depths) return QF_ERR_INVALID_ARGUMENT;
+    if (n > 0 && (!t_starts || !t_ends || !sigmas || !rgbs || !weights || !trans || !alphas)) return QF_ERR_INVALID_ARGUMENT;
+    QF_SIMPLE_LAUNCH(render_from_density_kernel, n_rays, t_starts, t_ends, sigmas, rgbs, packed_info, n_rays,
+                     bkgd, weights, trans, alphas, colors, opacities, depths);
+    return QF_OK;
+}
+
+extern "C" int qf_apply_deformation(const float *f, float scaling, const float *dirs, float *xyz, float *ts, int64_t n,
+                                    void *stream)
+{
+    if (n < 0) return QF_ERR_INVALID_ARGUMENT;
+    if (n == 0) return QF_OK;
+    if (!f || !dirs || !xyz || !ts) return QF_ERR_INVALID_ARGUMENT;
+    QF_SIMPLE_LAUNCH(apply_deformation_kernel, n, f, scaling, dirs, xyz, ts, n);
+    return QF_OK;
+}

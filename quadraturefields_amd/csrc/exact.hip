@@ -1,0 +1,475 @@
+// Index-exact kernels for gfx950: BVH multi-hit traversal, sample packing / per-ray sorting, texel
+// lookup and baked-texture decode.  This translation unit is compiled with -ffp-contract=off: every
+// comparison that decides an INTEGER output (triangle id, hit count, sample order, texel index) uses a
+// fixed sequence of individually rounded IEEE operations, restated independently by the oracle
+// (oracle/intersect_ref.c, oracle/quantize.py), so those outputs are bit-exact against it.
+//
+// Replaces: trimesh/Embree `intersects_id` and the OptiX
+// `Intersector.find_intersections` (examples/mesh_utils.py:77-96,350-354), the numpy argsort/lexsort
+// of sampling_raytrace_numpy / sampling_indexing (mesh_utils.py:359-381,394-403),
+// trimesh.triangles.points_to_barycentric + UV lookup (examples/utils.py:1055-1063) and
+// FeatureCompression.get_features_from_texture_map (examples/texture_utils.py:149-175).
+#include "qf_common.h"
+#include "bvh.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+constexpr int kMaxHits = QF_BVH_MAX_HITS;
+constexpr int kStack = 64;
+
+// fp32 Moller-Trumbore, operation order shared verbatim (as a contract, not as code) with the oracle.
+__device__ __forceinline__ bool mt_hit(const float4 a, const float4 b, const float4 c, const float ox, const float oy,
+                                       const float oz, const float dx, const float dy, const float dz, float *t_out)
+{
+    const float e1x = b.x - a.x, e1y = b.y - a.y, e1z = b.z - a.z;
+    const float e2x = c.x - a.x, e2y = c.y - a.y, e2z = c.z - a.z;
+    const float px = dy * e2z - dz * e2y;
+    const float py = dz * e2x - dx * e2z;
+    const float pz = dx * e2y - dy * e2x;
+    const float det = (e1x * px + e1y * py) + e1z * pz;
+    if (!(det != 0.0f)) return false;
+    const float inv = 1.0f / det;
+    const float tx = ox - a.x, ty = oy - a.y, tz = oz - a.z;
+    const float u = ((tx * px + ty * py) + tz * pz) * inv;
+    if (!(u >= 0.0f && u <= 1.0f)) return false;
+    const float qx = ty * e1z - tz * e1y;
+    const float qy = tz * e1x - tx * e1z;
+    const float qz = tx * e1y - ty * e1x;
+    const float v = ((dx * qx + dy * qy) + dz * qz) * inv;
+    if (!(v >= 0.0f && u + v <= 1.0f)) return false;
+    const float t = ((e2x * qx + e2y * qy) + e2z * qz) * inv;
+    if (!(t > 0.0f)) return false;
+    *t_out = t;
+    return true;
+}
+
+__device__ __forceinline__ float safe_inv(float d)
+{
+    const float tiny = 1e-30f;
+    if (fabsf(d) < tiny) d = (d < 0.0f || (d == 0.0f && signbit(d))) ? -tiny : tiny;
+    return 1.0f / d;
+}
+
+// Conservative slab test: boxes were inflated on the host; the exit distance is widened by 2 ulp-ish.
+__device__ __forceinline__ bool box_hit(const float lox, const float loy, const float loz, const float hix,
+                                        const float hiy, const float hiz, const float ox, const float oy, const float oz,
+                                        const float ix, const float iy, const float iz, const float t_limit, float *t_near)
+{
+    const float ax = (lox - ox) * ix, bx = (hix - ox) * ix;
+    const float ay = (loy - oy) * iy, by = (hiy - oy) * iy;
+    const float az = (loz - oz) * iz, bz = (hiz - oz) * iz;
+    const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
+    const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz)) * 1.0000005f;
+    *t_near = tn;
+    return tn <= tf && tn * 0.999999f <= t_limit;
+}
+
+// (t, tri) lexicographic "a sorts before b"
+__device__ __forceinline__ bool hit_less(float ta, int ia, float tb, int ib) { return ta < tb || (ta == tb && ia < ib); }
+
+__global__ __launch_bounds__(64) void bvh_traverse_kernel(const float4 *__restrict__ nodes, const float4 *__restrict__ tris,
+                                                          int root_is_valid, const float *__restrict__ rays_o,
+                                                          const float *__restrict__ rays_d, int64_t n_rays, int max_hits,
+                                                          int image_width, int image_height, int tiles_x,
+                                                          int32_t *__restrict__ hit_tri, float *__restrict__ hit_t,
+                                                          int32_t *__restrict__ hit_count)
+{
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t ray;
+    if (image_width > 0) {
+        const int64_t tile = tid >> 6;
+        const int in = (int)(tid & 63);
+        const int px = (int)(tile % tiles_x) * 8 + (in & 7);
+        const int py = (int)(tile / tiles_x) * 8 + (in >> 3);
+        if (px >= image_width || py >= image_height) return;
+        ray = (int64_t)py * image_width + px;
+    } else {
+        ray = tid;
+    }
+    if (ray >= n_rays) return;
+
+    const float ox = rays_o[ray * 3], oy = rays_o[ray * 3 + 1], oz = rays_o[ray * 3 + 2];
+    const float dx = rays_d[ray * 3], dy = rays_d[ray * 3 + 1], dz = rays_d[ray * 3 + 2];
+    const float ix = safe_inv(dx), iy = safe_inv(dy), iz = safe_inv(dz);
+    float *my_t = hit_t + ray * max_hits;
+    int32_t *my_tri = hit_tri + ray * max_hits;
+
+    int count = 0;
+    float worst_t = INFINITY;      // valid once the list is full: its lexicographically largest entry
+    int worst_tri = 0x7fffffff, worst_slot = -1;
+    float t_limit = INFINITY;
+
+    int stack[kStack];
+    int sp = 0;
+    int node = root_is_valid ? 0 : -1;
+    while (node >= 0) {
+        const float4 n0 = nodes[node * 4 + 0];   // c0.lo.xyz, c0.hi.x
+        const float4 n1 = nodes[node * 4 + 1];   // c0.hi.yz, c1.lo.xy
+        const float4 n2 = nodes[node * 4 + 2];   // c1.lo.z, c1.hi.xyz
+        const float4 n3 = nodes[node * 4 + 3];   // child0, child1, count0, count1 (int bits)
+        float tn0, tn1;
+        const bool h0 = box_hit(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, ox, oy, oz, ix, iy, iz, t_limit, &tn0);
+        const bool h1 = box_hit(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, ox, oy, oz, ix, iy, iz, t_limit, &tn1);
+        const int c0 = __float_as_int(n3.x), c1 = __float_as_int(n3.y);
+        const int k0 = __float_as_int(n3.z), k1 = __float_as_int(n3.w);
+        int next = -1;
+#pragma unroll
+        for (int side = 0; side < 2; ++side) {
+            // leaves are tested immediately; inner children are queued near-first
+            const bool hit = side ? h1 : h0;
+            const int child = side ? c1 : c0;
+            const int cnt = side ? k1 : k0;
+            if (!hit || child >= 0) continue;
+            const int first = ~child;
+            for (int k = 0; k < cnt; ++k) {
+                const float4 a = tris[(first + k) * 3 + 0];
+                const float4 b = tris[(first + k) * 3 + 1];
+                const float4 c = tris[(first + k) * 3 + 2];
+                float t;
+                if (!mt_hit(a, b, c, ox, oy, oz, dx, dy, dz, &t)) continue;
+                const int id = __float_as_int(a.w);
+                if (count < max_hits) {
+                    my_t[count] = t;
+                    my_tri[count] = id;
+                    ++count;
+                    if (count == max_hits) worst_slot = -1;   // recompute below
+                } else if (hit_less(t, id, worst_t, worst_tri)) {
+                    my_t[worst_slot] = t;
+                    my_tri[worst_slot] = id;
+                    worst_slot = -1;
+                } else {
+                    continue;
+                }
+                if (count == max_hits && worst_slot < 0) {
+                    worst_t = -INFINITY;
+                    worst_tri = -1;
+                    for (int s = 0; s < max_hits; ++s) {
+                        const float ts = my_t[s];
+                        const int is = my_tri[s];
+                        if (hit_less(worst_t, worst_tri, ts, is)) { worst_t = ts; worst_tri = is; worst_slot = s; }
+                    }
+                    t_limit = worst_t;
+                }
+            }
+        }
+        const bool in0 = h0 && c0 >= 0, in1 = h1 && c1 >= 0;
+        if (in0 && in1) {
+            const bool first0 = tn0 <= tn1;
+            next = first0 ? c0 : c1;
+            if (sp < kStack) stack[sp++] = first0 ? c1 : c0;
+        } else if (in0) {
+            next = c0;
+        } else if (in1) {
+            next = c1;
+        } else {
+            next = sp > 0 ? stack[--sp] : -1;
+        }
+        node = next;
+    }
+
+    // ascending (t, tri); pad the tail
+    for (int i = 1; i < count; ++i) {
+        const float t = my_t[i];
+        const int id = my_tri[i];
+        int j = i - 1;
+        while (j >= 0 && hit_less(t, id, my_t[j], my_tri[j])) {
+            my_t[j + 1] = my_t[j];
+            my_tri[j + 1] = my_tri[j];
+            --j;
+        }
+        my_t[j + 1] = t;
+        my_tri[j + 1] = id;
+    }
+    for (int i = count; i < max_hits; ++i) { my_t[i] = INFINITY; my_tri[i] = -1; }
+    hit_count[ray] = count;
+}
+
+// sampling_raytrace_numpy (mesh_utils.py:359-387) for rays whose hits are already ascending in (t, tri).
+__global__ void pack_samples_kernel(const float *rays_o, const float *rays_d, int64_t n_rays, int max_hits,
+                                    const int32_t *hit_tri, const float *hit_t, const int32_t *hit_count,
+                                    const int64_t *ray_offset, float *xyz, float *dirs, int64_t *index_ray, float *depth,
+                                    int64_t *index_tri, float *origins)
+{
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_rays; r += (int64_t)gridDim.x * blockDim.x) {
+        const int cnt = hit_count[r];
+        if (cnt <= 0) continue;
+        const float ox = rays_o[r * 3], oy = rays_o[r * 3 + 1], oz = rays_o[r * 3 + 2];
+        const float dx = rays_d[r * 3], dy = rays_d[r * 3 + 1], dz = rays_d[r * 3 + 2];
+        // vectors / (|vectors| + 1e-7) in float32 (mesh_utils.py:369-370)
+        const float nrm = sqrtf((dx * dx + dy * dy) + dz * dz) + 1e-7f;
+        const float ux = dx / nrm, uy = dy / nrm, uz = dz / nrm;
+        const double o64[3] = {(double)ox, (double)oy, (double)oz};
+        const double d64[3] = {(double)dx, (double)dy, (double)dz};
+        double dep[kMaxHits];
+        int order[kMaxHits];
+        for (int k = 0; k < cnt; ++k) {
+            const double t = (double)hit_t[r * max_hits + k];
+            const double qx = (o64[0] + t * d64[0]) - o64[0];
+            const double qy = (o64[1] + t * d64[1]) - o64[1];
+            const double qz = (o64[2] + t * d64[2]) - o64[2];
+            const double dk = sqrt((qx * qx + qy * qy) + qz * qz);   // |location - origin| (mesh_utils.py:371)
+            int j = k - 1;                                           // stable insertion: lexsort((depth, ray))
+            while (j >= 0 && dep[j] > dk) { dep[j + 1] = dep[j]; order[j + 1] = order[j]; --j; }
+            dep[j + 1] = dk;
+            order[j + 1] = k;
+        }
+        const int64_t base = ray_offset[r];
+        for (int k = 0; k < cnt; ++k) {
+            const int src = order[k];
+            const double t = (double)hit_t[r * max_hits + src];
+            const int64_t o = base + k;
+            xyz[o * 3 + 0] = (float)(o64[0] + t * d64[0]);
+            xyz[o * 3 + 1] = (float)(o64[1] + t * d64[1]);
+            xyz[o * 3 + 2] = (float)(o64[2] + t * d64[2]);
+            dirs[o * 3 + 0] = ux;
+            dirs[o * 3 + 1] = uy;
+            dirs[o * 3 + 2] = uz;
+            origins[o * 3 + 0] = ox;
+            origins[o * 3 + 1] = oy;
+            origins[o * 3 + 2] = oz;
+            index_ray[o] = r;
+            depth[o] = (float)dep[k];
+            index_tri[o] = (int64_t)hit_tri[r * max_hits + src];
+        }
+    }
+}
+
+// Stable per-ray insertion sort of sample indices by fp32 depth (np.lexsort((depth, index_ray)) on grouped rays).
+__global__ void resort_kernel(const int64_t *index_ray, const float *depth, int64_t n, int64_t *perm)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t ray = index_ray[i];
+        if (i != 0 && index_ray[i - 1] == ray) continue;
+        perm[i] = i;
+        for (int64_t k = i + 1; k < n && index_ray[k] == ray; ++k) {
+            const float dk = depth[k];
+            int64_t j = k - 1;
+            while (j >= i && depth[perm[j]] > dk) { perm[j + 1] = perm[j]; --j; }
+            perm[j + 1] = k;
+        }
+    }
+}
+
+// utils.py:1055-1063: float64 Cramer barycentrics -> fp32 clamp / renormalise -> uv -> floor -> clip.
+__global__ void texel_indices_kernel(const double *vertices, const int64_t *faces, const float *uv, const float *points,
+                                     const int64_t *index_tri, int64_t n, int texture_size, int64_t *texel)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t f = index_tri[i];
+        const int64_t ia = faces[f * 3], ib = faces[f * 3 + 1], ic = faces[f * 3 + 2];
+        const double ax = vertices[ia * 3], ay = vertices[ia * 3 + 1], az = vertices[ia * 3 + 2];
+        const double e0x = vertices[ib * 3] - ax, e0y = vertices[ib * 3 + 1] - ay, e0z = vertices[ib * 3 + 2] - az;
+        const double e1x = vertices[ic * 3] - ax, e1y = vertices[ic * 3 + 1] - ay, e1z = vertices[ic * 3 + 2] - az;
+        const double wx = (double)points[i * 3] - ax, wy = (double)points[i * 3 + 1] - ay, wz = (double)points[i * 3 + 2] - az;
+        const double d00 = (e0x * e0x + e0y * e0y) + e0z * e0z;
+        const double d01 = (e0x * e1x + e0y * e1y) + e0z * e1z;
+        const double d11 = (e1x * e1x + e1y * e1y) + e1z * e1z;
+        const double d02 = (e0x * wx + e0y * wy) + e0z * wz;
+        const double d12 = (e1x * wx + e1y * wy) + e1z * wz;
+        const double inv = 1.0 / (d00 * d11 - d01 * d01);
+        const double b2d = (d00 * d12 - d01 * d02) * inv;
+        const double b1d = (d11 * d02 - d01 * d12) * inv;
+        const double b0d = 1.0 - b1d - b2d;
+        float b0 = fminf(fmaxf((float)b0d, 0.0f), 1.0f);
+        float b1 = fminf(fmaxf((float)b1d, 0.0f), 1.0f);
+        float b2 = fminf(fmaxf((float)b2d, 0.0f), 1.0f);
+        const float s = (b0 + b1) + b2;
+        b0 = b0 / s;
+        b1 = b1 / s;
+        b2 = b2 / s;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const float u = (uv[ia * 2 + k] * b0 + uv[ib * 2 + k] * b1) + uv[ic * 2 + k] * b2;
+            float fl = floorf(u);
+            // torch: floor -> .long() -> clip(0, T-1); NaN (degenerate triangle) -> int64 min -> 0
+            int64_t q = (fl != fl) ? 0 : (fl <= -9.2e18f ? INT64_MIN : (fl >= 9.2e18f ? INT64_MAX : (int64_t)fl));
+            if (q < 0) q = 0;
+            if (q > texture_size - 1) q = texture_size - 1;
+            texel[i * 2 + k] = q;
+        }
+    }
+}
+
+struct TexArgs {
+    const uint8_t *alpha, *diffuse;
+    const uint8_t *colors[QF_MAX_LOBES];
+    const uint8_t *lam[QF_MAX_LOBES];
+    int size, n_lobes, sigmoid_codec;
+    float lambda_thres;
+};
+
+__device__ __forceinline__ float decode_color(uint8_t c, int sigmoid_codec)
+{
+    const float v = (float)c / 255.0f;
+    if (sigmoid_codec) return logf(fminf(fmaxf(v / (1.0f - v), 1e-8f), 1e37f));   // ngp.py:277-278
+    return v * 2.0f * 12.0f - 12.0f;                                              // ngp.py:280 (B-7)
+}
+
+// Decodes one texel into out[0 .. 3+7L] = [diffuse3 | (axis3, lambda, colour3) * L | sigma].
+__device__ __forceinline__ void decode_texel(const TexArgs &t, int64_t row, int64_t col, float *out)
+{
+    const int64_t px = row * t.size + col;
+    const float a = (float)t.alpha[px] / 255.0f;
+    const float sigma = -logf(fmaxf(1.0f - a, 1e-6f)) / 0.005f;                   // texture_utils.py:61-65 (B-9)
+    out[0] = decode_color(t.diffuse[px * 3 + 0], t.sigmoid_codec);
+    out[1] = decode_color(t.diffuse[px * 3 + 1], t.sigmoid_codec);
+    out[2] = decode_color(t.diffuse[px * 3 + 2], t.sigmoid_codec);
+    const float pi = 3.14159274101257324f;   // float32(np.pi)
+    for (int l = 0; l < t.n_lobes; ++l) {
+        const uint8_t lc = t.lam[l][px * 3 + 0], az8 = t.lam[l][px * 3 + 1], el8 = t.lam[l][px * 3 + 2];
+        const float az = (float)(uint8_t)(az8 - 128) / 128.0f * pi;               // uint8 wrap (B-8), ngp.py:246
+        const float el = (float)el8 / 256.0f * pi;                                // ngp.py:248
+        const float se = sinf(el);
+        float *o = out + 3 + 7 * l;
+        o[0] = cosf(az) * se;
+        o[1] = sinf(az) * se;
+        o[2] = cosf(el);
+        o[3] = expf((float)lc * t.lambda_thres / 255.0f - 2.5f);                  // ngp.py:261-262
+        o[4] = decode_color(t.colors[l][px * 3 + 0], t.sigmoid_codec);
+        o[5] = decode_color(t.colors[l][px * 3 + 1], t.sigmoid_codec);
+        o[6] = decode_color(t.colors[l][px * 3 + 2], t.sigmoid_codec);
+    }
+    out[3 + 7 * t.n_lobes] = sigma;
+}
+
+__global__ void texture_fetch_kernel(TexArgs t, const int64_t *texel, int64_t n, float *features)
+{
+    const int width = 3 + 7 * t.n_lobes + 1;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float f[3 + 7 * QF_MAX_LOBES + 1];
+        decode_texel(t, texel[i * 2], texel[i * 2 + 1], f);
+        for (int k = 0; k < width; ++k) features[i * width + k] = f[k];
+    }
+}
+
+__global__ void texture_shade_kernel(TexArgs t, const int64_t *texel, const float *dirs, int64_t n, float *rgb,
+                                     float *sigma)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float f[3 + 7 * QF_MAX_LOBES + 1];
+        decode_texel(t, texel[i * 2], texel[i * 2 + 1], f);
+        const float dx = dirs[i * 3], dy = dirs[i * 3 + 1], dz = dirs[i * 3 + 2];
+        float r = 0.0f, g = 0.0f, b = 0.0f;
+        for (int l = 0; l < t.n_lobes; ++l) {
+            const float *x = f + 3 + 7 * l;
+            const float nrm = sqrtf((x[0] * x[0] + x[1] * x[1]) + x[2] * x[2]);
+            const float dotp = ((x[0] / nrm) * dx + (x[1] / nrm) * dy) + (x[2] / nrm) * dz;
+            const float e = expf(fabsf(x[3]) * (dotp - 1.0f));
+            r += x[4] * e;
+            g += x[5] * e;
+            b += x[6] * e;
+        }
+        rgb[i * 3 + 0] = 1.0f / (1.0f + expf(-(f[0] + r)));
+        rgb[i * 3 + 1] = 1.0f / (1.0f + expf(-(f[1] + g)));
+        rgb[i * 3 + 2] = 1.0f / (1.0f + expf(-(f[2] + b)));
+        sigma[i] = f[3 + 7 * t.n_lobes];
+    }
+}
+
+int fill_tex_args(const qf_texture_set *tex, TexArgs *t)
+{
+    if (!tex || !tex->alpha || !tex->diffuse || tex->texture_size < 1) return QF_ERR_INVALID_ARGUMENT;
+    if (tex->n_lobes < 1 || tex->n_lobes > QF_MAX_LOBES) return QF_ERR_UNSUPPORTED;
+    t->alpha = tex->alpha;
+    t->diffuse = tex->diffuse;
+    for (int l = 0; l < QF_MAX_LOBES; ++l) {
+        t->colors[l] = l < tex->n_lobes ? tex->colors[l] : nullptr;
+        t->lam[l] = l < tex->n_lobes ? tex->lambda_axis[l] : nullptr;
+        if (l < tex->n_lobes && (!t->colors[l] || !t->lam[l])) return QF_ERR_INVALID_ARGUMENT;
+    }
+    t->size = tex->texture_size;
+    t->n_lobes = tex->n_lobes;
+    t->sigmoid_codec = tex->sigmoid_codec;
+    t->lambda_thres = tex->lambda_thres;
+    return QF_OK;
+}
+
+}  // namespace
+
+#define QF_SIMPLE_LAUNCH(kernel, count, ...)                                                                  \
+    hipLaunchKernelGGL(kernel, dim3(qf_grid_1d((count), 256)), dim3(256), 0, qf_stream(stream), __VA_ARGS__); \
+    QF_LAUNCH_CHECK();
+
+extern "C" int qf_bvh_intersect(const qf_bvh *bvh, const float *rays_o, const float *rays_d, int64_t n_rays,
+                                int32_t max_hits, int32_t image_width, int32_t *hit_tri, float *hit_t,
+                                int32_t *hit_count, void *stream)
+{
+    if (!bvh || n_rays < 0 || max_hits < 1 || max_hits > kMaxHits || image_width < 0) return QF_ERR_INVALID_ARGUMENT;
+    if (n_rays == 0) return QF_OK;
+    if (!rays_o || !rays_d || !hit_tri || !hit_t || !hit_count) return QF_ERR_INVALID_ARGUMENT;
+    int height = 0, tiles_x = 0;
+    int64_t threads = n_rays;
+    if (image_width > 0) {
+        if (n_rays % image_width) return QF_ERR_INVALID_ARGUMENT;
+        height = (int)(n_rays / image_width);
+        tiles_x = (image_width + 7) / 8;
+        threads = (int64_t)tiles_x * ((height + 7) / 8) * 64;
+    }
+    const int64_t blocks = qf_div_up(threads, 64);
+    if (blocks > 0x7fffffff) return QF_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(bvh_traverse_kernel, dim3((unsigned)blocks), dim3(64), 0, qf_stream(stream),
+                       reinterpret_cast<const float4 *>(bvh->d_nodes), reinterpret_cast<const float4 *>(bvh->d_tris),
+                       bvh->n_tri > 0 ? 1 : 0, rays_o, rays_d, n_rays, (int)max_hits, (int)image_width, height, tiles_x,
+                       hit_tri, hit_t, hit_count);
+    QF_LAUNCH_CHECK();
+    return QF_OK;
+}
+
+extern "C" int qf_pack_samples(const float *rays_o, const float *rays_d, int64_t n_rays, int32_t max_hits,
+                               const int32_t *hit_tri, const float *hit_t, const int32_t *hit_count,
+                               const int64_t *ray_offset, float *xyz, float *dirs, int64_t *index_ray, float *depth,
+                               int64_t *index_tri, float *origins, void *stream)
+{
+    if (n_rays < 0 || max_hits < 1 || max_hits > kMaxHits) return QF_ERR_INVALID_ARGUMENT;
+    if (n_rays == 0) return QF_OK;
+    if (!rays_o || !rays_d || !hit_tri || !hit_t || !hit_count || !ray_offset) return QF_ERR_INVALID_ARGUMENT;
+    QF_SIMPLE_LAUNCH(pack_samples_kernel, n_rays, rays_o, rays_d, n_rays, (int)max_hits, hit_tri, hit_t, hit_count,
+                     ray_offset, xyz, dirs, index_ray, depth, index_tri, origins);
+    return QF_OK;
+}
+
+extern "C" int qf_resort_by_depth(const int64_t *index_ray, const float *depth, int64_t n, int64_t *perm, void *stream)
+{
+    if (n < 0) return QF_ERR_INVALID_ARGUMENT;
+    if (n == 0) return QF_OK;
+    if (!index_ray || !depth || !perm) return QF_ERR_INVALID_ARGUMENT;
+    QF_SIMPLE_LAUNCH(resort_kernel, n, index_ray, depth, n, perm);
+    return QF_OK;
+}
+
+extern "C" int qf_texel_indices(const double *vertices, const int64_t *faces, const float *uv, const float *points,
+                                const int64_t *index_tri, int64_t n, int32_t texture_size, int64_t *texel, void *stream)
+{
+    if (n < 0 || texture_size < 1) return QF_ERR_INVALID_ARGUMENT;
+    if (n == 0) return QF_OK;
+    if (!vertices || !faces || !uv || !points || !index_tri || !texel) return QF_ERR_INVALID_ARGUMENT;
+    QF_SIMPLE_LAUNCH(texel_indices_kernel, n, vertices, faces, uv, points, index_tri, n, (int)texture_size, texel);
+    return QF_OK;
+}
+
+extern "C" int qf_texture_fetch(const qf_texture_set *tex, const int64_t *texel, int64_t n, float *features, void *stream)
+{
+    TexArgs t;
+    int rc = fill_tex_args(tex, &t);
+    if (rc != QF_OK) return rc;
+    if (n < 0) return QF_ERR_INVALID_ARGUMENT;
+    if (n == 0) return QF_OK;
+    if (!texel || !features) return QF_ERR_INVALID_ARGUMENT;
+    QF_SIMPLE_LAUNCH(texture_fetch_kernel, n, t, texel, n, features);
+    return QF_OK;
+}
+
+extern "C" int qf_texture_shade(const qf_texture_set *tex, const int64_t *texel, const float *dirs, int64_t n,
+                                float *rgb, float *sigma, void *stream)
+{
+    TexArgs t;
+    int rc = fill_tex_args(tex, &t);
+    if (rc != QF_OK) return rc;
+    if (n < 0) return QF_ERR_INVALID_ARGUMENT;
+    if (n == 0) return QF_OK;
+    if (!texel || !dirs || !rgb || !sigma) return QF_ERR_INVALID_ARGUMENT;
+    QF_SIMPLE_LAUNCH(texture_shade_kernel, n, t, texel, dirs, n, rgb, sigma);
+    return QF_OK;
+}

@@ -1,0 +1,775 @@
+// Fused field evaluation for gfx950: multi-resolution hash-grid gather + tiny MLPs on the
+// fp32 matrix cores + SH / spherical-Gaussian head, one launch per batch of quadrature points.
+//
+// Replaces: tcnn GridEncoding + FullyFusedMLP + SphericalHarmonics behind
+// NGPRadianceField.forward (examples/radiance_fields/ngp.py:757-809) and the BasicDecoder + SG
+// mixture behind NGPRadianceFieldSGNew.forward / features (ngp.py:371-470).
+//
+// Mapping (DESIGN.md "field kernel"):
+//   * a wave handles 16 points per pass; lane l = (p = l & 15, g = l >> 4): point p of the group,
+//     level quartet g.  Lane (g,p) gathers levels {g, 4+g, 8+g, 12+g} of point p: 4 levels x 8
+//     corners x float2 = 32 independent 8-byte loads in flight per lane.
+//   * every layer is computed transposed, H^T[neuron][point] = W . X^T, with
+//     v_mfma_f32_16x16x4_f32 (exact fp32, = fmaf chain).  W tiles are the A operand (staged once
+//     per workgroup into LDS, already in per-lane operand order), X^T is the B operand.  The
+//     16x16x4 C/D layout puts D[4g+r][p] in register r of lane (g,p), i.e. each lane ends up with
+//     four neurons of ITS OWN point -- exactly the B operand of the next layer's k-step, so
+//     activations never leave registers between layers (no LDS, no shuffles).  The k order of each
+//     layer is permuted to match; the permutation is folded into the LDS weight image.
+//   * workgroup = 8 waves, persistent: grid = CUs x 2, waves stride over the 16-point groups.
+#include "qf_common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define QF_PRIME_Y 2654435761u
+#define QF_PRIME_Z 805459861u
+
+namespace {
+
+constexpr int kBlock = 512;          // 8 waves
+constexpr int kBaseMfma = 48;        // 32 (32->64) + 16 (64->16)
+constexpr int kNgpHeadMfma = 112;    // 32 + 64 + 16
+constexpr int kSgHeadMfmaFixed = 80; // 16 (16->64) + 64 (64->64); + 16 per output tile
+
+struct GridArgs {
+    uint32_t offset[QF_MAX_LEVELS];
+    uint32_t rows[QF_MAX_LEVELS];
+    uint32_t res[QF_MAX_LEVELS];
+    float scale[QF_MAX_LEVELS];
+    uint32_t hashed_mask;
+};
+
+struct FieldArgs {
+    GridArgs grid;
+    float aabb_lo[3];
+    float aabb_inv[3];   // unused: division kept for parity, see normalise()
+    float aabb_hi[3];
+    const float2 *table;
+    const float *base_w;
+    const float *head_w;   // NGP head
+    qf_sg_head sg;         // SG head
+    const float *xyz;
+    const float *dirs;
+    int64_t n;
+    float *rgb;
+    float *sigma;
+    float *geo;
+    float *features;
+    int32_t n_lobes;
+    int32_t n_out;      // 3 + 7L
+    int32_t nt_out;     // ceil(n_out / 16)
+};
+
+__device__ __forceinline__ f32x4 mfma(float a, float b, f32x4 c)
+{
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ int img_index(int m, int lane)
+{
+    return ((((m >> 2) << 6) + lane) << 2) + (m & 3);
+}
+
+// column of the (64-wide) hidden input consumed at k-step s by lane quartet kq
+__device__ __forceinline__ int hidden_col(int s, int kq) { return 16 * (s >> 2) + 4 * kq + (s & 3); }
+
+// Weight value that lane `lane` must feed as A operand of MFMA number m (program order).
+template <int HEAD>
+__device__ float weight_for(const FieldArgs &a, int m, int lane)
+{
+    const int i = lane & 15, kq = lane >> 4;
+    if (m < 32) {                       // base 32 -> 64: s outer, mt inner
+        const int s = m >> 2, mt = m & 3;
+        const int col = 2 * (4 * (s >> 1) + kq) + (s & 1);
+        return a.base_w[(16 * mt + i) * 32 + col];
+    }
+    if (m < kBaseMfma) {                // base 64 -> 16
+        const int s = m - 32;
+        return a.base_w[2048 + i * 64 + hidden_col(s, kq)];
+    }
+    m -= kBaseMfma;
+    if (HEAD == QF_HEAD_NGP) {
+        if (m < 32) {                   // [SH16 | geo15 | 1] -> 64
+            const int s = m >> 2, mt = m & 3;
+            int col;
+            if (s < 4) col = 4 * kq + s;
+            else { const int o = 4 * kq + (s - 4); col = (o == 0) ? 31 : 15 + o; }
+            return a.head_w[(16 * mt + i) * 32 + col];
+        }
+        if (m < 96) {                   // 64 -> 64
+            const int q = m - 32, s = q >> 2, mt = q & 3;
+            return a.head_w[2048 + (16 * mt + i) * 64 + hidden_col(s, kq)];
+        }
+        const int s = m - 96;           // 64 -> 16 (3 used)
+        return a.head_w[2048 + 4096 + i * 64 + hidden_col(s, kq)];
+    }
+    if (HEAD == QF_HEAD_SG || HEAD == QF_HEAD_SG_FEATURES) {
+        if (m < 16) {                   // [geo15 | bias] -> 64 ; slot of the density carries b1
+            const int s = m >> 2, mt = m & 3, row = 16 * mt + i;
+            const int o = 4 * kq + s;
+            return (o == 0) ? a.sg.b1[row] : a.sg.w1[row * 15 + (o - 1)];
+        }
+        if (m < 80) {
+            const int q = m - 16, s = q >> 2, mt = q & 3;
+            return a.sg.w2[(16 * mt + i) * 64 + hidden_col(s, kq)];
+        }
+        const int q = m - 80, mt = q >> 4, s = q & 15;   // output tiles: mt outer, s inner
+        const int row = 16 * mt + i;
+        return (row < a.n_out) ? a.sg.wout[row * 64 + hidden_col(s, kq)] : 0.0f;
+    }
+    return 0.0f;
+}
+
+template <int HEAD>
+__device__ __forceinline__ int n_mfma(const FieldArgs &a)
+{
+    if (HEAD == QF_HEAD_NGP) return kBaseMfma + kNgpHeadMfma;
+    if (HEAD == QF_HEAD_SG || HEAD == QF_HEAD_SG_FEATURES) return kBaseMfma + kSgHeadMfmaFixed + 16 * a.nt_out;
+    return kBaseMfma;
+}
+
+// One hash-grid level for one point: issues the 8 corner gathers and blends them.
+struct LevelConst {
+    uint32_t offset, rows, res, hashed;
+    float scale;
+};
+
+__device__ __forceinline__ void level_indices(const LevelConst &lc, float x, float y, float z,
+                                              uint32_t idx[8], float frac[3])
+{
+    const float px = fmaf(lc.scale, x, 0.5f), py = fmaf(lc.scale, y, 0.5f), pz = fmaf(lc.scale, z, 0.5f);
+    const float fx = floorf(px), fy = floorf(py), fz = floorf(pz);
+    frac[0] = px - fx;
+    frac[1] = py - fy;
+    frac[2] = pz - fz;
+    const uint32_t gx = (uint32_t)(int32_t)fx, gy = (uint32_t)(int32_t)fy, gz = (uint32_t)(int32_t)fz;
+
+    uint32_t cx[2] = {gx, gx + 1u}, cy[2] = {gy, gy + 1u}, cz[2] = {gz, gz + 1u};
+    if (lc.hashed) {
+        const uint32_t hy[2] = {cy[0] * QF_PRIME_Y, cy[1] * QF_PRIME_Y};
+        const uint32_t hz[2] = {cz[0] * QF_PRIME_Z, cz[1] * QF_PRIME_Z};
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+            idx[c] = (cx[c & 1] ^ hy[(c >> 1) & 1] ^ hz[c >> 2]) & (lc.rows - 1u);   // rows is 2^T when hashed
+    } else {
+        // dense: stride walks 1, res, res^2 while stride <= rows (A.1); res^2 <= rows always holds
+        // for a dense level except the degenerate res^2 > rows case handled by the host check.
+        const uint32_t r2 = lc.res * lc.res;
+        const uint32_t sy[2] = {cy[0] * lc.res, cy[1] * lc.res};
+        const uint32_t sz[2] = {cz[0] * r2, cz[1] * r2};
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            uint32_t v = cx[c & 1] + sy[(c >> 1) & 1] + sz[c >> 2];
+            if (v >= lc.rows) v %= lc.rows;   // rare: cell on the upper faces, or point outside the aabb
+            idx[c] = v;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) idx[c] += lc.offset;
+}
+
+// Trilinear blend of the 8 gathered corners; weight = ((1 * wx?) * wy?) * wz?, corner order 0..7
+// (bit d of the corner index selects the upper cell along axis d) -- as tcnn / the oracle.
+__device__ __forceinline__ void level_blend(const float2 val[8], const float frac[3], float *f0, float *f1)
+{
+    const float wx = frac[0], wy = frac[1], wz = frac[2];
+    const float wx0 = 1.0f - wx, wy0 = 1.0f - wy, wz0 = 1.0f - wz;
+    const float wxy[4] = {wx0 * wy0, wx * wy0, wx0 * wy, wx * wy};
+    float a = 0.0f, b = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const float w = wxy[c & 3] * ((c & 4) ? wz : wz0);
+        a = fmaf(w, val[c].x, a);
+        b = fmaf(w, val[c].y, b);
+    }
+    *f0 = a;
+    *f1 = b;
+}
+
+__device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// 4 of the 16 degree-4 SH basis values: components 4g .. 4g+3 (A.3).
+__device__ __forceinline__ void sh4_quartet(int g, float x, float y, float z, float out[4])
+{
+    const float xy = x * y, xz = x * z, yz = y * z, x2 = x * x, y2 = y * y, z2 = z * z;
+    float v[16];
+    v[0] = 0.28209479177387814f;
+    v[1] = -0.48860251190291987f * y;
+    v[2] = 0.48860251190291987f * z;
+    v[3] = -0.48860251190291987f * x;
+    v[4] = 1.0925484305920792f * xy;
+    v[5] = -1.0925484305920792f * yz;
+    v[6] = 0.94617469575755997f * z2 - 0.31539156525251999f;
+    v[7] = -1.0925484305920792f * xz;
+    v[8] = 0.54627421529603959f * x2 - 0.54627421529603959f * y2;
+    v[9] = 0.59004358992664352f * y * (-3.0f * x2 + y2);
+    v[10] = 2.8906114426405538f * xy * z;
+    v[11] = 0.45704579946446572f * y * (1.0f - 5.0f * z2);
+    v[12] = 0.3731763325901154f * z * (5.0f * z2 - 3.0f);
+    v[13] = 0.45704579946446572f * x * (1.0f - 5.0f * z2);
+    v[14] = 1.4453057213202769f * z * (x2 - y2);
+    v[15] = 0.59004358992664352f * x * (-x2 + 3.0f * y2);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float a = v[r], b = v[4 + r], c = v[8 + r], d = v[12 + r];
+        out[r] = g == 0 ? a : (g == 1 ? b : (g == 2 ? c : d));
+    }
+}
+
+template <int HEAD>
+__global__ __launch_bounds__(kBlock, 4) void field_kernel(const FieldArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int g = lane >> 4, p = lane & 15;
+
+    // ---- stage the A-operand images (and SG biases) into LDS, once per workgroup
+    const int total = n_mfma<HEAD>(a) * 64;
+    for (int e = tid; e < total; e += kBlock) {
+        const int m = e >> 6, l = e & 63;
+        lds[img_index(m, l)] = weight_for<HEAD>(a, m, l);
+    }
+    float *bias_lds = lds + total;      // [b2 (64) | bout (64, zero padded)]
+    if (HEAD == QF_HEAD_SG || HEAD == QF_HEAD_SG_FEATURES) {
+        if (tid < 64) bias_lds[tid] = a.sg.b2[tid];
+        else if (tid < 128) bias_lds[tid] = (tid - 64 < a.n_out) ? a.sg.bout[tid - 64] : 0.0f;
+    }
+    __syncthreads();
+    const f32x4 *img_base = reinterpret_cast<const f32x4 *>(lds);   // img_base[(m>>2)*64 + lane]
+
+    // ---- per-lane constants: the four levels this lane quartet owns
+    LevelConst lc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int level = 4 * j + g;
+        lc[j].offset = a.grid.offset[level];
+        lc[j].rows = a.grid.rows[level];
+        lc[j].res = a.grid.res[level];
+        lc[j].scale = a.grid.scale[level];
+        lc[j].hashed = (a.grid.hashed_mask >> level) & 1u;
+    }
+
+    const int64_t n_groups = (a.n + 15) >> 4;
+    const int64_t wave_global = (int64_t)blockIdx.x * (kBlock / 64) + (tid >> 6);
+    const int64_t wave_stride = (int64_t)gridDim.x * (kBlock / 64);
+
+    for (int64_t grp = wave_global; grp < n_groups; grp += wave_stride) {
+        const int64_t pt_raw = grp * 16 + p;
+        const bool valid = pt_raw < a.n;
+        const int64_t pt = valid ? pt_raw : a.n - 1;
+
+        const float X = a.xyz[pt * 3 + 0], Y = a.xyz[pt * 3 + 1], Z = a.xyz[pt * 3 + 2];
+        // (x - lo) / (hi - lo), ngp.py:761-763
+        const float x01 = (X - a.aabb_lo[0]) / (a.aabb_hi[0] - a.aabb_lo[0]);
+        const float y01 = (Y - a.aabb_lo[1]) / (a.aabb_hi[1] - a.aabb_lo[1]);
+        const float z01 = (Z - a.aabb_lo[2]) / (a.aabb_hi[2] - a.aabb_lo[2]);
+        const bool selector = x01 > 0.0f && x01 < 1.0f && y01 > 0.0f && y01 < 1.0f && z01 > 0.0f && z01 < 1.0f;
+
+        // ---- hash grid: issue all 32 gathers, then blend
+        float frac[4][3];
+        float2 val[4][8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            uint32_t idx[8];
+            level_indices(lc[j], x01, y01, z01, idx, frac[j]);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) val[j][c] = a.table[idx[c]];
+        }
+        float feat[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) level_blend(val[j], frac[j], &feat[2 * j], &feat[2 * j + 1]);
+
+        // weights are loop-invariant in LDS; an opaque lane offset keeps the compiler from hoisting
+        // all 160 operand registers out of the point loop
+        int loff = lane;
+        asm volatile("" : "+v"(loff));
+        const f32x4 *img = img_base + loff;
+
+        // ---- base MLP 32 -> 64 (ReLU) -> 16
+        f32x4 h[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) h[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const f32x4 w4 = img[s * 64];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) h[mt] = mfma(w4[mt], feat[s], h[mt]);
+        }
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) h[mt][r] = fmaxf(h[mt][r], 0.0f);
+        f32x4 oa = (f32x4){0.f, 0.f, 0.f, 0.f}, ob = oa;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 w4 = img[(8 + q) * 64];
+            oa = mfma(w4[0], h[q][0], oa);
+            ob = mfma(w4[1], h[q][1], ob);
+            oa = mfma(w4[2], h[q][2], oa);
+            ob = mfma(w4[3], h[q][3], ob);
+        }
+        const f32x4 base_out = oa + ob;    // lane (g,p): outputs 4g .. 4g+3 of point p
+
+        // density = exp(raw - 1) * selector, ngp.py:772-775 (B-5, B-6)
+        const float density = selector ? expf(base_out[0] - 1.0f) : 0.0f;
+        if (g == 0 && valid && a.sigma) a.sigma[pt] = density;
+        if (a.geo && valid) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int o = 4 * g + r;
+                if (o > 0) a.geo[pt * 15 + (o - 1)] = base_out[r];
+            }
+        }
+
+        if (HEAD == QF_HEAD_NGP) {
+            const float dx = a.dirs[pt * 3 + 0], dy = a.dirs[pt * 3 + 1], dz = a.dirs[pt * 3 + 2];
+            // ngp.py:784 feeds (d+1)/2; tcnn maps back 2u-1 (A.3)
+            const float ux = ((dx + 1.0f) / 2.0f) * 2.0f - 1.0f;
+            const float uy = ((dy + 1.0f) / 2.0f) * 2.0f - 1.0f;
+            const float uz = ((dz + 1.0f) / 2.0f) * 2.0f - 1.0f;
+            float in[8];
+            sh4_quartet(g, ux, uy, uz, in);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) in[4 + r] = base_out[r];
+            if (g == 0) in[4] = 1.0f;      // the density slot carries the constant-1 pad input
+            f32x4 h1[4];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) h1[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const f32x4 w4 = img[(12 + s) * 64];
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) h1[mt] = mfma(w4[mt], in[s], h1[mt]);
+            }
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) h1[mt][r] = fmaxf(h1[mt][r], 0.0f);
+            f32x4 h2[4];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) h2[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const f32x4 w4 = img[(20 + s) * 64];
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) h2[mt] = mfma(w4[mt], h1[s >> 2][s & 3], h2[mt]);
+            }
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) h2[mt][r] = fmaxf(h2[mt][r], 0.0f);
+            f32x4 ca = (f32x4){0.f, 0.f, 0.f, 0.f}, cb = ca;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 w4 = img[(36 + q) * 64];
+                ca = mfma(w4[0], h2[q][0], ca);
+                cb = mfma(w4[1], h2[q][1], cb);
+                ca = mfma(w4[2], h2[q][2], ca);
+                cb = mfma(w4[3], h2[q][3], cb);
+            }
+            const f32x4 c = ca + cb;
+            if (g == 0 && valid) {
+                a.rgb[pt * 3 + 0] = sigmoidf(c[0]);
+                a.rgb[pt * 3 + 1] = sigmoidf(c[1]);
+                a.rgb[pt * 3 + 2] = sigmoidf(c[2]);
+            }
+        }
+
+        if (HEAD == QF_HEAD_SG || HEAD == QF_HEAD_SG_FEATURES) {
+            float in[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) in[r] = base_out[r];
+            if (g == 0) in[0] = 1.0f;      // bias slot
+            f32x4 h1[4];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) h1[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const f32x4 w4 = img[(12 + s) * 64];
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) h1[mt] = mfma(w4[mt], in[s], h1[mt]);
+            }
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) h1[mt][r] = fmaxf(h1[mt][r], 0.0f);
+            f32x4 h2[4];
+            const f32x4 *b2v = reinterpret_cast<const f32x4 *>(bias_lds);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) h2[mt] = b2v[4 * mt + g];
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const f32x4 w4 = img[(16 + s) * 64];
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) h2[mt] = mfma(w4[mt], h1[s >> 2][s & 3], h2[mt]);
+            }
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) h2[mt][r] = fmaxf(h2[mt][r], 0.0f);
+            // output tiles: lane (g,p) register r of tile mt = head output 16mt + 4g + r
+            f32x4 out[4];
+            const f32x4 *bov = reinterpret_cast<const f32x4 *>(bias_lds + 64);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                out[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (mt < a.nt_out) {
+                    f32x4 ea = bov[4 * mt + g], eb = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4 w4 = img[(32 + 4 * mt + q) * 64];
+                        ea = mfma(w4[0], h2[q][0], ea);
+                        eb = mfma(w4[1], h2[q][1], eb);
+                        ea = mfma(w4[2], h2[q][2], ea);
+                        eb = mfma(w4[3], h2[q][3], eb);
+                    }
+                    out[mt] = ea + eb;
+                }
+            }
+            if (HEAD == QF_HEAD_SG_FEATURES) {
+                if (valid) {
+                    const int64_t row = pt * (int64_t)(a.n_out + 1);
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int o = 16 * mt + 4 * g + r;
+                            if (o < a.n_out) a.features[row + o] = out[mt][r];
+                        }
+                    if (g == 0) a.features[row + a.n_out] = density;
+                }
+            } else {
+                const float dx = a.dirs[pt * 3 + 0], dy = a.dirs[pt * 3 + 1], dz = a.dirs[pt * 3 + 2];
+                // gather each head output from the lane quartet that holds it (compile-time slot)
+                auto fetch = [&](int o) -> float {
+                    return __shfl(out[o >> 4][o & 3], p + 16 * ((o >> 2) & 3), 64);
+                };
+                float acc_r = 0.0f, acc_g = 0.0f, acc_b = 0.0f;
+#pragma unroll
+                for (int l = 0; l < QF_MAX_LOBES; ++l) {
+                    if (l < a.n_lobes) {
+                        const int o = 3 + 7 * l;
+                        const float ax = fetch(o), ay = fetch(o + 1), az = fetch(o + 2);
+                        const float lam = fabsf(fetch(o + 3));
+                        const float cr = fetch(o + 4), cg = fetch(o + 5), cb = fetch(o + 6);
+                        const float nrm = sqrtf(ax * ax + ay * ay + az * az);
+                        const float dotp = (ax / nrm) * dx + (ay / nrm) * dy + (az / nrm) * dz;
+                        const float e = expf(lam * (dotp - 1.0f));
+                        acc_r += cr * e;
+                        acc_g += cg * e;
+                        acc_b += cb * e;
+                    }
+                }
+                const float d0 = fetch(0), d1 = fetch(1), d2 = fetch(2);
+                if (g == 0 && valid) {
+                    a.rgb[pt * 3 + 0] = sigmoidf(d0 + acc_r);
+                    a.rgb[pt * 3 + 1] = sigmoidf(d1 + acc_g);
+                    a.rgb[pt * 3 + 2] = sigmoidf(d2 + acc_b);
+                }
+            }
+        }
+    }
+}
+
+// Plain grid encode (tcnn.Encoding.forward): one thread per (point, level).
+__global__ void grid_encode_kernel(GridArgs ga, const float2 *table, const float *x01, int64_t n, float *out)
+{
+    const int64_t total = n * QF_MAX_LEVELS;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+         e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t pt = e >> 4;
+        const int level = (int)(e & 15);
+        LevelConst lc;
+        lc.offset = ga.offset[level];
+        lc.rows = ga.rows[level];
+        lc.res = ga.res[level];
+        lc.scale = ga.scale[level];
+        lc.hashed = (ga.hashed_mask >> level) & 1u;
+        uint32_t idx[8];
+        float frac[3];
+        float2 val[8];
+        level_indices(lc, x01[pt * 3], x01[pt * 3 + 1], x01[pt * 3 + 2], idx, frac);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) val[c] = table[idx[c]];
+        float f0, f1;
+        level_blend(val, frac, &f0, &f1);
+        out[pt * 32 + 2 * level] = f0;
+        out[pt * 32 + 2 * level + 1] = f1;
+    }
+}
+
+__global__ void sg_features_to_rgb_kernel(const float *features, int64_t stride, const float *dirs,
+                                          int64_t n, int n_lobes, float *rgb)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const float *f = features + i * stride;
+        const float dx = dirs[i * 3], dy = dirs[i * 3 + 1], dz = dirs[i * 3 + 2];
+        float r = 0.0f, g = 0.0f, b = 0.0f;
+        for (int l = 0; l < n_lobes; ++l) {
+            const float *x = f + 3 + 7 * l;
+            const float nrm = sqrtf(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
+            const float dotp = (x[0] / nrm) * dx + (x[1] / nrm) * dy + (x[2] / nrm) * dz;
+            const float e = expf(fabsf(x[3]) * (dotp - 1.0f));
+            r += x[4] * e;
+            g += x[5] * e;
+            b += x[6] * e;
+        }
+        rgb[i * 3 + 0] = sigmoidf(f[0] + r);
+        rgb[i * 3 + 1] = sigmoidf(f[1] + g);
+        rgb[i * 3 + 2] = sigmoidf(f[2] + b);
+    }
+}
+
+// Deformation field (examples/field.py:186-203): cat[x01(3), grid(32)] -> 32 -> 32 -> 1, ReLU, biases.
+// Same wave mapping as field_kernel.  k-steps of layer 1: 0..7 grid features of the lane's level quartet,
+// step 8: lane quartets 0..2 feed x01.{x,y,z}, quartet 3 feeds the constant 1 that carries b1.
+struct DeformArgs {
+    GridArgs grid;
+    const float2 *table;
+    float scale;
+    const float *w1, *b1, *w2, *b2, *wout, *bout;
+    const float *xyz;
+    int64_t n;
+    float *out;
+};
+
+constexpr int kDeformMfma = 18 + 16 + 8;
+
+__device__ float deform_weight_for(const DeformArgs &a, int m, int lane)
+{
+    const int i = lane & 15, kq = lane >> 4;
+    if (m < 18) {                        // 36(pad) -> 32 : s outer (9), mt inner (2)
+        const int s = m >> 1, mt = m & 1, row = 16 * mt + i;
+        if (s < 8) return a.w1[row * 35 + 3 + 2 * (4 * (s >> 1) + kq) + (s & 1)];
+        return kq < 3 ? a.w1[row * 35 + kq] : a.b1[row];
+    }
+    if (m < 34) {                        // 32 -> 32 : s outer (8), mt inner (2); hidden col = 16*(s>>2) + 4kq + (s&3)
+        const int q = m - 18, s = q >> 1, mt = q & 1;
+        return a.w2[(16 * mt + i) * 32 + hidden_col(s, kq)];
+    }
+    const int s = m - 34;                // 32 -> 1 (row 0 of a 16-row tile)
+    return i == 0 ? a.wout[hidden_col(s, kq)] : 0.0f;
+}
+
+__global__ __launch_bounds__(kBlock, 4) void deform_kernel(const DeformArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, p = lane & 15;
+    // image: plain [m][lane] floats (ds_read_b32); + b2[32] + bout[1]
+    for (int e = tid; e < kDeformMfma * 64; e += kBlock) lds[e] = deform_weight_for(a, e >> 6, e & 63);
+    float *bias = lds + kDeformMfma * 64;
+    if (tid < 32) bias[tid] = a.b2[tid];
+    if (tid == 32) bias[32] = a.bout[0];
+    __syncthreads();
+
+    LevelConst lc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int level = 4 * j + g;
+        lc[j].offset = a.grid.offset[level];
+        lc[j].rows = a.grid.rows[level];
+        lc[j].res = a.grid.res[level];
+        lc[j].scale = a.grid.scale[level];
+        lc[j].hashed = (a.grid.hashed_mask >> level) & 1u;
+    }
+    const int64_t n_groups = (a.n + 15) >> 4;
+    const int64_t wave_global = (int64_t)blockIdx.x * (kBlock / 64) + (tid >> 6);
+    const int64_t wave_stride = (int64_t)gridDim.x * (kBlock / 64);
+    for (int64_t grp = wave_global; grp < n_groups; grp += wave_stride) {
+        const int64_t pt_raw = grp * 16 + p;
+        const bool valid = pt_raw < a.n;
+        const int64_t pt = valid ? pt_raw : a.n - 1;
+        // (x - (-s)) / (s - (-s)), field.py:195
+        const float x01 = (a.xyz[pt * 3 + 0] + a.scale) / (a.scale + a.scale);
+        const float y01 = (a.xyz[pt * 3 + 1] + a.scale) / (a.scale + a.scale);
+        const float z01 = (a.xyz[pt * 3 + 2] + a.scale) / (a.scale + a.scale);
+        float in[9];
+        float frac[4][3];
+        float2 val[4][8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            uint32_t idx[8];
+            level_indices(lc[j], x01, y01, z01, idx, frac[j]);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) val[j][c] = a.table[idx[c]];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) level_blend(val[j], frac[j], &in[2 * j], &in[2 * j + 1]);
+        int loff = lane;
+        asm volatile("" : "+v"(loff));
+        const float *wl = lds + loff;
+        in[8] = g == 0 ? x01 : (g == 1 ? y01 : (g == 2 ? z01 : 1.0f));
+        f32x4 h1[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int s = 0; s < 9; ++s)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) h1[mt] = mfma(wl[(2 * s + mt) * 64], in[s], h1[mt]);
+        f32x4 h2[2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { h1[mt][r] = fmaxf(h1[mt][r], 0.0f); h2[mt][r] = bias[16 * mt + 4 * g + r]; }
+        }
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) h2[mt] = mfma(wl[(18 + 2 * s + mt) * 64], h1[s >> 2][s & 3], h2[mt]);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) h2[mt][r] = fmaxf(h2[mt][r], 0.0f);
+        f32x4 oa = (f32x4){0.f, 0.f, 0.f, 0.f}, ob = oa;
+#pragma unroll
+        for (int s = 0; s < 8; s += 2) {
+            oa = mfma(wl[(34 + s) * 64], h2[s >> 2][s & 3], oa);
+            ob = mfma(wl[(35 + s) * 64], h2[(s + 1) >> 2][(s + 1) & 3], ob);
+        }
+        if (g == 0 && valid) a.out[pt] = (oa[0] + ob[0]) + bias[32];
+    }
+}
+
+int fill_grid_args(const qf_grid_desc *d, GridArgs *ga)
+{
+    if (!d || d->n_levels != QF_MAX_LEVELS || d->n_features != 2) return QF_ERR_UNSUPPORTED;
+    for (int l = 0; l < QF_MAX_LEVELS; ++l) {
+        ga->offset[l] = d->offset[l];
+        ga->rows[l] = d->offset[l + 1] - d->offset[l];
+        ga->res[l] = d->resolution[l];
+        ga->scale[l] = d->scale[l];
+        const bool hashed = (d->hashed_mask >> l) & 1u;
+        if (hashed && (ga->rows[l] & (ga->rows[l] - 1u))) return QF_ERR_UNSUPPORTED;
+        // dense levels must take all three strides (res^2 <= rows), true for rows >= res^3
+        if (!hashed && (uint64_t)d->resolution[l] * d->resolution[l] > ga->rows[l]) return QF_ERR_UNSUPPORTED;
+    }
+    ga->hashed_mask = d->hashed_mask;
+    return QF_OK;
+}
+
+template <int HEAD>
+int launch_field(const FieldArgs &a, hipStream_t st)
+{
+    int n_m = kBaseMfma;
+    if (HEAD == QF_HEAD_NGP) n_m += kNgpHeadMfma;
+    if (HEAD == QF_HEAD_SG || HEAD == QF_HEAD_SG_FEATURES) n_m += kSgHeadMfmaFixed + 16 * a.nt_out;
+    const size_t lds_bytes = (size_t)(n_m * 64 + 128) * sizeof(float);
+    const int64_t n_groups = (a.n + 15) / 16;
+    int64_t blocks = qf_div_up(n_groups, kBlock / 64);
+    const int64_t cap = (int64_t)qf_cu_count_cached() * 2;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(field_kernel<HEAD>, dim3((unsigned)blocks), dim3(kBlock), lds_bytes, st, a);
+    QF_LAUNCH_CHECK();
+    return QF_OK;
+}
+
+}  // namespace
+
+extern "C" int qf_grid_encode(const qf_grid_desc *desc, const float *table, const float *x01,
+                              int64_t n, float *out, void *stream)
+{
+    if (!desc || !table || n < 0 || (n > 0 && (!x01 || !out))) return QF_ERR_INVALID_ARGUMENT;
+    GridArgs ga;
+    int rc = fill_grid_args(desc, &ga);
+    if (rc != QF_OK) return rc;
+    if (n == 0) return QF_OK;
+    hipLaunchKernelGGL(grid_encode_kernel, dim3(qf_grid_1d(n * 16, 256)), dim3(256), 0, qf_stream(stream), ga,
+                       reinterpret_cast<const float2 *>(table), x01, n, out);
+    QF_LAUNCH_CHECK();
+    return QF_OK;
+}
+
+extern "C" int qf_field_forward(const qf_field_desc *desc, const float *table, const float *base_w,
+                                const float *head_ngp_w, const qf_sg_head *head_sg, const float *xyz,
+                                const float *dirs, int64_t n, float *rgb, float *sigma, float *geo,
+                                float *features, void *stream)
+{
+    if (!desc || !table || !base_w || n < 0) return QF_ERR_INVALID_ARGUMENT;
+    FieldArgs a = {};
+    int rc = fill_grid_args(&desc->grid, &a.grid);
+    if (rc != QF_OK) return rc;
+    for (int k = 0; k < 3; ++k) {
+        a.aabb_lo[k] = desc->aabb[k];
+        a.aabb_hi[k] = desc->aabb[3 + k];
+        if (!(desc->aabb[3 + k] > desc->aabb[k])) return QF_ERR_INVALID_ARGUMENT;
+    }
+    a.table = reinterpret_cast<const float2 *>(table);
+    a.base_w = base_w;
+    a.xyz = xyz;
+    a.dirs = dirs;
+    a.n = n;
+    a.rgb = rgb;
+    a.sigma = sigma;
+    a.geo = geo;
+    a.features = features;
+    if (n == 0) return QF_OK;
+    if (!xyz) return QF_ERR_INVALID_ARGUMENT;
+    hipStream_t st = qf_stream(stream);
+    switch (desc->head) {
+    case QF_HEAD_NONE:
+        if (!sigma && !geo) return QF_ERR_INVALID_ARGUMENT;
+        return launch_field<QF_HEAD_NONE>(a, st);
+    case QF_HEAD_NGP:
+        if (!head_ngp_w || !dirs || !rgb) return QF_ERR_INVALID_ARGUMENT;
+        a.head_w = head_ngp_w;
+        return launch_field<QF_HEAD_NGP>(a, st);
+    case QF_HEAD_SG:
+    case QF_HEAD_SG_FEATURES:
+        if (!head_sg || !head_sg->w1 || !head_sg->b1 || !head_sg->w2 || !head_sg->b2 || !head_sg->wout ||
+            !head_sg->bout)
+            return QF_ERR_INVALID_ARGUMENT;
+        if (desc->n_lobes < 1 || desc->n_lobes > QF_MAX_LOBES) return QF_ERR_UNSUPPORTED;
+        a.sg = *head_sg;
+        a.n_lobes = desc->n_lobes;
+        a.n_out = 3 + 7 * desc->n_lobes;
+        a.nt_out = (a.n_out + 15) / 16;
+        if (desc->head == QF_HEAD_SG) {
+            if (!dirs || !rgb) return QF_ERR_INVALID_ARGUMENT;
+            return launch_field<QF_HEAD_SG>(a, st);
+        }
+        if (!features) return QF_ERR_INVALID_ARGUMENT;
+        return launch_field<QF_HEAD_SG_FEATURES>(a, st);
+    default:
+        return QF_ERR_INVALID_ARGUMENT;
+    }
+}
+
+extern "C" int qf_sg_features_to_rgb(const float *features, int64_t feat_stride, const float *dirs, int64_t n,
+                                     int32_t n_lobes, float *rgb, void *stream)
+{
+    if (n < 0 || n_lobes < 1 || n_lobes > QF_MAX_LOBES || feat_stride < 3 + 7 * n_lobes) return QF_ERR_INVALID_ARGUMENT;
+    if (n == 0) return QF_OK;
+    if (!features || !dirs || !rgb) return QF_ERR_INVALID_ARGUMENT;
+    hipLaunchKernelGGL(sg_features_to_rgb_kernel, dim3(qf_grid_1d(n, 256)), dim3(256), 0, qf_stream(stream),
+                       features, feat_stride, dirs, n, (int)n_lobes, rgb);
+    QF_LAUNCH_CHECK();
+    return QF_OK;
+}
+
+extern "C" int qf_deform_field_forward(const qf_grid_desc *grid, const float *table, float scale, int32_t hidden,
+                                       const float *w1, const float *b1, const float *w2, const float *b2,
+                                       const float *wout, const float *bout, const float *xyz, int64_t n, float *out,
+                                       void *stream)
+{
+    if (!grid || !table || n < 0 || !(scale > 0.0f)) return QF_ERR_INVALID_ARGUMENT;
+    if (hidden != 32) return QF_ERR_UNSUPPORTED;
+    if (!w1 || !b1 || !w2 || !b2 || !wout || !bout) return QF_ERR_INVALID_ARGUMENT;
+    DeformArgs a = {};
+    int rc = fill_grid_args(grid, &a.grid);
+    if (rc != QF_OK) return rc;
+    if (n == 0) return QF_OK;
+    if (!xyz || !out) return QF_ERR_INVALID_ARGUMENT;
+    a.table = reinterpret_cast<const float2 *>(table);
+    a.scale = scale;
+    a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2; a.wout = wout; a.bout = bout;
+    a.xyz = xyz;
+    a.n = n;
+    a.out = out;
+    const size_t lds_bytes = (size_t)(kDeformMfma * 64 + 64) * sizeof(float);
+    int64_t blocks = qf_div_up((n + 15) / 16, kBlock / 64);
+    const int64_t cap = (int64_t)qf_cu_count_cached() * 2;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(deform_kernel, dim3((unsigned)blocks), dim3(kBlock), lds_bytes, qf_stream(stream), a);
+    QF_LAUNCH_CHECK();
+    return QF_OK;
+}
