@@ -1,0 +1,232 @@
+"""Headline benchmark: rays/s of the mesh-quadrature render at 800x800 (BASELINE.json configs[1]).
+
+    python bench.py --gpus N --steps K --warmup W
+
+One step = one full 800x800 frame through the hot path on synthetic inputs already resident in HBM:
+BVH multi-hit traversal -> sample packing -> fused field evaluation (fp32 hash grid + MLPs) -> per-ray
+compositing.  N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL): every rank renders its own
+frame (weak scaling, no collective on the data path) and the finished tiles are exchanged with one
+all_gather_into_tensor per step.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+W = H = 800
+MAX_HITS = 25
+LOG2_T = 19
+N_SHELLS, SUBDIV = 12, 6           # 12 x 81,920 = 983,040 triangles
+STEP = 5e-3
+HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+ALG_BYTES_PER_POINT = 16 * 8 * 2 * 4   # 16 levels x 8 corners x 2 features x 4 B
+
+
+def build_scene(device, seed=42):
+    from quadraturefields_amd import synthetic
+    from quadraturefields_amd.mesh_utils import MeshIntersection
+    from quadraturefields_amd.radiance_fields.ngp import NGPRadianceField
+    mesh = synthetic.shell_mesh(n_shells=N_SHELLS, subdivisions=SUBDIV, seed=seed)
+    mi = MeshIntersection(mesh, simplify_mesh=False, scale=1.0, num_intersections=MAX_HITS, render_step_size=STEP,
+                          device=device)
+    field = NGPRadianceField(aabb=[-1.5] * 3 + [1.5] * 3, log2_hashmap_size=LOG2_T)
+    field.load_state_dict(synthetic.seeded_ngp_state(LOG2_T, field.mlp_base.grid.n_rows, seed=seed), strict=False)
+    return mesh, mi, field.to(device)
+
+
+class Stages:
+    """One frame, stage by stage, with a HIP event pair around each stage on the launch stream."""
+    NAMES = ("traverse", "pack", "field", "composite")
+
+    def __init__(self, mi, field):
+        self.mi, self.field = mi, field
+        self.ev = {k: [] for k in self.NAMES}
+
+    def _timed(self, name, fn, record):
+        if not record:
+            return fn()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        out = fn()
+        b.record()
+        self.ev[name].append((a, b))
+        return out
+
+    def frame(self, o, d, record=False):
+        from quadraturefields_amd import utils
+        n_rays = o.shape[0]
+        ri = self.mi.rayintersector
+        hits = self._timed("traverse", lambda: ri.hits(o, d, MAX_HITS, image_width=W), record)
+        data = self._timed("pack", lambda: self._pack(hits), record)
+        xyz, dirs, index_ray, ts, index_tri, org = data
+        rgbs, sigmas = self._timed("field", lambda: self.field(xyz, dirs), record)
+        out = self._timed("composite", lambda: utils.derive_properties(
+            rgbs, sigmas.reshape(-1), ts, STEP, None, index_ray, bg_color="white", N=n_rays), record)
+        rgb, alpha, _, depth, _ = out
+        return rgb, alpha, depth, xyz.shape[0]
+
+    def _pack(self, hits):
+        from quadraturefields_amd import _C
+        hit_tri, hit_t, hit_count, o, d = hits
+        n = o.shape[0]
+        csum = torch.cumsum(hit_count.to(torch.int64), dim=0)
+        total = int(csum[-1].item())
+        offset = (csum - hit_count).contiguous()
+        dev = o.device
+        xyz = torch.empty((total, 3), dtype=torch.float32, device=dev)
+        dirs = torch.empty((total, 3), dtype=torch.float32, device=dev)
+        org = torch.empty((total, 3), dtype=torch.float32, device=dev)
+        index_ray = torch.empty((total,), dtype=torch.int64, device=dev)
+        index_tri = torch.empty((total,), dtype=torch.int64, device=dev)
+        depth = torch.empty((total,), dtype=torch.float32, device=dev)
+        _C.check(_C.lib().qf_pack_samples(_C.ptr(o), _C.ptr(d), n, MAX_HITS, _C.ptr(hit_tri), _C.ptr(hit_t),
+                                          _C.ptr(hit_count), _C.ptr(offset), _C.ptr(xyz), _C.ptr(dirs),
+                                          _C.ptr(index_ray), _C.ptr(depth), _C.ptr(index_tri), _C.ptr(org),
+                                          _C.stream()), "qf_pack_samples")
+        return xyz, dirs, index_ray, depth, index_tri, org
+
+    def stage_ms(self):
+        torch.cuda.synchronize()
+        return {k: (float(np.mean([a.elapsed_time(b) for a, b in v])) if v else None) for k, v in self.ev.items()}
+
+
+def cpu_baseline(mesh, field, cam_o, cam_d, crop=40):
+    """The oracle (CPU restatement of the reference path) timed on this box's host cores on a bounded sample:
+    the centre crop x crop pixels of frame 0 through brute-force multi-hit intersection (OpenMP C), torch-CPU
+    field evaluation and compositing."""
+    from oracle import meshpath as om
+    from tests import helpers
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    y0 = x0 = (W - crop) // 2
+    idx = (torch.arange(y0, y0 + crop)[:, None] * W + torch.arange(x0, x0 + crop)[None, :]).reshape(-1)
+    o, d = cam_o[idx].numpy(), cam_d[idx].numpy()
+    wts = helpers.oracle_ngp_weights(field)
+    bf = om.BruteForceIntersector(mesh.vertices, mesh.faces)
+    t0 = time.perf_counter()
+    sample = om.sampling_raytrace_numpy(bf, d, o, MAX_HITS)
+    t1 = time.perf_counter()
+    data = om.to_loader_tensors(sample)
+    rgb = om.render_image_finetune(wts, None, data, crop * crop)[0]
+    t2 = time.perf_counter()
+    n_pts = data[0].shape[0]
+    return {
+        "value": crop * crop / (t2 - t0), "unit": "rays/s", "cores": cores, "kind": "port",
+        "sample": f"centre {crop}x{crop} crop of frame 0 ({crop * crop} rays, {n_pts} quadrature points): "
+                  f"brute-force intersection over {mesh.faces.shape[0]} triangles {t1 - t0:.1f} s (OpenMP C, "
+                  f"{cores} threads) + torch-CPU field/compositing {t2 - t1:.2f} s "
+                  f"({n_pts / max(t2 - t1, 1e-9):.0f} points/s)",
+    }, rgb, idx
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from quadraturefields_amd import parallel, synthetic
+    rank, local_rank, world = parallel.init_from_env("nccl")
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+
+    mesh, mi, field = build_scene(device)
+    n_frames = args.steps + args.warmup
+    cams = synthetic.orbit_cameras(n_frames * world, seed=42)
+    focal = synthetic.lego_focal(W)
+    rays = [synthetic.camera_rays(cams[i * world + rank], focal, W, H, device=device) for i in range(n_frames)]
+    stages = Stages(mi, field)
+    gather_buf = torch.empty((world, W * H, 5), dtype=torch.float32, device=device) if world > 1 else None
+
+    def step(i, record):
+        o, d = rays[i]
+        rgb, alpha, depth, n_pts = stages.frame(o, d, record)
+        if world > 1:
+            torch.distributed.all_gather_into_tensor(gather_buf, torch.cat([rgb, alpha, depth], dim=1))
+        return rgb, n_pts
+
+    for i in range(args.warmup):
+        step(i, False)
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    pts = 0
+    for i in range(args.warmup, n_frames):
+        rgb, n_pts = step(i, True)
+        pts += n_pts
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed, float(pts)], dtype=torch.float64, device=device)
+    if world > 1:
+        tmax = t.clone()
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        tsum = t.clone()
+        torch.distributed.all_reduce(tsum, op=torch.distributed.ReduceOp.SUM)
+        elapsed, pts_total = float(tmax[0]), float(tsum[1])
+    else:
+        pts_total = float(pts)
+
+    if rank != 0:
+        return
+    ms = stages.stage_ms()
+    rays_total = W * H * args.steps * world
+    pts_per_launch = pts / args.steps
+    field_s = (ms["field"] or 0.0) * 1e-3
+    achieved = pts_per_launch * ALG_BYTES_PER_POINT / field_s / 1e9 if field_s > 0 else 0.0
+    result = {
+        "metric": "rays/sec at 800x800 Lego (mesh-quadrature render: BVH traversal + hash-grid/MLP field + compositing)",
+        "value": rays_total / elapsed,
+        "unit": "rays/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": "Lego 800x800 (configs[1]), 1xMI355X per frame, fp32 hash-grid + tiny-MLP HIP kernels",
+            "rays_per_frame": W * H, "max_hits": MAX_HITS, "triangles": int(mesh.faces.shape[0]),
+            "log2_hashmap_size": LOG2_T, "render_step_size": STEP, "up_sample": 1,
+            "parallelism": f"{world} rank(s), one frame per rank per step" + (", all_gather of tiles" if world > 1 else ""),
+        },
+        "quadrature_points_per_frame": pts_per_launch,
+        "field_evals_per_s": pts_total / elapsed,
+        "field_evals_per_s_in_kernel": pts_per_launch / field_s if field_s > 0 else None,
+        "stage_ms": ms,
+        "roofline": {
+            "kernel": "field_kernel<NGP> (hash-grid gather + MLPs)", "bound": "hbm", "achieved": achieved,
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "algorithmic_bytes_per_point": ALG_BYTES_PER_POINT, "points_per_launch": pts_per_launch,
+            "avg_launch_ms": ms["field"],
+        },
+    }
+    if not args.no_cpu_baseline:
+        base, rgb_o, idx = cpu_baseline(mesh, field, rays[0][0].cpu(), rays[0][1].cpu())
+        rgb0 = stages.frame(rays[0][0], rays[0][1])[0].cpu()[idx]
+        base["max_abs_err_vs_hip"] = float((rgb0 - rgb_o).abs().max())
+        mse = float(((rgb0.double() - rgb_o.double()) ** 2).mean())
+        base["psnr_hip_vs_oracle_db"] = float("inf") if mse == 0 else -10.0 * float(np.log10(mse))
+        result["cpu_baseline"] = base
+    print(json.dumps(result))
+
+
+if __name__ == "__main__":
+    main()

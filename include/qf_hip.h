@@ -63,6 +63,11 @@ int qf_grid_desc_init(qf_grid_desc *desc /* host, out */, uint32_t n_levels,
 int qf_grid_encode(const qf_grid_desc *desc /* host */, const float *table /* [rows,2] */,
                    const float *x01, int64_t n, float *out /* [n,32] */, void *stream);
 
+/* Grid + 1-hidden-layer 64-wide MLP: x01 [n,3] -> raw [n,16].  Replaces
+ * tcnn.NetworkWithInputEncoding.forward for mlp_base (ngp.py:764-768); base_w as below.       */
+int qf_grid_mlp_forward(const qf_grid_desc *grid /* host */, const float *table, const float *base_w,
+                        const float *x01, int64_t n, float *out16, void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * Radiance fields.  Replaces NGPRadianceField.query_density/_query_rgb/forward
  * (ngp.py:757-809) and NGPRadianceFieldSGNew.query_density/_query_rgb/features/forward

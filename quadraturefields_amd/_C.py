@@ -50,6 +50,7 @@ _SIGNATURES = {
     "qf_device_cu_count": (c_int, []),
     "qf_grid_desc_init": (c_int, [POINTER(GridDesc), c_uint32, c_uint32, c_uint32, c_double]),
     "qf_grid_encode": (c_int, [POINTER(GridDesc), _P, _P, c_int64, _P, _P]),
+    "qf_grid_mlp_forward": (c_int, [POINTER(GridDesc), _P, _P, _P, c_int64, _P, _P]),
     "qf_field_forward": (c_int, [POINTER(FieldDesc), _P, _P, _P, POINTER(SGHead), _P, _P, c_int64, _P, _P, _P, _P, _P]),
     "qf_sg_features_to_rgb": (c_int, [_P, c_int64, _P, c_int64, c_int32, _P, _P]),
     "qf_deform_field_forward": (c_int, [POINTER(GridDesc), _P, c_float, c_int32, _P, _P, _P, _P, _P, _P, _P, c_int64, _P, _P]),

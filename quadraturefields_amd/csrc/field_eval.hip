@@ -42,7 +42,6 @@ struct GridArgs {
 struct FieldArgs {
     GridArgs grid;
     float aabb_lo[3];
-    float aabb_inv[3];   // unused: division kept for parity, see normalise()
     float aabb_hi[3];
     const float2 *table;
     const float *base_w;
@@ -55,6 +54,7 @@ struct FieldArgs {
     float *sigma;
     float *geo;
     float *features;
+    float *raw16;       // optional [n,16]: raw base-MLP outputs (tcnn NetworkWithInputEncoding.forward)
     int32_t n_lobes;
     int32_t n_out;      // 3 + 7L
     int32_t nt_out;     // ceil(n_out / 16)
@@ -314,6 +314,7 @@ __global__ __launch_bounds__(kBlock, 4) void field_kernel(const FieldArgs a)
         // density = exp(raw - 1) * selector, ngp.py:772-775 (B-5, B-6)
         const float density = selector ? expf(base_out[0] - 1.0f) : 0.0f;
         if (g == 0 && valid && a.sigma) a.sigma[pt] = density;
+        if (a.raw16 && valid) *reinterpret_cast<f32x4 *>(a.raw16 + pt * 16 + 4 * g) = base_out;
         if (a.geo && valid) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -772,4 +773,22 @@ extern "C" int qf_deform_field_forward(const qf_grid_desc *grid, const float *ta
     hipLaunchKernelGGL(deform_kernel, dim3((unsigned)blocks), dim3(kBlock), lds_bytes, qf_stream(stream), a);
     QF_LAUNCH_CHECK();
     return QF_OK;
+}
+
+extern "C" int qf_grid_mlp_forward(const qf_grid_desc *grid, const float *table, const float *base_w, const float *x01,
+                                   int64_t n, float *out16, void *stream)
+{
+    if (!grid || !table || !base_w || n < 0) return QF_ERR_INVALID_ARGUMENT;
+    FieldArgs a = {};
+    int rc = fill_grid_args(grid, &a.grid);
+    if (rc != QF_OK) return rc;
+    if (n == 0) return QF_OK;
+    if (!x01 || !out16) return QF_ERR_INVALID_ARGUMENT;
+    for (int k = 0; k < 3; ++k) { a.aabb_lo[k] = 0.0f; a.aabb_hi[k] = 1.0f; }   // (x - 0) / (1 - 0) == x exactly
+    a.table = reinterpret_cast<const float2 *>(table);
+    a.base_w = base_w;
+    a.xyz = x01;
+    a.n = n;
+    a.raw16 = out16;
+    return launch_field<QF_HEAD_NONE>(a, qf_stream(stream));
 }

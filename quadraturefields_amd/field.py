@@ -1,0 +1,81 @@
+"""Deformation / quadrature scalar field on the gfx950 kernels.
+
+Mirrors ``Field`` of ``examples/field.py:130-270`` as the render path uses it
+(``examples/utils.py:555-566``: ``field_net(x, return_grad=False)[0]``): hash grid (tcnn ``Encoding``)
+followed by ``cat[x01, h] -> BasicDecoder``.  Forward only; gradients of the field w.r.t. its input
+(``field_grad`` and the training losses) belong to training and are not implemented.
+"""
+import numpy as np
+import torch
+from torch import nn
+
+from . import _C
+from . import tinycudann as tcnn
+
+
+class BasicDecoder(nn.Module):
+    """examples/field.py's BasicDecoder variant: like ngp.BasicDecoder plus ``bias_last``."""
+
+    def __init__(self, input_dim, output_dim, activation, bias, layer=nn.Linear, num_layers=1, hidden_dim=128,
+                 skip=[], bias_last=True):
+        super().__init__()
+        self.input_dim, self.output_dim, self.activation = input_dim, output_dim, activation
+        self.num_layers, self.hidden_dim, self.skip = num_layers, hidden_dim, ([] if skip is None else skip)
+        self.layers = nn.ModuleList(
+            [layer(input_dim if i == 0 else hidden_dim, hidden_dim, bias=bias) for i in range(num_layers)])
+        self.lout = layer(hidden_dim, output_dim, bias=bias_last)
+
+    def forward(self, x):
+        h = x
+        for l in self.layers:
+            h = self.activation(l(h))
+        return self.lout(h)
+
+
+class Field(nn.Module):
+    def __init__(self, scale, back_prop=0, precision=16, log2_T=19, L=16, max_res=512, output_dim=1, min_res=16,
+                 hidden_size=32, num_features=2, nl="elu", bias=True, bias_last=True):
+        super().__init__()
+        if nl != "relu" or output_dim != 1 or hidden_size != 32 or not bias or not bias_last:
+            raise NotImplementedError("the fused kernel implements the finetune configuration of "
+                                      "train_finetune.py:387-399 (relu, hidden 32, output 1, biases)")
+        self.output_dim = output_dim
+        self.dtype = torch.float16 if precision == 16 else torch.float32   # kept for API parity; compute is fp32
+        self.scale = scale
+        self.register_buffer("center", torch.zeros(1, 3))
+        self.register_buffer("xyz_min", -torch.ones(1, 3) * scale)
+        self.register_buffer("xyz_max", torch.ones(1, 3) * scale)
+        self.register_buffer("half_size", (self.xyz_max - self.xyz_min) / 2)
+        self.back_prop = back_prop
+        b = np.exp(np.log(max_res * scale / min_res) / (L - 1))
+        self.xyz_encoder = tcnn.Encoding(
+            n_input_dims=3,
+            encoding_config={"otype": "Grid", "type": "Hash", "n_levels": L, "n_features_per_level": num_features,
+                             "log2_hashmap_size": log2_T, "base_resolution": min_res, "per_level_scale": b,
+                             "interpolation": "Linear"},
+            dtype=self.dtype)
+        self.decoder_field = BasicDecoder(input_dim=L * num_features + 3, output_dim=output_dim,
+                                          activation=torch.nn.ReLU(), bias=bias, num_layers=2,
+                                          hidden_dim=hidden_size, skip=[], bias_last=bias_last)
+
+    def density(self, x):
+        """[N,3] in [-scale, scale] -> [N,1].  field.py:186-203, one fused launch."""
+        x = _C.f32c(x.reshape(-1, 3))
+        n = x.shape[0]
+        out = torch.empty((n,), dtype=torch.float32, device=x.device)
+        d = self.decoder_field
+        w = [_C.f32c(t.detach()) for t in (d.layers[0].weight, d.layers[0].bias, d.layers[1].weight,
+                                           d.layers[1].bias, d.lout.weight, d.lout.bias)]
+        _C.check(_C.lib().qf_deform_field_forward(
+            self.xyz_encoder.grid.desc, _C.ptr(self.xyz_encoder.params.detach()), float(self.scale), 32,
+            *[_C.ptr(t) for t in w], _C.ptr(x), n, _C.ptr(out), _C.stream()), "qf_deform_field_forward")
+        return out[:, None]
+
+    def field(self, x):
+        return self.density(x)[:, 0:self.output_dim]
+
+    def forward(self, x, return_grad=True):
+        """(field [N,1], None).  field.py:206-223 with return_grad=False."""
+        if return_grad:
+            raise NotImplementedError("field gradients are a training feature (SURVEY.md section 8f item 1)")
+        return self.field(x), None

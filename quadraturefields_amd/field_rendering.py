@@ -1,0 +1,228 @@
+"""nerfacc-style packed volume rendering on the gfx950 compositing kernels.
+
+Mirrors ``examples/field_rendering.py`` of the reference (a vendored copy of nerfacc 0.5.3 ``volrend``
+plus ``rendering_field``) together with the ``nerfacc.pack.pack_info`` / ``nerfacc.scan.exclusive_sum``
+/ ``exclusive_prod`` it imports (:10-11): same function names, arguments, assertions and return values.
+Flattened (packed) inputs run on the device kernels; ``rgb_sigma_fn`` / ``rgb_alpha_fn`` stay Python
+callables.  Batched [n_rays, n_samples] inputs are packed row by row.  Inference only (no autograd).
+"""
+from typing import Callable, Dict, Optional, Tuple
+
+import torch
+from torch import Tensor
+
+from . import _C
+
+
+# ---------------------------------------------------------------- nerfacc.pack / nerfacc.scan
+def pack_info(ray_indices: Tensor, n_rays: Optional[int] = None) -> Tensor:
+    """(start, count) per ray, int64 [n_rays, 2]; ``ray_indices`` must be sorted (as nerfacc requires)."""
+    ray_indices = _C.i64c(ray_indices)
+    if n_rays is None:
+        n_rays = int(ray_indices.max().item()) + 1 if ray_indices.numel() else 0
+    out = torch.empty((n_rays, 2), dtype=torch.int64, device=ray_indices.device)
+    _C.check(_C.lib().qf_pack_info(_C.ptr(ray_indices), ray_indices.shape[0], n_rays, _C.ptr(out), _C.stream()),
+             "qf_pack_info")
+    return out
+
+
+def _batched_info(x: Tensor) -> Tensor:
+    rows, cols = x.reshape(-1, x.shape[-1]).shape
+    starts = torch.arange(rows, device=x.device, dtype=torch.int64) * cols
+    return torch.stack([starts, torch.full_like(starts, cols)], dim=-1).contiguous()
+
+
+def _scan(x: Tensor, packed_info: Optional[Tensor], mode: int) -> Tensor:
+    shape = x.shape
+    if packed_info is None:
+        packed_info = _batched_info(x)
+    xf = _C.f32c(x.reshape(-1))
+    info = _C.i64c(packed_info)
+    out = torch.empty_like(xf)
+    _C.check(_C.lib().qf_exclusive_scan(_C.ptr(xf), _C.ptr(info), info.shape[0], xf.shape[0], mode, _C.ptr(out),
+                                        _C.stream()), "qf_exclusive_scan")
+    return out.reshape(shape)
+
+
+def exclusive_sum(inputs: Tensor, packed_info: Optional[Tensor] = None) -> Tensor:
+    """Per-chunk exclusive prefix sum (along the last dim when ``packed_info`` is None)."""
+    return _scan(inputs, packed_info, 0)
+
+
+def exclusive_prod(inputs: Tensor, packed_info: Optional[Tensor] = None) -> Tensor:
+    """Per-chunk exclusive prefix product."""
+    return _scan(inputs, packed_info, 1)
+
+
+# ------------------------------------------------------------------------------ volrend
+def render_transmittance_from_alpha(alphas, packed_info=None, ray_indices=None, n_rays=None, prefix_trans=None):
+    """T_i = prod_{j<i}(1 - alpha_j).  Reference: field_rendering.py:161-206."""
+    if ray_indices is not None and packed_info is None:
+        packed_info = pack_info(ray_indices, n_rays)
+    trans = exclusive_prod(1 - alphas, packed_info)
+    if prefix_trans is not None:
+        trans = trans * prefix_trans
+    return trans
+
+
+def render_transmittance_from_density(t_starts, t_ends, sigmas, packed_info=None, ray_indices=None, n_rays=None,
+                                      prefix_trans=None):
+    """(T, alpha) from densities.  Reference: field_rendering.py:209-264."""
+    if ray_indices is not None and packed_info is None:
+        packed_info = pack_info(ray_indices, n_rays)
+    sigmas_dt = sigmas * (t_ends - t_starts)
+    alphas = 1.0 - torch.exp(-sigmas_dt)
+    trans = torch.exp(-exclusive_sum(sigmas_dt, packed_info))
+    if prefix_trans is not None:
+        trans = trans * prefix_trans
+    return trans, alphas
+
+
+def render_weight_from_alpha(alphas, packed_info=None, ray_indices=None, n_rays=None, prefix_trans=None):
+    """(w, T).  Reference: field_rendering.py:267-309."""
+    trans = render_transmittance_from_alpha(alphas, packed_info, ray_indices, n_rays, prefix_trans)
+    return trans * alphas, trans
+
+
+def render_weight_from_density(t_starts, t_ends, sigmas, packed_info=None, ray_indices=None, n_rays=None,
+                               prefix_trans=None):
+    """(w, T, alpha).  Reference: field_rendering.py:312-362."""
+    trans, alphas = render_transmittance_from_density(t_starts, t_ends, sigmas, packed_info, ray_indices, n_rays,
+                                                      prefix_trans)
+    return trans * alphas, trans, alphas
+
+
+@torch.no_grad()
+def render_visibility_from_alpha(alphas, packed_info=None, ray_indices=None, n_rays=None, early_stop_eps=1e-4,
+                                 alpha_thre=0.0, prefix_trans=None):
+    """Reference: field_rendering.py:365-418."""
+    trans = render_transmittance_from_alpha(alphas, packed_info, ray_indices, n_rays, prefix_trans)
+    vis = trans >= early_stop_eps
+    if alpha_thre > 0:
+        vis = vis & (alphas >= alpha_thre)
+    return vis
+
+
+@torch.no_grad()
+def render_visibility_from_density(t_starts, t_ends, sigmas, packed_info=None, ray_indices=None, n_rays=None,
+                                   early_stop_eps=1e-4, alpha_thre=0.0, prefix_trans=None):
+    """Reference: field_rendering.py:421-480."""
+    trans, alphas = render_transmittance_from_density(t_starts, t_ends, sigmas, packed_info, ray_indices, n_rays,
+                                                      prefix_trans)
+    vis = trans >= early_stop_eps
+    if alpha_thre > 0:
+        vis = vis & (alphas >= alpha_thre)
+    return vis
+
+
+def _accumulate(weights: Tensor, values: Optional[Tensor], info: Tensor, n_rows: int) -> Tensor:
+    w = _C.f32c(weights.reshape(-1))
+    c = 1 if values is None else values.shape[-1]
+    v = None if values is None else _C.f32c(values.reshape(-1, c))
+    out = torch.empty((n_rows, c), dtype=torch.float32, device=w.device)
+    _C.check(_C.lib().qf_accumulate_along_rays(_C.ptr(w), _C.ptr(v), c, _C.ptr(info), n_rows, w.shape[0],
+                                               _C.ptr(out), _C.stream()), "qf_accumulate_along_rays")
+    return out
+
+
+def accumulate_along_rays(weights: Tensor, values: Optional[Tensor] = None, ray_indices: Optional[Tensor] = None,
+                          n_rays: Optional[int] = None) -> Tensor:
+    """sum_i w_i v_i per ray, [n_rays, D].  Reference: field_rendering.py:483-547.
+    Deterministic (per-ray sequential) instead of index_add_ atomics; needs sorted ``ray_indices``."""
+    if values is not None:
+        assert values.dim() == weights.dim() + 1
+        assert weights.shape == values.shape[:-1]
+    if ray_indices is not None:
+        assert n_rays is not None, "n_rays must be provided"
+        assert weights.dim() == 1, "weights must be flattened"
+        return _accumulate(weights, values, pack_info(ray_indices, n_rays), n_rays)
+    lead = weights.shape[:-1]
+    out = _accumulate(weights, values, _batched_info(weights), int(torch.tensor(lead).prod()) if lead else 1)
+    return out.reshape(tuple(lead) + (out.shape[-1],))
+
+
+def accumulate_along_rays_(weights: Tensor, values: Optional[Tensor] = None, ray_indices: Optional[Tensor] = None,
+                           outputs: Optional[Tensor] = None) -> None:
+    """In-place variant.  Reference: field_rendering.py:550-573."""
+    if ray_indices is not None:
+        assert weights.dim() == 1, "weights must be flattened"
+        d = 1 if values is None else values.shape[-1]
+        assert outputs.dim() == 2 and outputs.shape[-1] == d, "outputs must be of shape (n_rays, D)"
+        outputs.add_(accumulate_along_rays(weights, values, ray_indices, outputs.shape[0]))
+    else:
+        outputs.add_(accumulate_along_rays(weights, values))
+
+
+def _query(fn, t_starts, t_ends, ray_indices):
+    if t_starts.shape[0] != 0:
+        return fn(t_starts, t_ends, ray_indices)
+    return (torch.empty((0, 3), device=t_starts.device), torch.empty((0,), device=t_starts.device))
+
+
+def rendering(t_starts: Tensor, t_ends: Tensor, ray_indices: Optional[Tensor] = None, n_rays: Optional[int] = None,
+              rgb_sigma_fn: Optional[Callable] = None, rgb_alpha_fn: Optional[Callable] = None,
+              render_bkgd: Optional[Tensor] = None) -> Tuple[Tensor, Tensor, Tensor, Dict]:
+    """Render packed samples: (colors [R,3], opacities [R,1], depths [R,1], extras).
+    Reference: field_rendering.py:14-158.  The density branch on flattened input is one fused launch
+    (weights + the three per-ray accumulations)."""
+    if ray_indices is not None:
+        assert t_starts.shape == t_ends.shape == ray_indices.shape, \
+            "Since nerfacc 0.5.0, t_starts, t_ends and ray_indices must have the same shape (N,). "
+    if rgb_sigma_fn is None and rgb_alpha_fn is None:
+        raise ValueError("At least one of `rgb_sigma_fn` and `rgb_alpha_fn` should be specified.")
+
+    if rgb_sigma_fn is not None:
+        rgbs, sigmas = _query(rgb_sigma_fn, t_starts, t_ends, ray_indices)
+        assert rgbs.shape[-1] == 3, "rgbs must have 3 channels, got {}".format(rgbs.shape)
+        assert sigmas.shape == t_starts.shape, "sigmas must have shape of (N,)! Got {}".format(sigmas.shape)
+        if ray_indices is not None:
+            info = pack_info(ray_indices, n_rays)
+            n = t_starts.shape[0]
+            dev = t_starts.device
+            ts, te, sg, rg = _C.f32c(t_starts), _C.f32c(t_ends), _C.f32c(sigmas), _C.f32c(rgbs)
+            weights, trans, alphas = (torch.empty(n, dtype=torch.float32, device=dev) for _ in range(3))
+            colors = torch.empty((n_rays, 3), dtype=torch.float32, device=dev)
+            opacities = torch.empty((n_rays, 1), dtype=torch.float32, device=dev)
+            depths = torch.empty((n_rays, 1), dtype=torch.float32, device=dev)
+            bk = None if render_bkgd is None else _C.f32c(render_bkgd.reshape(3).to(dev))
+            _C.check(_C.lib().qf_render_from_density(
+                _C.ptr(ts), _C.ptr(te), _C.ptr(sg), _C.ptr(rg), _C.ptr(info), n_rays, n, _C.ptr(bk),
+                _C.ptr(weights), _C.ptr(trans), _C.ptr(alphas), _C.ptr(colors), _C.ptr(opacities), _C.ptr(depths),
+                _C.stream()), "qf_render_from_density")
+            extras = {"weights": weights, "alphas": alphas, "trans": trans, "sigmas": sigmas, "rgbs": rgbs}
+            return colors, opacities, depths, extras
+        weights, trans, alphas = render_weight_from_density(t_starts, t_ends, sigmas)
+        extras = {"weights": weights, "alphas": alphas, "trans": trans, "sigmas": sigmas, "rgbs": rgbs}
+    else:
+        rgbs, alphas = _query(rgb_alpha_fn, t_starts, t_ends, ray_indices)
+        assert rgbs.shape[-1] == 3, "rgbs must have 3 channels, got {}".format(rgbs.shape)
+        assert alphas.shape == t_starts.shape, "alphas must have shape of (N,)! Got {}".format(alphas.shape)
+        weights, trans = render_weight_from_alpha(alphas, ray_indices=ray_indices, n_rays=n_rays)
+        extras = {"weights": weights, "trans": trans, "rgbs": rgbs, "alphas": alphas}
+
+    colors = accumulate_along_rays(weights, values=rgbs, ray_indices=ray_indices, n_rays=n_rays)
+    opacities = accumulate_along_rays(weights, values=None, ray_indices=ray_indices, n_rays=n_rays)
+    depths = accumulate_along_rays(weights, values=(t_starts + t_ends)[..., None] / 2.0, ray_indices=ray_indices,
+                                   n_rays=n_rays)
+    depths = depths / opacities.clamp_min(torch.finfo(rgbs.dtype).eps)
+    if render_bkgd is not None:
+        colors = colors + render_bkgd * (1.0 - opacities)
+    return colors, opacities, depths, extras
+
+
+def rendering_field(t_starts: Tensor, t_ends: Tensor, ray_indices: Optional[Tensor] = None,
+                    n_rays: Optional[int] = None, rgb_sigma_fn: Optional[Callable] = None,
+                    rgb_alpha_fn: Optional[Callable] = None, render_bkgd: Optional[Tensor] = None):
+    """``rendering`` plus the weights of the reversed rays: (colors, opacities, depths, weights, weights_rev).
+    Reference: field_rendering.py:575-733 (its chunking quirk on the flipped ray ids is kept: pack_info lays
+    chunks out in ascending ray-id order even though the flipped ids descend)."""
+    colors, opacities, depths, extras = rendering(t_starts, t_ends, ray_indices, n_rays, rgb_sigma_fn=rgb_sigma_fn,
+                                                  rgb_alpha_fn=rgb_alpha_fn, render_bkgd=render_bkgd)
+    weights, sigmas = extras["weights"], extras["sigmas"]
+    max_val = torch.max(t_starts) + torch.max(t_ends)
+    ts_r = torch.flip(max_val - t_starts, dims=[0])
+    te_r = torch.flip(max_val - t_ends, dims=[0])
+    # pack_info of the flipped ids has the same counts; starts = cumsum(counts) - counts in ray-id order
+    info = pack_info(ray_indices, n_rays)
+    weights_rev, _, _ = render_weight_from_density(te_r, ts_r, torch.flip(sigmas, dims=[0]), packed_info=info)
+    return colors, opacities, depths, weights, torch.flip(weights_rev, dims=[0])

@@ -1,0 +1,210 @@
+"""Ray / mesh quadrature points on the gfx950 BVH kernels.
+
+Mirrors the live part of ``examples/mesh_utils.py`` of the reference: ``RayIntersector`` (the duck type
+of the trimesh / OptiX intersectors, :75-109), ``MeshIntersection`` (:180-412: ``sampling_raytrace_numpy``,
+``sampling_indexing``, ``find_deltas``) and ``MeshFinetune`` (:112-156).  The K-iteration Embree loop, the
+numpy argsort / lexsort and the device->host->device round trip of ``sampling_indexing`` are replaced by
+one traversal launch that emits every ray's hits already ordered front to back, plus a per-ray device
+re-sort after deformation.
+"""
+import ctypes
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _C, spc_render
+from .mesh_io import TriMesh, load_mesh
+
+
+def _as_device_f32(x, device) -> torch.Tensor:
+    if isinstance(x, np.ndarray):
+        x = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32))
+    return x.to(device=device, dtype=torch.float32).contiguous()
+
+
+class RayIntersector:
+    """Multi-hit ray/mesh intersector.  Duck-types trimesh's ``RayMeshIntersector`` and the reference's OptiX
+    adapter (``intersects_id``, ``update_intersector``; mesh_utils.py:75-109)."""
+
+    def __init__(self, mesh: TriMesh, max_hits: int = 10, device="cuda:0"):
+        if max_hits < 1 or max_hits > _C.QF_BVH_MAX_HITS:
+            raise ValueError(f"max_hits must be in 1..{_C.QF_BVH_MAX_HITS}")
+        self.mesh = mesh
+        self.max_hits = int(max_hits)
+        self.device = torch.device(device)
+        self._handle = ctypes.c_void_p()
+        tri = np.ascontiguousarray(mesh.vertices.astype(np.float32)[mesh.faces].reshape(-1, 9))
+        with torch.cuda.device(self.device):
+            _C.check(_C.lib().qf_bvh_create(tri.ctypes.data_as(ctypes.c_void_p), tri.shape[0],
+                                            ctypes.byref(self._handle)), "qf_bvh_create")
+
+    def __del__(self):
+        h = getattr(self, "_handle", None)
+        if h is not None and h.value:
+            try:
+                _C.lib().qf_bvh_destroy(h)
+            except Exception:
+                pass
+            self._handle = ctypes.c_void_p()
+
+    @property
+    def num_nodes(self) -> int:
+        return int(_C.lib().qf_bvh_num_nodes(self._handle))
+
+    def update_intersector(self, vertices) -> None:
+        """New vertex positions, same faces (Intersector.update_vertices; train_finetune.py:716-718).
+        ``vertices``: [V,3] vertex array, or the flattened [F*9] triangle soup the OptiX module took."""
+        v = np.asarray(vertices, dtype=np.float32)
+        if v.size == self.mesh.faces.shape[0] * 9 and v.shape != tuple(self.mesh.vertices.shape):
+            tri = np.ascontiguousarray(v.reshape(-1, 9))
+        else:
+            tri = np.ascontiguousarray(v.reshape(-1, 3)[self.mesh.faces].reshape(-1, 9))
+        _C.check(_C.lib().qf_bvh_refit(self._handle, tri.ctypes.data_as(ctypes.c_void_p), tri.shape[0]), "qf_bvh_refit")
+
+    def hits(self, origins, vectors, max_hits: Optional[int] = None, image_width: int = 0):
+        """Device result: (hit_tri [R,K] int32 (-1 pad), hit_t [R,K] fp32 (+inf pad), hit_count [R] int32),
+        each ray's hits ascending in (t, triangle id)."""
+        k = self.max_hits if max_hits is None else int(max_hits)
+        o = _as_device_f32(origins, self.device).reshape(-1, 3)
+        d = _as_device_f32(vectors, self.device).reshape(-1, 3)
+        if o.shape != d.shape:
+            raise ValueError("origins and vectors must have the same shape")
+        n = o.shape[0]
+        hit_tri = torch.empty((n, k), dtype=torch.int32, device=self.device)
+        hit_t = torch.empty((n, k), dtype=torch.float32, device=self.device)
+        hit_count = torch.empty((n,), dtype=torch.int32, device=self.device)
+        _C.check(_C.lib().qf_bvh_intersect(self._handle, _C.ptr(o), _C.ptr(d), n, k, int(image_width),
+                                           _C.ptr(hit_tri), _C.ptr(hit_t), _C.ptr(hit_count), _C.stream()),
+                 "qf_bvh_intersect")
+        return hit_tri, hit_t, hit_count, o, d
+
+    def find_intersections(self, rays) -> np.ndarray:
+        """OptiX-module shape: rays float[R*6] (origin, direction) -> int[R*max_hits] triangle ids, -1 padded."""
+        r = np.asarray(rays, dtype=np.float32).reshape(-1, 6)
+        hit_tri, _, _, _, _ = self.hits(r[:, :3], r[:, 3:])
+        return hit_tri.reshape(-1).cpu().numpy()
+
+    def sample_device(self, origins, vectors, max_hits: Optional[int] = None, image_width: int = 0):
+        """Packed, sorted samples on the device: [xyzs, dirs, index_ray, ts, index_tri, origins] -- the six
+        tensors the reference's DataLoader hands to the renderers (nerf_synthetic.py:256-257) -- or None
+        when no ray hits anything."""
+        k = self.max_hits if max_hits is None else int(max_hits)
+        hit_tri, hit_t, hit_count, o, d = self.hits(origins, vectors, k, image_width)
+        n = o.shape[0]
+        csum = torch.cumsum(hit_count.to(torch.int64), dim=0)
+        total = int(csum[-1].item()) if n else 0          # output size is data dependent: one sync
+        if total == 0:
+            return None
+        offset = (csum - hit_count).contiguous()
+        dev = self.device
+        xyz = torch.empty((total, 3), dtype=torch.float32, device=dev)
+        dirs = torch.empty((total, 3), dtype=torch.float32, device=dev)
+        org = torch.empty((total, 3), dtype=torch.float32, device=dev)
+        index_ray = torch.empty((total,), dtype=torch.int64, device=dev)
+        index_tri = torch.empty((total,), dtype=torch.int64, device=dev)
+        depth = torch.empty((total,), dtype=torch.float32, device=dev)
+        _C.check(_C.lib().qf_pack_samples(_C.ptr(o), _C.ptr(d), n, k, _C.ptr(hit_tri), _C.ptr(hit_t),
+                                          _C.ptr(hit_count), _C.ptr(offset), _C.ptr(xyz), _C.ptr(dirs),
+                                          _C.ptr(index_ray), _C.ptr(depth), _C.ptr(index_tri), _C.ptr(org),
+                                          _C.stream()), "qf_pack_samples")
+        return [xyz, dirs, index_ray, depth, index_tri, org]
+
+    @torch.no_grad()
+    def intersects_id(self, origins, vectors, multiple_hits=True, return_locations=True, max_hits=10):
+        """numpy (index_tri[S], index_ray[S], locations[S,3]) like trimesh / mesh_utils.py:86-109.  Rows come
+        grouped by ray, front to back (a valid ordering: the reference's callers sort anyway)."""
+        k = int(max_hits) if multiple_hits else 1
+        out = self.sample_device(origins, vectors, k)
+        if out is None:
+            return np.zeros(0, np.int64), np.zeros(0, np.int64), np.zeros((0, 3), np.float64)
+        xyz, _, index_ray, _, index_tri, _ = out
+        return index_tri.cpu().numpy(), index_ray.cpu().numpy(), xyz.cpu().numpy().astype(np.float64)
+
+
+class MeshFinetune:
+    """Per-triangle accumulation of weighted displacements and the vertex update (mesh_utils.py:112-156).
+    scatter_add / scatter_mean run as torch index_add_ on the device (not on the render hot path)."""
+
+    def __init__(self, vertices, faces, scaling, device="cuda:0") -> None:
+        self.vertices = np.array(vertices).astype(np.float32)
+        self.device = torch.device(device)
+        self.faces = torch.from_numpy(np.asarray(faces)).to(self.device).long()
+        self.cache_d = torch.zeros((self.faces.shape[0], 3), device=self.device)
+        self.cache_w = torch.ones(self.faces.shape[0], device=self.device) * 1e-8
+        self.scaling = scaling
+
+    @torch.no_grad()
+    def update_d(self, d, w, index_tri):
+        self.cache_d.index_add_(0, index_tri, d * w[..., None])
+        self.cache_w.index_add_(0, index_tri, w)
+
+    @torch.no_grad()
+    def update_faces(self):
+        deformation = torch.clip(self.cache_d / self.cache_w.unsqueeze(1), -self.scaling, self.scaling)
+        df_vertices = torch.repeat_interleave(deformation, dim=0, repeats=3)
+        flat = self.faces.flatten()
+        n_v = self.vertices.shape[0]
+        dv = torch.zeros((n_v, 3), device=self.device).index_add_(0, flat, df_vertices)
+        cnt = torch.zeros(n_v, device=self.device).index_add_(0, flat, torch.ones_like(flat, dtype=torch.float32))
+        self.vertices += (dv / cnt.clamp_min(1.0)[:, None]).cpu().numpy()
+
+    @torch.no_grad()
+    def reset_d(self):
+        self.cache_d[:] = 0
+        self.cache_w[:] = 1e-8
+
+
+class MeshIntersection:
+    """Quadrature-point generator of the mesh path (mesh_utils.py:180-412).  ``mesh_path`` may also be a
+    ``TriMesh``.  ``optix`` is accepted and ignored: there is one intersector, the gfx950 BVH."""
+
+    def __init__(self, mesh_path, simplify_mesh=True, scale=1.0, num_repeat=16, optix=False, voxel_size=512,
+                 num_intersections=20, render_step_size=0.005, device="cuda:0"):
+        if isinstance(mesh_path, TriMesh):
+            self.mesh = TriMesh(mesh_path.vertices.copy(), mesh_path.faces.copy(), mesh_path.visual.uv)
+        else:
+            self.mesh = load_mesh(mesh_path)
+        if simplify_mesh:
+            raise NotImplementedError("vertex-clustering simplification is offline mesh tooling (out of scope); "
+                                      "the reference's scripts pass simplify_mesh=False")
+        self.num_repeat = num_repeat
+        self.num_intersections = num_intersections
+        self.render_step_size = render_step_size
+        self.device = torch.device(device)
+        self.mesh.vertices *= scale
+        self.vertices = torch.from_numpy(self.mesh.vertices.astype(np.float32)).to(self.device)
+        self.rayintersector = RayIntersector(self.mesh, max_hits=self.num_intersections, device=device)
+
+    def find_deltas(self, boundary, depth):
+        """Constant step for every sample (mesh_utils.py:225-231; B-4)."""
+        return torch.full((depth.shape[0],), self.render_step_size, dtype=torch.float32, device=self.device)
+
+    def sampling_raytrace_device(self, vectors, origins, image_width: int = 0):
+        """Fast path of ``sampling_raytrace_numpy``: same six arrays, on the device, no host round trip."""
+        return self.rayintersector.sample_device(origins, vectors, self.num_intersections, image_width)
+
+    def sampling_raytrace_numpy(self, vectors, origins, random=0):
+        """numpy 7-tuple (points, dirs, index_ray, depth, index_tri, 0, origins) sorted by (ray, depth), or None
+        when nothing is hit -- mesh_utils.py:343-387.  (The reference returns float64 arrays that the loader
+        casts to float32, nerf_synthetic.py:256-257; these are the float32 values directly.)"""
+        out = self.sampling_raytrace_device(vectors, origins)
+        if out is None:
+            return None
+        xyz, dirs, index_ray, depth, index_tri, org = [t.cpu().numpy() for t in out]
+        return xyz, dirs, index_ray, depth, index_tri, 0, org
+
+    def sampling_indexing(self, points, origins, vectors, index_ray, depth, index_tri, random=0):
+        """Re-sort by (ray, depth) after deformation, boundaries, deltas -- mesh_utils.py:389-412, without
+        leaving the device."""
+        index_ray = _C.i64c(index_ray)
+        depth = _C.f32c(depth)
+        n = depth.shape[0]
+        perm = torch.empty((n,), dtype=torch.int64, device=depth.device)
+        _C.check(_C.lib().qf_resort_by_depth(_C.ptr(index_ray), _C.ptr(depth), n, _C.ptr(perm), _C.stream()),
+                 "qf_resort_by_depth")
+        index_tri, index_ray = index_tri[perm], index_ray[perm]
+        points, depth, origins, vectors = points[perm], depth[perm], origins[perm], vectors[perm]
+        boundary = spc_render.mark_pack_boundaries(index_ray)
+        deltas = self.find_deltas(boundary, depth)
+        return points, deltas, boundary, vectors, index_ray, depth, index_tri, origins

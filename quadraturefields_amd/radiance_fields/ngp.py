@@ -1,0 +1,285 @@
+"""Instant-NGP radiance fields on the fused gfx950 field kernel.
+
+Same classes, constructor arguments, methods and state-dict keys as
+``examples/radiance_fields/ngp.py`` of the reference (``NGPRadianceField`` :657-809,
+``NGPRadianceFieldSGNew`` :284-470, ``BasicDecoder`` :35-143, the uint8 quantisers :210-281), so the
+reference's checkpoints load and its renderers (``examples/utils.py``) can call them unchanged.  Each
+``forward`` / ``query_density`` / ``features`` is ONE launch of ``qf_field_forward``: hash-grid gather,
+both MLPs on the fp32 matrix cores and the SH / spherical-Gaussian head never leave registers.
+Inference only: the kernels have no backward.
+"""
+import ctypes
+from typing import Callable, List, Union
+
+import numpy as np
+import torch
+from torch import nn
+
+from .. import _C
+from .. import tinycudann as tcnn
+
+
+def trunc_exp(x):
+    """Forward of the reference's _TruncExp (ngp.py:146-153): a plain exp."""
+    return torch.exp(x)
+
+
+class BasicDecoder(nn.Module):
+    """nn.Linear + activation stack with the reference's attribute and state-dict names (ngp.py:35-121)."""
+
+    def __init__(self, input_dim, output_dim, activation, bias, layer=nn.Linear, num_layers=1,
+                 hidden_dim=128, skip=[]):
+        super().__init__()
+        self.input_dim, self.output_dim = input_dim, output_dim
+        self.activation, self.bias, self.layer = activation, bias, layer
+        self.num_layers, self.hidden_dim = num_layers, hidden_dim
+        self.skip = [] if skip is None else skip
+        layers = []
+        for i in range(num_layers):
+            if i == 0:
+                layers.append(layer(input_dim, hidden_dim, bias=bias))
+            elif i in self.skip:
+                layers.append(layer(hidden_dim + input_dim, hidden_dim, bias=bias))
+            else:
+                layers.append(layer(hidden_dim, hidden_dim, bias=bias))
+        self.layers = nn.ModuleList(layers)
+        self.lout = layer(hidden_dim, output_dim, bias=bias)
+
+    def forward(self, x, return_h=False):
+        """Stand-alone evaluation (library GEMMs); the fields below run it inside the fused kernel."""
+        h = x
+        for i, l in enumerate(self.layers):
+            if i != 0 and i in self.skip:
+                h = torch.cat([x, h], dim=-1)
+            h = self.activation(l(h))
+        out = self.lout(h)
+        return (out, h) if return_h else out
+
+    def name(self) -> str:
+        return "BasicDecoder"
+
+
+# ------------------------------------------------------------------ quantisers (ngp.py:210-281)
+def discretize_axis(axis):
+    return ((axis + 1.0) * 255 / 2).to(torch.uint8)
+
+
+def continuous_axis(axis):
+    return axis.to(torch.float32) / 255.0 * 2 - 1
+
+
+def discretize_color(color):
+    return (torch.sigmoid(color) * 255).to(torch.uint8)
+
+
+def continuous_color(color):
+    color = color.to(torch.float32) / 255.0
+    return torch.log(torch.clip(color / (1 - color), 1e-8, 1e37))
+
+
+def compress_polar_coordinates_torch(vectors):
+    vectors = vectors / (torch.norm(vectors, dim=-1, keepdim=True) + 1e-6)
+    azimuth = (torch.atan2(vectors[..., 1], vectors[..., 0]) * 128 / np.pi + 128).to(torch.uint8)
+    elevation = (torch.acos(vectors[..., 2]) * 256 / np.pi).to(torch.uint8)
+    return azimuth, elevation
+
+
+def inverse_of_azimuth_and_elevantion_torch(azimuth, elevation):
+    azimuth = (azimuth - 128) / 128 * np.pi      # uint8 inputs wrap mod 256, as in the reference (B-8)
+    elevation = elevation / 256 * np.pi
+    return torch.stack([torch.cos(azimuth) * torch.sin(elevation),
+                        torch.sin(azimuth) * torch.sin(elevation),
+                        torch.cos(elevation)], dim=-1)
+
+
+def compress_lambda_torch(lambdas, compress_threshold=7.5):
+    log_lambda = torch.log(torch.clamp(lambdas, 1e-5, np.inf))
+    return (255 * torch.clamp((log_lambda + 2.5) / compress_threshold, 0.0, 1.0)).to(torch.uint8)
+
+
+def torch_invserse_of_compressed_lambda(compressed_lambda, compress_threshold=7.5):
+    return torch.exp(compressed_lambda * compress_threshold / 255 - 2.5)
+
+
+def compress_colors(colors, thres=12, compress_type="sigma"):
+    if compress_type == "sigma":       # the scripts pass "sigmoid"/"linear": both take the linear branch (B-7)
+        colors = torch.sigmoid(colors)
+    else:
+        colors = (torch.clip(colors, -thres, thres) + thres) / 2 / thres
+    return (colors * 255).to(torch.uint8)
+
+
+def inverse_of_compressed_colors(colors, thres=12, compress_type="sigma"):
+    colors = colors.to(torch.float32) / 255.0
+    if compress_type == "sigma":
+        return torch.log(torch.clip(colors / (1 - colors), 1e-8, 1e37))
+    return colors * 2 * thres - thres
+
+
+# ------------------------------------------------------------------------------ fields
+class _FusedFieldBase(nn.Module):
+    """Shared plumbing: aabb buffer, mlp_base, descriptor cache, launch helper."""
+
+    def _init_common(self, aabb, num_dim, use_viewdirs, density_activation, unbounded, base_resolution,
+                     max_resolution, geo_feat_dim, n_levels, log2_hashmap_size):
+        if not isinstance(aabb, torch.Tensor):
+            aabb = torch.tensor(aabb, dtype=torch.float32)
+        self.register_buffer("aabb", aabb.to(torch.float32))
+        if unbounded:
+            raise NotImplementedError("unbounded scenes (contract_to_unisphere) are outside the hot path")
+        if num_dim != 3 or geo_feat_dim != 15:
+            raise NotImplementedError("the fused kernel implements num_dim=3, geo_feat_dim=15")
+        self.num_dim, self.use_viewdirs = num_dim, use_viewdirs
+        self.density_activation, self.unbounded = density_activation, unbounded
+        self.base_resolution, self.max_resolution = base_resolution, max_resolution
+        self.geo_feat_dim, self.n_levels, self.log2_hashmap_size = geo_feat_dim, n_levels, log2_hashmap_size
+        self.per_level_scale = np.exp((np.log(max_resolution) - np.log(base_resolution)) / (n_levels - 1)).tolist()
+        self.mlp_base = tcnn.NetworkWithInputEncoding(
+            n_input_dims=num_dim,
+            n_output_dims=1 + geo_feat_dim,
+            encoding_config={"otype": "HashGrid", "n_levels": n_levels, "n_features_per_level": 2,
+                             "log2_hashmap_size": log2_hashmap_size, "base_resolution": base_resolution,
+                             "per_level_scale": self.per_level_scale},
+            network_config={"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": "None",
+                            "n_neurons": 64, "n_hidden_layers": 1},
+        )
+        self._desc_cache = None
+
+    def _field_desc(self, head: int, n_lobes: int = 0) -> _C.FieldDesc:
+        key = (self.aabb.data_ptr(), self.aabb._version)
+        if self._desc_cache is None or self._desc_cache[0] != key:
+            aabb_host = self.aabb.detach().to("cpu", torch.float32).tolist()   # one sync per aabb change
+            self._desc_cache = (key, aabb_host)
+        d = _C.FieldDesc()
+        ctypes.memmove(ctypes.byref(d.grid), ctypes.byref(self.mlp_base.grid.desc), ctypes.sizeof(_C.GridDesc))
+        for k in range(6):
+            d.aabb[k] = self._desc_cache[1][k]
+        d.head, d.n_lobes = head, n_lobes
+        return d
+
+    def normalize(self, x):
+        """(selector, x01) -- ngp.py:748-755; elementwise, kept in torch."""
+        aabb_min, aabb_max = torch.split(self.aabb, self.num_dim, dim=-1)
+        x = (x - aabb_min) / (aabb_max - aabb_min)
+        selector = ((x > 0.0) & (x < 1.0)).all(dim=-1)
+        return selector, x
+
+    def _launch(self, head, n_lobes, xyz, dirs, want_rgb=False, want_sigma=False, want_geo=False, want_features=0,
+                head_ngp=None, head_sg=None):
+        xyz = _C.f32c(xyz.reshape(-1, 3))
+        n = xyz.shape[0]
+        dev = xyz.device
+        if dirs is not None:
+            dirs = _C.f32c(dirs.reshape(-1, 3))
+            if dirs.shape[0] != n:
+                raise ValueError(f"{tuple(xyz.shape)} v.s. {tuple(dirs.shape)}")
+        rgb = torch.empty((n, 3), dtype=torch.float32, device=dev) if want_rgb else None
+        sigma = torch.empty((n,), dtype=torch.float32, device=dev) if want_sigma else None
+        geo = torch.empty((n, 15), dtype=torch.float32, device=dev) if want_geo else None
+        feats = torch.empty((n, want_features), dtype=torch.float32, device=dev) if want_features else None
+        desc = self._field_desc(head, n_lobes)
+        sg = None
+        if head_sg is not None:
+            sg = _C.SGHead(*[_C.ptr(t) for t in head_sg])
+        _C.check(_C.lib().qf_field_forward(
+            ctypes.byref(desc), _C.ptr(self.mlp_base.grid_params()), _C.ptr(self.mlp_base.network_params()),
+            _C.ptr(head_ngp), ctypes.byref(sg) if sg is not None else None, _C.ptr(xyz), _C.ptr(dirs), n,
+            _C.ptr(rgb), _C.ptr(sigma), _C.ptr(geo), _C.ptr(feats), _C.stream()), "qf_field_forward")
+        return rgb, sigma, geo, feats
+
+    def query_density(self, x, return_feat: bool = False):
+        """density = exp(raw - 1) * selector, [..,1] (+ the 15 geometry features).  ngp.py:757-779."""
+        lead = list(x.shape[:-1])
+        _, sigma, geo, _ = self._launch(_C.HEAD_NONE, 0, x, None, want_sigma=True, want_geo=return_feat)
+        density = sigma.reshape(lead + [1])
+        if return_feat:
+            return density, geo.reshape(lead + [self.geo_feat_dim])
+        return density
+
+
+class NGPRadianceField(_FusedFieldBase):
+    """Instant-NGP radiance field with the SH-degree-4 view-dependent head (ngp.py:657-809)."""
+
+    def __init__(self, aabb: Union[torch.Tensor, List[float]], num_dim: int = 3, use_viewdirs: bool = True,
+                 density_activation: Callable = lambda x: trunc_exp(x - 1), unbounded: bool = False,
+                 base_resolution: int = 16, max_resolution: int = 4096, geo_feat_dim: int = 15,
+                 n_levels: int = 16, log2_hashmap_size: int = 19, num_layers=2, hidden_size=64) -> None:
+        super().__init__()
+        self._init_common(aabb, num_dim, use_viewdirs, density_activation, unbounded, base_resolution,
+                          max_resolution, geo_feat_dim, n_levels, log2_hashmap_size)
+        if not use_viewdirs or hidden_size != 64:
+            raise NotImplementedError("the fused kernel implements use_viewdirs=True, hidden_size=64")
+        self.direction_encoding = tcnn.Encoding(
+            n_input_dims=num_dim,
+            encoding_config={"otype": "Composite",
+                             "nested": [{"n_dims_to_encode": 3, "otype": "SphericalHarmonics", "degree": 4}]})
+        self.mlp_head = tcnn.Network(
+            n_input_dims=self.direction_encoding.n_output_dims + geo_feat_dim, n_output_dims=3,
+            network_config={"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": "None",
+                            "n_neurons": hidden_size, "n_hidden_layers": 2})
+
+    def forward(self, positions: torch.Tensor, directions: torch.Tensor = None):
+        """(rgb [..,3], density [..,1]).  ngp.py:798-809."""
+        if directions is None:
+            raise ValueError("NGPRadianceField.forward needs view directions")
+        assert positions.shape == directions.shape, f"{positions.shape} v.s. {directions.shape}"
+        lead = list(positions.shape[:-1])
+        rgb, sigma, _, _ = self._launch(_C.HEAD_NGP, 0, positions, directions, want_rgb=True, want_sigma=True,
+                                        head_ngp=self.mlp_head.params.detach())
+        return rgb.reshape(lead + [3]), sigma.reshape(lead + [1])
+
+
+class NGPRadianceFieldSGNew(_FusedFieldBase):
+    """Instant-NGP field with the spherical-Gaussian head (ngp.py:284-470)."""
+
+    def __init__(self, aabb: Union[torch.Tensor, List[float]], num_dim: int = 3, use_viewdirs: bool = True,
+                 density_activation: Callable = lambda x: trunc_exp(x - 1), unbounded: bool = False,
+                 base_resolution: int = 16, max_resolution: int = 4096, geo_feat_dim: int = 15,
+                 n_levels: int = 16, log2_hashmap_size: int = 19, num_g_lobes=3, hidden_size=64, num_layers=2,
+                 output_activation="sigmoid", discretize=False) -> None:
+        super().__init__()
+        self._init_common(aabb, num_dim, use_viewdirs, density_activation, unbounded, base_resolution,
+                          max_resolution, geo_feat_dim, n_levels, log2_hashmap_size)
+        if use_viewdirs:
+            raise NotImplementedError("the reference scripts build the SG field with use_viewdirs=False "
+                                      "(train_finetune.py:374-380); only that form is implemented")
+        if discretize:
+            raise NotImplementedError("discretize=True (quantise-dequantise inside the field) is not on the hot path")
+        if hidden_size != 64 or num_layers != 2 or not (1 <= num_g_lobes <= _C.QF_MAX_LOBES):
+            raise NotImplementedError("the fused kernel implements hidden_size=64, num_layers=2, 1..8 lobes")
+        self.num_g_lobes = num_g_lobes
+        self.output_activation = output_activation
+        self.discretize = discretize
+        self.mlp_head = BasicDecoder(input_dim=geo_feat_dim, output_dim=3 + num_g_lobes * 7, num_layers=num_layers,
+                                     bias=True, activation=torch.nn.ReLU(), hidden_dim=hidden_size)
+
+    def _sg_params(self):
+        h = self.mlp_head
+        return [_C.f32c(t.detach()) for t in (h.layers[0].weight, h.layers[0].bias, h.layers[1].weight,
+                                              h.layers[1].bias, h.lout.weight, h.lout.bias)]
+
+    def features(self, x):
+        """[head(3+7L) | density], ngp.py:445-454."""
+        width = 3 + 7 * self.num_g_lobes + 1
+        _, _, _, feats = self._launch(_C.HEAD_SG_FEATURES, self.num_g_lobes, x, None, want_features=width,
+                                      head_sg=self._sg_params())
+        return feats
+
+    def features_to_rgb(self, features, dir):
+        """sigmoid(diffuse + SG mixture), ngp.py:456-461.  features [n, >= 3+7L] (extra columns ignored)."""
+        features = _C.f32c(features)
+        dir = _C.f32c(dir.reshape(-1, 3))
+        n = features.shape[0]
+        rgb = torch.empty((n, 3), dtype=torch.float32, device=features.device)
+        _C.check(_C.lib().qf_sg_features_to_rgb(_C.ptr(features), features.shape[1], _C.ptr(dir), n,
+                                                self.num_g_lobes, _C.ptr(rgb), _C.stream()), "qf_sg_features_to_rgb")
+        return rgb
+
+    def forward(self, positions: torch.Tensor, directions: torch.Tensor = None):
+        """(rgb, density), ngp.py:463-470."""
+        if directions is None:
+            raise ValueError("NGPRadianceFieldSGNew.forward needs view directions")
+        lead = list(positions.shape[:-1])
+        rgb, sigma, _, _ = self._launch(_C.HEAD_SG, self.num_g_lobes, positions, directions, want_rgb=True,
+                                        want_sigma=True, head_sg=self._sg_params())
+        return rgb.reshape(lead + [3]), sigma.reshape(lead + [1])

@@ -1,0 +1,76 @@
+"""Whole-frame driver of the mesh-quadrature path: rays -> BVH quadrature points -> field -> composite.
+
+This is the loop body of ``test()`` in ``examples/train_finetune.py:574-629`` (and of
+``examples/test_baking_texture_images.py:341-399`` for baked textures) with the DataLoader-side
+intersection folded in: every stage is a device launch on the current stream, nothing returns to the host
+between the rays and the finished image except one 8-byte sample count.
+"""
+from typing import Optional
+
+import torch
+
+from . import utils
+from .datasets.utils import Rays
+
+
+class FrameRenderer:
+    def __init__(self, mesh_intersect, radiance_field, field_net=None, render_step_size: float = 5e-3,
+                 bg_color: str = "white"):
+        self.mesh_intersect = mesh_intersect
+        self.radiance_field = radiance_field
+        self.field_net = field_net
+        self.render_step_size = render_step_size
+        self.bg_color = bg_color
+
+    @torch.no_grad()
+    def quadrature_points(self, origins: torch.Tensor, viewdirs: torch.Tensor, image_width: int = 0):
+        """[xyzs, dirs, index_ray, ts, index_tri, origins] on the device (None if no hit)."""
+        return self.mesh_intersect.sampling_raytrace_device(viewdirs, origins, image_width=image_width)
+
+    @torch.no_grad()
+    def render(self, origins: torch.Tensor, viewdirs: torch.Tensor, image_width: int = 0, scaling: float = 0.0,
+               render_bkgd: Optional[torch.Tensor] = None):
+        """(rgb [R,3], alpha [R,1], depth [R,1], n_samples) for R rays."""
+        n_rays = origins.shape[0]
+        data = self.quadrature_points(origins, viewdirs, image_width)
+        if data is None:
+            dev = origins.device
+            fill = 0.0 if self.bg_color == "black" else 1.0
+            return (torch.full((n_rays, 3), fill, device=dev), torch.zeros((n_rays, 1), device=dev),
+                    torch.zeros((n_rays, 1), device=dev), 0)
+        rays = Rays(origins=origins, viewdirs=viewdirs)
+        rgb, alpha, depth, n_samples, *_ = utils.render_image_finetune_with_occgrid(
+            self.radiance_field, self.field_net, None, rays, data, render_step_size=self.render_step_size,
+            render_bkgd=render_bkgd, mesh_intersect=self.mesh_intersect, mesh_finetune=None, scaling=scaling,
+            bg_color=self.bg_color)
+        return rgb, alpha, depth, n_samples
+
+    @torch.no_grad()
+    def render_baked(self, origins, viewdirs, uv, compressor, image_width: int = 0):
+        """Baked-texture variant (test_baking_texture_images.py:355-371)."""
+        n_rays = origins.shape[0]
+        data = self.quadrature_points(origins, viewdirs, image_width)
+        if data is None:
+            dev = origins.device
+            return (torch.ones((n_rays, 3), device=dev), torch.zeros((n_rays, 1), device=dev),
+                    torch.zeros((n_rays, 1), device=dev), 0)
+        rays = Rays(origins=origins, viewdirs=viewdirs)
+        rgb, alpha, depth, n_samples, *_ = utils.render_image_bake_texture_images_with_occgrid(
+            self.radiance_field, rays, data, uv=uv, render_step_size=self.render_step_size,
+            mesh_intersect=self.mesh_intersect, compressor=compressor, bg_color=self.bg_color)
+        return rgb, alpha, depth, n_samples
+
+
+def area_downsample(img: torch.Tensor, factor: int) -> torch.Tensor:
+    """cv2.resize(..., INTER_AREA) by an integer factor (train_finetune.py:624-627) == box average."""
+    if factor == 1:
+        return img
+    h, w = img.shape[:2]
+    rest = img.shape[2:]
+    return img.reshape(h // factor, factor, w // factor, factor, *rest).mean(dim=(1, 3))
+
+
+def psnr(a: torch.Tensor, b: torch.Tensor) -> float:
+    """-10 log10(mse) (train_finetune.py:631-632)."""
+    mse = torch.mean((a.double() - b.double()) ** 2)
+    return float("inf") if mse == 0 else float(-10.0 * torch.log10(mse))

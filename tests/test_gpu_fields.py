@@ -1,0 +1,153 @@
+"""GPU parity: fused field kernels (through the C ABI) vs the CPU oracle on the same seeded inputs.
+
+Tolerance: every operand and accumulator is fp32 on both sides; the kernels differ from the oracle only in
+summation order (MFMA k-order vs MKL sgemm, fma vs mul+add) and libm (expf), so outputs agree to a few 1e-6
+relative.  Stated bound: |a-b| <= 2e-5 + 2e-5*|b| on rgb (values in [0,1]) and geo features, 5e-5 relative on
+densities (exp amplifies the raw-output error by |raw|).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import fields as ofields
+from tests import helpers
+
+pytestmark = pytest.mark.gpu
+
+
+def _make(cls, device, log2_T=12, seed=42, **kw):
+    from quadraturefields_amd import synthetic
+    torch.manual_seed(0)
+    f = cls(aabb=[-1.5, -1.5, -1.5, 1.5, 1.5, 1.5], log2_hashmap_size=log2_T, **kw)
+    lobes = kw.get("num_g_lobes", 0)
+    st = synthetic.seeded_ngp_state(log2_T, f.mlp_base.grid.n_rows, seed=seed, sg_lobes=lobes)
+    missing = f.load_state_dict(st, strict=False)
+    assert not missing.unexpected_keys
+    return f.to(device)
+
+
+def _close(a, b, atol, rtol):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    err = (a - b).abs()
+    bound = atol + rtol * b.abs()
+    assert bool((err <= bound).all()), f"max err {err.max().item():.3e}, worst ratio {(err / bound).max().item():.2f}"
+
+
+@pytest.mark.parametrize("log2_T", [8, 14, 19])
+def test_grid_encode_matches_oracle(device, log2_T):
+    from quadraturefields_amd import tinycudann as tcnn
+    torch.manual_seed(1)
+    enc = tcnn.Encoding(3, {"otype": "HashGrid", "n_levels": 16, "n_features_per_level": 2,
+                            "log2_hashmap_size": log2_T, "base_resolution": 16,
+                            "per_level_scale": ofields.ngp_per_level_scale(4096, 16, 16)})
+    with torch.no_grad():
+        enc.params.copy_((torch.rand_like(enc.params) * 2 - 1))
+    enc = enc.to(device)
+    x = torch.rand(4099, 3)
+    x[:7] = torch.tensor([[0.0, 0.0, 0.0], [1.0, 1.0, 1.0], [0.999999, 0.5, 0.25], [1e-7, 0.5, 1.0],
+                          [-0.25, 0.5, 0.5], [1.3, -0.1, 0.5], [0.5, 0.5, 0.5]])
+    lv = ofields.grid_levels(16, log2_T, 16, ofields.ngp_per_level_scale(4096, 16, 16))
+    want = ofields.hash_encode(x, enc.params.detach().cpu().reshape(-1, 2), lv)
+    got = enc(x.to(device))
+    _close(got, want, 2e-6, 2e-6)
+
+
+@pytest.mark.parametrize("n", [1, 15, 16, 17, 4096 + 5])
+def test_ngp_forward_matches_oracle(device, n):
+    from quadraturefields_amd.radiance_fields.ngp import NGPRadianceField
+    f = _make(NGPRadianceField, device)
+    x, d = helpers.random_points(n, seed=n)
+    w = helpers.oracle_ngp_weights(f)
+    rgb_o, den_o = ofields.ngp_forward(x, d, w)
+    rgb, den = f(x.to(device), d.to(device))
+    assert rgb.shape == (n, 3) and den.shape == (n, 1)
+    _close(rgb, rgb_o, 2e-5, 2e-5)
+    _close(den, den_o, 1e-7, 5e-5)
+    # selector: strictly inside the aabb, zero density outside (ngp.py:763)
+    sel, _ = ofields.normalize_to_aabb(x, w.aabb)
+    assert bool((den.cpu()[~sel] == 0).all())
+
+
+def test_ngp_query_density_and_feat(device):
+    from quadraturefields_amd.radiance_fields.ngp import NGPRadianceField
+    f = _make(NGPRadianceField, device, log2_T=19)
+    x, _ = helpers.random_points(2048, seed=3)
+    w = helpers.oracle_ngp_weights(f)
+    den_o, feat_o = ofields.query_density(x, w, return_feat=True)
+    den, feat = f.query_density(x.to(device), return_feat=True)
+    assert feat.shape == (2048, 15)
+    _close(den, den_o, 1e-7, 5e-5)
+    _close(feat, feat_o, 2e-5, 2e-5)
+    den2 = f.query_density(x.to(device).reshape(32, 64, 3))
+    assert den2.shape == (32, 64, 1)
+    assert torch.equal(den2.reshape(-1), den.reshape(-1))
+    # the tcnn duck type returns the raw 16 outputs
+    sel, x01 = f.normalize(x.to(device))
+    raw = f.mlp_base(x01)
+    _close(raw[:, 1:], feat_o, 2e-5, 2e-5)
+
+
+@pytest.mark.parametrize("lobes", [1, 3, 6, 8])
+def test_sg_forward_and_features_match_oracle(device, lobes):
+    from quadraturefields_amd.radiance_fields.ngp import NGPRadianceFieldSGNew
+    f = _make(NGPRadianceFieldSGNew, device, use_viewdirs=False, num_g_lobes=lobes)
+    x, d = helpers.random_points(1000 + lobes, seed=lobes)
+    w = helpers.oracle_ngp_weights(f)
+    rgb_o, den_o = ofields.sg_forward(x, d, w)
+    feats_o = ofields.sg_features(x, w)
+    rgb, den = f(x.to(device), d.to(device))
+    feats = f.features(x.to(device))
+    assert feats.shape == (x.shape[0], 3 + 7 * lobes + 1)
+    _close(den, den_o, 1e-7, 5e-5)
+    _close(feats[:, :-1], feats_o[:, :-1], 5e-5, 5e-5)
+    _close(feats[:, -1], feats_o[:, -1], 1e-7, 5e-5)
+    _close(rgb, rgb_o, 5e-5, 5e-5)
+    # features_to_rgb on the oracle's features reproduces the oracle rgb
+    rgb2 = f.features_to_rgb(feats_o[:, :-1].contiguous().to(device), d.to(device))
+    _close(rgb2, ofields.features_to_rgb(feats_o[:, :-1], d, lobes), 5e-6, 5e-6)
+
+
+def test_deform_field_matches_oracle(device):
+    from quadraturefields_amd import synthetic
+    from quadraturefields_amd.field import Field
+    torch.manual_seed(0)
+    f = Field(scale=1.5, precision=16, log2_T=16, L=16, max_res=512, min_res=16, output_dim=1, hidden_size=32,
+              num_features=2, back_prop=False, nl="relu")
+    f.load_state_dict(synthetic.seeded_deform_state(f.xyz_encoder.grid.n_params), strict=False)
+    f = f.to(device)
+    x, _ = helpers.random_points(3001, seed=9, outside_frac=0.0)
+    want = ofields.deform_field(x, helpers.oracle_deform_weights(f))
+    got, grad = f(x.to(device), return_grad=False)
+    assert grad is None and got.shape == (3001, 1)
+    _close(got, want, 2e-5, 2e-5)
+
+
+def test_linearity_of_grid_in_table(device):
+    """Size-independent property at the full T=2^19 table: the encoding is linear in the table."""
+    from quadraturefields_amd import tinycudann as tcnn
+    cfg = {"otype": "HashGrid", "n_levels": 16, "n_features_per_level": 2, "log2_hashmap_size": 19,
+           "base_resolution": 16, "per_level_scale": ofields.ngp_per_level_scale(4096, 16, 16)}
+    a, b = tcnn.Encoding(3, cfg).to(device), tcnn.Encoding(3, cfg).to(device)
+    with torch.no_grad():
+        a.params.uniform_(-1, 1)
+        b.params.uniform_(-1, 1)
+    x = torch.rand(200000, 3, device=device)
+    ea, eb = a(x), b(x)
+    with torch.no_grad():
+        a.params.add_(b.params)
+    assert torch.allclose(a(x), ea + eb, atol=1e-5, rtol=1e-5)
+    # constant table -> constant features (the trilinear weights sum to one)
+    with torch.no_grad():
+        a.params.fill_(0.75)
+    assert torch.allclose(a(x), torch.full((200000, 32), 0.75, device=device), atol=1e-6)
+
+
+def test_errors(device):
+    from quadraturefields_amd.radiance_fields.ngp import NGPRadianceField
+    f = _make(NGPRadianceField, device)
+    with pytest.raises(RuntimeError):
+        f(torch.zeros(4, 3), torch.zeros(4, 3))          # host tensors: no CPU fallback
+    with pytest.raises(AssertionError):
+        f(torch.zeros(4, 3, device=device), torch.zeros(5, 3, device=device))
+    rgb, den = f(torch.zeros(0, 3, device=device), torch.zeros(0, 3, device=device))
+    assert rgb.shape == (0, 3) and den.shape == (0, 1)

@@ -1,0 +1,193 @@
+"""GPU parity: BVH multi-hit traversal, sample packing and re-sorting vs the brute-force oracle.
+
+Bar: bit-exact triangle ids, hit counts, ray ids and sample order.  The hit distance t, the fp64 locations and
+the depths are computed with the same individually rounded IEEE operations on both sides (no FMA contraction in
+exact.hip / intersect_ref.c), so they are compared for exact equality too.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import meshpath as om
+from tests import helpers
+
+pytestmark = pytest.mark.gpu
+
+
+def _scene(subdiv=3, shells=4, seed=42):
+    from quadraturefields_amd import synthetic
+    return synthetic.shell_mesh(n_shells=shells, subdivisions=subdiv, seed=seed)
+
+
+def _rays(n, seed=0, radius=4.0):
+    rng = np.random.default_rng(seed)
+    o = rng.normal(size=(n, 3))
+    o = (o / np.linalg.norm(o, axis=1, keepdims=True) * radius).astype(np.float32)
+    target = rng.uniform(-1.0, 1.0, size=(n, 3)).astype(np.float32)
+    d = target - o
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    return o, d
+
+
+@pytest.mark.parametrize("max_hits", [1, 5, 25])
+def test_hits_bit_exact_vs_bruteforce(device, max_hits):
+    from quadraturefields_amd.mesh_utils import RayIntersector
+    mesh = _scene()
+    ri = RayIntersector(mesh, max_hits=max_hits)
+    o, d = _rays(3000, seed=max_hits)
+    # a few rays from inside the object, axis-aligned rays (zero direction components) and misses
+    o[:50] = 0.0
+    d[50:53] = np.array([[1, 0, 0], [0, -1, 0], [0, 0, 1]], dtype=np.float32)
+    o[53:60] = np.array([10, 10, 10], dtype=np.float32)
+    tri_o, t_o, cnt_o = om.BruteForceIntersector(mesh.vertices, mesh.faces).hits(o, d, max_hits)
+    tri, t, cnt, _, _ = ri.hits(o, d)
+    assert np.array_equal(cnt.cpu().numpy(), cnt_o)
+    assert np.array_equal(tri.cpu().numpy(), tri_o)
+    assert np.array_equal(t.cpu().numpy(), t_o)
+    assert cnt_o.max() == max_hits or max_hits == 25   # the K-nearest truncation is exercised for small K
+    # tile-ordered traversal of an image-shaped batch gives identical results
+    o2, d2 = o[:2048], d[:2048]
+    a = ri.hits(o2, d2, image_width=0)
+    b = ri.hits(o2, d2, image_width=64)
+    for x, y in zip(a[:3], b[:3]):
+        assert torch.equal(x, y)
+
+
+def test_find_intersections_shape(device):
+    from quadraturefields_amd.mesh_utils import RayIntersector
+    mesh = _scene(2, 2)
+    ri = RayIntersector(mesh, max_hits=6)
+    o, d = _rays(100, seed=3)
+    ints = ri.find_intersections(np.concatenate([o, d], 1).flatten())
+    assert ints.shape == (600,) and ints.dtype == np.int32
+    tri_o, _, _ = om.BruteForceIntersector(mesh.vertices, mesh.faces).hits(o, d, 6)
+    assert np.array_equal(ints.reshape(100, 6), tri_o)
+
+
+def test_sampling_raytrace_matches_oracle(device):
+    from quadraturefields_amd.mesh_utils import MeshIntersection
+    mesh = _scene()
+    mi = MeshIntersection(mesh, simplify_mesh=False, scale=1.0, num_intersections=25)
+    o, d = _rays(4000, seed=7)
+    want = om.sampling_raytrace_numpy(om.BruteForceIntersector(mesh.vertices, mesh.faces), d, o, 25)
+    want = om.to_loader_tensors(want)
+    got = mi.sampling_raytrace_device(d, o)
+    names = ["xyzs", "dirs", "index_ray", "ts", "index_tri", "origins"]
+    for name, g, w in zip(names, got, want):
+        assert g.shape == w.shape, name
+        assert torch.equal(g.cpu(), w), f"{name}: max diff {(g.cpu().double() - w.double()).abs().max()}"
+    # numpy duck type
+    got_np = mi.sampling_raytrace_numpy(d, o, 0)
+    assert got_np[5] == 0 and np.array_equal(got_np[2], want[2].numpy())
+    tri, ray, loc = mi.rayintersector.intersects_id(o, d, multiple_hits=True, return_locations=True, max_hits=25)
+    assert np.array_equal(tri, want[4].numpy()) and np.array_equal(ray, want[2].numpy())
+    # no hit at all -> None (mesh_utils.py:357-358)
+    far = np.tile(np.array([[50, 50, 50]], np.float32), (8, 1))
+    assert mi.sampling_raytrace_numpy(d[:8], far, 0) is None
+
+
+def test_scale_and_refit(device):
+    from quadraturefields_amd.mesh_utils import MeshIntersection
+    mesh = _scene(2, 3)
+    mi = MeshIntersection(mesh, simplify_mesh=False, scale=1.5, num_intersections=10)
+    assert np.allclose(mi.mesh.vertices, mesh.vertices * 1.5)
+    o, d = _rays(1000, seed=5, radius=6.0)
+    bf = om.BruteForceIntersector(mi.mesh.vertices, mi.mesh.faces)
+    tri, t, cnt, _, _ = mi.rayintersector.hits(o, d)
+    tri_o, t_o, cnt_o = bf.hits(o, d, 10)
+    assert np.array_equal(tri.cpu().numpy(), tri_o) and np.array_equal(cnt.cpu().numpy(), cnt_o)
+    # move the vertices, refit, compare with a brute force on the moved mesh
+    rng = np.random.default_rng(0)
+    moved = mi.mesh.vertices + rng.normal(scale=0.02, size=mi.mesh.vertices.shape)
+    mi.rayintersector.update_intersector(moved)
+    tri, t, cnt, _, _ = mi.rayintersector.hits(o, d)
+    tri_o, t_o, cnt_o = om.BruteForceIntersector(moved, mi.mesh.faces).hits(o, d, 10)
+    assert np.array_equal(cnt.cpu().numpy(), cnt_o)
+    assert np.array_equal(tri.cpu().numpy(), tri_o)
+    assert np.array_equal(t.cpu().numpy(), t_o)
+
+
+def test_sampling_indexing_resort(device):
+    from quadraturefields_amd.mesh_utils import MeshIntersection
+    mesh = _scene(2, 3)
+    mi = MeshIntersection(mesh, simplify_mesh=False, scale=1.0, num_intersections=25)
+    ridx, _ = helpers.packed_segments(300, 25, seed=2)
+    n = ridx.shape[0]
+    g = torch.Generator().manual_seed(5)
+    depth = torch.rand(n, generator=g)
+    depth[10:40] = 0.5                                   # ties: the sort must be stable
+    pts, org, vec = torch.rand(n, 3, generator=g), torch.rand(n, 3, generator=g), torch.rand(n, 3, generator=g)
+    tri = torch.randint(0, 1000, (n,), generator=g)
+    want = om.sampling_indexing(pts, org, vec, ridx, depth, tri)
+    dev = lambda t: t.to(device)
+    got = mi.sampling_indexing(dev(pts), dev(org), dev(vec), dev(ridx), dev(depth), dev(tri))
+    for k, (a, b) in enumerate(zip(got, want)):
+        assert torch.equal(a.cpu(), b), k
+    # already sorted input is a fixed point
+    again = mi.sampling_indexing(got[0], got[7], got[3], got[4], got[5], got[6])
+    assert torch.equal(again[0], got[0]) and torch.equal(again[6], got[6])
+
+
+def test_bvh_structure(device):
+    """Every triangle sits in exactly one leaf and every child box encloses its triangles."""
+    from quadraturefields_amd import _C
+    from quadraturefields_amd.mesh_utils import RayIntersector
+    mesh = _scene(3, 2)
+    ri = RayIntersector(mesh, max_hits=4)
+    n_nodes, n_tri = ri.num_nodes, mesh.faces.shape[0]
+    nodes = np.zeros((n_nodes, 16), np.float32)
+    ids = np.zeros(n_tri, np.int32)
+    _C.check(_C.lib().qf_bvh_copy_nodes(ri._handle, nodes.ctypes.data, n_nodes))
+    _C.check(_C.lib().qf_bvh_copy_tri_ids(ri._handle, ids.ctypes.data, n_tri))
+    assert sorted(ids.tolist()) == list(range(n_tri))
+    child = nodes[:, 12:14].copy().view(np.int32)
+    count = nodes[:, 14:16].copy().view(np.int32)
+    tris = mesh.vertices.astype(np.float32)[mesh.faces]
+    seen = np.zeros(n_tri, bool)
+    for n in range(n_nodes):
+        for s in range(2):
+            if child[n, s] < 0:
+                first = ~child[n, s]
+                for k in range(count[n, s]):
+                    tid = ids[first + k]
+                    assert not seen[tid]
+                    seen[tid] = True
+                    lo, hi = nodes[n, 6 * s:6 * s + 3], nodes[n, 6 * s + 3:6 * s + 6]
+                    assert (tris[tid] >= lo).all() and (tris[tid] <= hi).all()
+            else:
+                assert child[n, s] > n
+    assert seen.all()
+
+
+def test_full_size_mesh_sampled_against_bruteforce(device):
+    """BASELINE size: ~1M-triangle shell mesh; a random subset of camera rays is checked bit-exactly against the
+    brute force, all rays through size-independent properties (sortedness, counts, depth == |xyz - o|)."""
+    from quadraturefields_amd import synthetic
+    from quadraturefields_amd.mesh_utils import MeshIntersection
+    mesh = synthetic.shell_mesh(n_shells=12, subdivisions=6)
+    assert mesh.faces.shape[0] == 983040
+    mi = MeshIntersection(mesh, simplify_mesh=False, scale=1.0, num_intersections=25)
+    c2w = synthetic.orbit_cameras(1)[0]
+    o, d = synthetic.camera_rays(c2w, synthetic.lego_focal(800), 800, 800)
+    tri, t, cnt, _, _ = mi.rayintersector.hits(o, d, image_width=800)
+    cnt_h = cnt.cpu().numpy()
+    assert cnt_h.max() <= 25 and 4.0 < cnt_h.mean() < 12.0
+    t_h = t.cpu().numpy()
+    k = np.arange(25)[None, :]
+    valid = k < cnt_h[:, None]
+    assert np.isinf(t_h[~valid]).all() and (tri.cpu().numpy()[~valid] == -1).all()
+    tt = np.where(valid, t_h, np.inf)
+    assert (np.diff(tt, axis=1)[valid[:, 1:]] >= 0).all()          # ascending within each ray
+    rng = np.random.default_rng(1)
+    pick = np.concatenate([rng.choice(640000, 192, replace=False), np.flatnonzero(cnt_h == cnt_h.max())[:64]])
+    tri_o, t_o, cnt_o = om.BruteForceIntersector(mesh.vertices, mesh.faces).hits(o[pick].numpy(), d[pick].numpy(), 25)
+    assert np.array_equal(cnt_h[pick], cnt_o)
+    assert np.array_equal(tri.cpu().numpy()[pick], tri_o)
+    assert np.array_equal(t_h[pick], t_o)
+    data = mi.sampling_raytrace_device(d, o, image_width=800)
+    xyz, dirs, index_ray, ts, index_tri, org = data
+    assert xyz.shape[0] == int(cnt_h.sum())
+    assert bool((index_ray[1:] >= index_ray[:-1]).all())
+    same = index_ray[1:] == index_ray[:-1]
+    assert bool((ts[1:][same] >= ts[:-1][same]).all())
+    assert torch.allclose((xyz - org).norm(dim=-1), ts, rtol=1e-5, atol=1e-6)

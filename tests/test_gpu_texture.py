@@ -1,0 +1,94 @@
+"""GPU parity: baked SG texture path vs the CPU oracle.
+
+Bar: texel indices (int64) bit-exact; decoded features / rgb / sigma within 2e-6 + 2e-5*|x| (libm differences in
+log / exp / sin / cos only).  All 256 code points of every codec are exercised.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import fields as ofields
+from oracle import quantize as oq
+
+pytestmark = pytest.mark.gpu
+
+
+def _close(a, b, atol=2e-6, rtol=2e-5):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    err = (a - b).abs()
+    assert bool((err <= atol + rtol * b.abs()).all()), f"max err {err.max().item():.3e}"
+
+
+@pytest.mark.parametrize("codec,lobes,thres", [("sigmoid", 6, 7.5), ("linear", 3, 5.0), ("sigma", 2, 7.5)])
+def test_all_code_points(device, codec, lobes, thres):
+    from quadraturefields_amd.texture_utils import FeatureCompression
+    t = 256
+    # texel (r, c): every channel walks all 256 codes along the columns, rows permute the pairing
+    base = np.arange(t, dtype=np.uint8)[None, :].repeat(t, 0)
+    rows = np.arange(t, dtype=np.uint8)[:, None].repeat(t, 1)
+    alpha = base.copy()
+    diffuse = np.stack([base, rows, base ^ rows], -1).astype(np.uint8)
+    colors = [np.stack([base + np.uint8(i), rows, base], -1).astype(np.uint8) for i in range(lobes)]
+    lambdas = [np.stack([base, rows, (base + rows).astype(np.uint8)], -1).astype(np.uint8) for i in range(lobes)]
+    comp = FeatureCompression.from_arrays(alpha, diffuse, colors, lambdas, compression_type=codec, lambda_thres=thres)
+    ii, jj = np.meshgrid(np.arange(t), np.arange(t), indexing="ij")
+    idx = torch.from_numpy(np.stack([ii.ravel(), jj.ravel()], 1)).long()
+    want = oq.features_from_texture_map(idx, torch.from_numpy(alpha), torch.from_numpy(diffuse),
+                                        [torch.from_numpy(c) for c in colors], [torch.from_numpy(l) for l in lambdas],
+                                        codec, thres)
+    got = comp.get_features_from_texture_map(idx.to(device))
+    assert got.shape == want.shape == (t * t, 3 + 7 * lobes + 1)
+    finite = torch.isfinite(want)
+    assert torch.equal(torch.isfinite(got.cpu()), finite)      # sigmoid codec: code 255 -> log(inf) clipped, 0 -> log(1e-8)
+    _close(got.cpu()[finite], want[finite])
+    # fused shade == decode + features_to_rgb
+    d = torch.randn(t * t, 3)
+    d = d / d.norm(dim=-1, keepdim=True)
+    rgb, sigma = comp.shade(idx.to(device), d.to(device))
+    _close(sigma, want[:, -1])
+    _close(rgb, ofields.features_to_rgb(want[:, :-1], d, lobes), atol=5e-6, rtol=5e-5)
+
+
+def test_texel_indices_bit_exact(device):
+    from quadraturefields_amd import synthetic, utils
+    from quadraturefields_amd.mesh_utils import MeshIntersection
+    from oracle import meshpath as om
+    mesh = synthetic.shell_mesh(n_shells=3, subdivisions=3)
+    size = 512
+    mi = MeshIntersection(mesh, simplify_mesh=False, scale=1.0, num_intersections=25)
+    c2w = synthetic.orbit_cameras(1, seed=3)[0]
+    o, d = synthetic.camera_rays(c2w, synthetic.lego_focal(96), 96, 96)
+    data = mi.sampling_raytrace_device(d, o, image_width=96)
+    xyz, _, _, _, index_tri, _ = data
+    uv = synthetic.scaled_uv(mesh, size)
+    f = mesh.faces[index_tri.cpu().numpy()]
+    want = oq.texel_indices(mesh.vertices[f], xyz.cpu().numpy(), torch.from_numpy(uv)[torch.from_numpy(f)], size)
+    got = utils.texel_indices(mi, uv, xyz, index_tri, size)
+    assert got.dtype == torch.int64
+    assert torch.equal(got.cpu(), want)
+    assert int(got.min()) >= 0 and int(got.max()) <= size - 1
+    # points far off the triangle: barycentrics clamp + renormalise (utils.py:1058-1061)
+    far = xyz + 0.5
+    want = oq.texel_indices(mesh.vertices[f], far.cpu().numpy(), torch.from_numpy(uv)[torch.from_numpy(f)], size)
+    assert torch.equal(utils.texel_indices(mi, uv, far, index_tri, size).cpu(), want)
+
+
+def test_compress_roundtrip_through_textures(device):
+    """encode (reference's compress) -> device decode: decoded values are within one quantisation step."""
+    from quadraturefields_amd.texture_utils import FeatureCompression
+    lobes, t = 3, 64
+    comp = FeatureCompression(lobes, initialize=True, texture_size=t, compression_type="linear", lambda_thres=7.5)
+    g = torch.Generator().manual_seed(0)
+    n = t * t
+    feats = torch.randn(n, 3 + 7 * lobes + 1, generator=g) * 2
+    feats[:, -1] = torch.rand(n, generator=g) * 200
+    ii, jj = np.meshgrid(np.arange(t), np.arange(t), indexing="ij")
+    idx = torch.from_numpy(np.stack([ii.ravel(), jj.ravel()], 1)).long().to(device)
+    comp.load_features_into_maps(feats.to(device), idx)
+    back = comp.get_features_from_texture_map(idx).cpu()
+    assert torch.allclose(back[:, :3], feats[:, :3].clamp(-12, 12), atol=24 / 255 + 1e-4)
+    a = 1 - torch.exp(-feats[:, -1] * 0.005)
+    assert torch.allclose(1 - torch.exp(-back[:, -1] * 0.005), a, atol=1 / 255 + 1e-4)
+    data = oq.compress_features(feats, lobes, "linear", 7.5)
+    assert torch.equal(comp.alpha.cpu().reshape(-1), data["alpha"])
+    assert torch.equal(comp.diffuse.cpu().reshape(-1, 3), data["diffuse"])
