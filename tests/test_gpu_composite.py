@@ -162,7 +162,7 @@ def test_derive_properties_closed_forms(device):
     a0 = 1 - np.exp(-0.5)
     assert abs(float(alpha[0]) - a0) < 1e-6
     # white background with the reference's double alpha: (1-a) + a*(a*c)
-    assert torch.allclose(rgb[0].cpu(), torch.tensor([(1 - a0) + a0 * a0 * c for c in (0.2, 0.4, 0.6)]), atol=1e-6)
+    assert torch.allclose(rgb[0].cpu(), torch.tensor([(1 - a0) + a0 * a0 * c for c in (0.2, 0.4, 0.6)], dtype=torch.float32), atol=1e-6)
     assert abs(float(dep[0]) - a0 * 2.0) < 1e-6
     assert torch.equal(rgb[1].cpu(), torch.ones(3)) and float(alpha[1]) == 0.0            # empty ray
     assert torch.allclose(rgb[2].cpu(), torch.tensor([0.0, 1.0, 0.0]), atol=1e-6)           # opaque second sample
