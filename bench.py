@@ -30,6 +30,11 @@ HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 ALG_BYTES_PER_POINT = 16 * 8 * 2 * 4   # 16 levels x 8 corners x 2 features x 4 B
 
 
+def log(msg):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
 def build_scene(device, seed=42):
     from quadraturefields_amd import synthetic
     from quadraturefields_amd.mesh_utils import MeshIntersection
@@ -104,7 +109,7 @@ def cpu_baseline(mesh, field, cam_o, cam_d, crop=40):
     field evaluation and compositing."""
     from oracle import meshpath as om
     from tests import helpers
-    cores = os.cpu_count() or 1
+    cores = om.host_cores()
     torch.set_num_threads(cores)
     y0 = x0 = (W - crop) // 2
     idx = (torch.arange(y0, y0 + crop)[:, None] * W + torch.arange(x0, x0 + crop)[None, :]).reshape(-1)
@@ -142,7 +147,9 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
 
+    log("building scene (mesh, BVH, field)")
     mesh, mi, field = build_scene(device)
+    log(f"scene ready: {mesh.faces.shape[0]} triangles, {mi.rayintersector.num_nodes} BVH nodes")
     n_frames = args.steps + args.warmup
     cams = synthetic.orbit_cameras(n_frames * world, seed=42)
     focal = synthetic.lego_focal(W)
@@ -159,6 +166,8 @@ def main():
 
     for i in range(args.warmup):
         step(i, False)
+        torch.cuda.synchronize()
+        log(f"warmup {i} done")
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
@@ -171,6 +180,7 @@ def main():
         torch.distributed.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    log(f"timed region done: {elapsed:.3f} s for {args.steps} steps")
     t = torch.tensor([elapsed, float(pts)], dtype=torch.float64, device=device)
     if world > 1:
         tmax = t.clone()
@@ -219,6 +229,7 @@ def main():
         },
     }
     if not args.no_cpu_baseline:
+        log("cpu baseline (oracle on host cores)")
         base, rgb_o, idx = cpu_baseline(mesh, field, rays[0][0].cpu(), rays[0][1].cpu())
         rgb0 = stages.frame(rays[0][0], rays[0][1])[0].cpu()[idx]
         base["max_abs_err_vs_hip"] = float((rgb0 - rgb_o).abs().max())

@@ -48,10 +48,11 @@ static inline int mt_hit(const float *tri, const float *o, const float *d, float
  * out_tri/out_t [n_rays][max_hits] (unused slots: -1 / +inf), out_count [n_rays]. */
 int qf_oracle_multihit(const float *tri_verts, int64_t n_tri,
                        const float *rays_o, const float *rays_d, int64_t n_rays,
-                       int max_hits, int32_t *out_tri, float *out_t, int32_t *out_count)
+                       int max_hits, int n_threads, int32_t *out_tri, float *out_t, int32_t *out_count)
 {
     if (max_hits <= 0 || n_tri < 0 || n_rays < 0) return -1;
-#pragma omp parallel for schedule(dynamic, 16)
+    if (n_threads < 1) n_threads = 1;
+#pragma omp parallel for schedule(dynamic, 4) num_threads(n_threads)
     for (int64_t r = 0; r < n_rays; ++r) {
         int32_t *ht = out_tri + r * max_hits;
         float *tt = out_t + r * max_hits;

@@ -25,6 +25,22 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
 
+def host_cores(cap: int = 16) -> int:
+    """Usable host cores: affinity mask and cgroup quota respected, capped (a 1-GPU box shares its host)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, cap))
+
+
 def build() -> str:
     """Compile intersect_ref.c with gcc (oracle/Makefile) and return the .so path."""
     subprocess.run(["make", "-s", "-C", _HERE], check=True)
@@ -41,7 +57,7 @@ def _lib():
         _LIB.qf_oracle_multihit.restype = ctypes.c_int
         _LIB.qf_oracle_multihit.argtypes = [
             ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
-            ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+            ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
     return _LIB
 
 
@@ -72,7 +88,7 @@ class BruteForceIntersector:
         self.faces = np.ascontiguousarray(faces, dtype=np.int64)
         self.tri = np.ascontiguousarray(self.vertices.astype(np.float32)[self.faces].reshape(-1, 9))
 
-    def hits(self, origins, vectors, max_hits):
+    def hits(self, origins, vectors, max_hits, n_threads=None):
         """-> (tri [R,K] int32 (-1 pad), t [R,K] fp32 (+inf pad), count [R] int32)."""
         o = np.ascontiguousarray(origins, dtype=np.float32)
         d = np.ascontiguousarray(vectors, dtype=np.float32)
@@ -82,7 +98,7 @@ class BruteForceIntersector:
         cnt = np.empty(n, dtype=np.int32)
         rc = _lib().qf_oracle_multihit(
             self.tri.ctypes.data, self.tri.shape[0], o.ctypes.data, d.ctypes.data, n,
-            int(max_hits), tri.ctypes.data, t.ctypes.data, cnt.ctypes.data)
+            int(max_hits), int(n_threads or host_cores()), tri.ctypes.data, t.ctypes.data, cnt.ctypes.data)
         if rc != 0:
             raise RuntimeError("qf_oracle_multihit failed: %d" % rc)
         return tri, t, cnt
