@@ -155,7 +155,7 @@ def main():
     focal = synthetic.lego_focal(W)
     rays = [synthetic.camera_rays(cams[i * world + rank], focal, W, H, device=device) for i in range(n_frames)]
     stages = Stages(mi, field)
-    gather_buf = torch.empty((world, W * H, 5), dtype=torch.float32, device=device) if world > 1 else None
+    gather_buf = torch.empty((world * W * H, 5), dtype=torch.float32, device=device) if world > 1 else None
 
     def step(i, record):
         o, d = rays[i]

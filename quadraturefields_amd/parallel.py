@@ -54,9 +54,10 @@ def gather_frame(local: torch.Tensor, width: int, height: int, rank: int, world_
     if world_size == 1:
         gathered = local[None]
     else:
-        buf = torch.empty((world_size,) + tuple(local.shape), dtype=local.dtype, device=local.device)
+        # concatenated layout [world*n_local, C]: accepted by both RCCL and gloo
+        buf = torch.empty((world_size * local.shape[0], c), dtype=local.dtype, device=local.device)
         dist.all_gather_into_tensor(buf, local.contiguous())
-        gathered = buf
+        gathered = buf.view(world_size, local.shape[0], c)
     frame = torch.zeros((width * height, c), dtype=local.dtype, device=local.device)
     for r in range(world_size):
         ids = tile_ray_indices(shard_tiles(width, height, r, world_size), width, height).reshape(-1).to(local.device)
