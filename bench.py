@@ -51,8 +51,8 @@ class Stages:
     """One frame, stage by stage, with a HIP event pair around each stage on the launch stream."""
     NAMES = ("traverse", "pack", "field", "composite")
 
-    def __init__(self, mi, field):
-        self.mi, self.field = mi, field
+    def __init__(self, mi, field, coherent=True):
+        self.mi, self.field, self.coherent, self.order = mi, field, coherent, None
         self.ev = {k: [] for k in self.NAMES}
 
     def _timed(self, name, fn, record):
@@ -65,14 +65,19 @@ class Stages:
         self.ev[name].append((a, b))
         return out
 
-    def frame(self, o, d, record=False):
+    def frame(self, o, d, cam=None, record=False):
+        """cam (mesh_utils.make_camera): the rays are that camera's pixel grid -> camera-coherent intersector,
+        with the exact K-nearest BVH traversal as fallback when a pixel collects more than MAX_HITS candidates."""
         from quadraturefields_amd import utils
         n_rays = o.shape[0]
         ri = self.mi.rayintersector
-        hits = self._timed("traverse", lambda: ri.hits(o, d, MAX_HITS, image_width=W), record)
+        if cam is not None:
+            hits = self._timed("traverse", lambda: ri._hits_raster(o, d, MAX_HITS, cam) + (o, d), record)
+        else:
+            hits = self._timed("traverse", lambda: ri._hits_bvh(o, d, MAX_HITS, W) + (None, o, d), record)
         data = self._timed("pack", lambda: self._pack(hits), record)
         xyz, dirs, index_ray, ts, index_tri, org = data
-        rgbs, sigmas = self._timed("field", lambda: self.field(xyz, dirs), record)
+        rgbs, sigmas = self._timed("field", lambda: self.field(xyz, dirs, order=self.order), record)
         out = self._timed("composite", lambda: utils.derive_properties(
             rgbs, sigmas.reshape(-1), ts, STEP, None, index_ray, bg_color="white", N=n_rays), record)
         rgb, alpha, _, depth, _ = out
@@ -80,10 +85,18 @@ class Stages:
 
     def _pack(self, hits):
         from quadraturefields_amd import _C
-        hit_tri, hit_t, hit_count, o, d = hits
+        hit_tri, hit_t, hit_count, overflow, o, d = hits
         n = o.shape[0]
         csum = torch.cumsum(hit_count.to(torch.int64), dim=0)
-        total = int(csum[-1].item())
+        if overflow is not None:      # one readback: sample total + raster overflow flag
+            total, ovf = torch.stack([csum[-1], overflow[0].to(torch.int64)]).tolist()
+            if ovf:
+                hit_tri, hit_t, hit_count = self.mi.rayintersector._hits_bvh(o, d, MAX_HITS, W)
+                csum = torch.cumsum(hit_count.to(torch.int64), dim=0)
+                total = int(csum[-1].item())
+                self.fallbacks = getattr(self, "fallbacks", 0) + 1
+        else:
+            total = int(csum[-1].item())
         offset = (csum - hit_count).contiguous()
         dev = o.device
         xyz = torch.empty((total, 3), dtype=torch.float32, device=dev)
@@ -96,6 +109,7 @@ class Stages:
                                           _C.ptr(hit_count), _C.ptr(offset), _C.ptr(xyz), _C.ptr(dirs),
                                           _C.ptr(index_ray), _C.ptr(depth), _C.ptr(index_tri), _C.ptr(org),
                                           _C.stream()), "qf_pack_samples")
+        self.order = self.mi.rayintersector.coherent_order(hit_count, offset, total, W) if self.coherent else None
         return xyz, dirs, index_ray, depth, index_tri, org
 
     def stage_ms(self):
@@ -138,6 +152,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--intersector", default="raster", choices=["raster", "bvh"],
+                    help="raster: camera-coherent intersector (BVH fallback on overflow); bvh: BVH traversal only")
     args = ap.parse_args()
 
     from quadraturefields_amd import parallel, synthetic
@@ -153,13 +169,15 @@ def main():
     n_frames = args.steps + args.warmup
     cams = synthetic.orbit_cameras(n_frames * world, seed=42)
     focal = synthetic.lego_focal(W)
+    from quadraturefields_amd.mesh_utils import make_camera
     rays = [synthetic.camera_rays(cams[i * world + rank], focal, W, H, device=device) for i in range(n_frames)]
+    cameras = [None if args.intersector == "bvh" else make_camera(cams[i * world + rank], focal, W, H) for i in range(n_frames)]
     stages = Stages(mi, field)
     gather_buf = torch.empty((world * W * H, 5), dtype=torch.float32, device=device) if world > 1 else None
 
     def step(i, record):
         o, d = rays[i]
-        rgb, alpha, depth, n_pts = stages.frame(o, d, record)
+        rgb, alpha, depth, n_pts = stages.frame(o, d, cameras[i], record)
         if world > 1:
             torch.distributed.all_gather_into_tensor(gather_buf, torch.cat([rgb, alpha, depth], dim=1))
         return rgb, n_pts
@@ -215,6 +233,7 @@ def main():
             "workload": "Lego 800x800 (configs[1]), 1xMI355X per frame, fp32 hash-grid + tiny-MLP HIP kernels",
             "rays_per_frame": W * H, "max_hits": MAX_HITS, "triangles": int(mesh.faces.shape[0]),
             "log2_hashmap_size": LOG2_T, "render_step_size": STEP, "up_sample": 1,
+            "intersector": args.intersector, "bvh_fallback_frames": getattr(stages, "fallbacks", 0),
             "parallelism": f"{world} rank(s), one frame per rank per step" + (", all_gather of tiles" if world > 1 else ""),
         },
         "quadrature_points_per_frame": pts_per_launch,
@@ -231,7 +250,7 @@ def main():
     if not args.no_cpu_baseline:
         log("cpu baseline (oracle on host cores)")
         base, rgb_o, idx = cpu_baseline(mesh, field, rays[0][0].cpu(), rays[0][1].cpu())
-        rgb0 = stages.frame(rays[0][0], rays[0][1])[0].cpu()[idx]
+        rgb0 = stages.frame(rays[0][0], rays[0][1], cameras[0])[0].cpu()[idx]
         base["max_abs_err_vs_hip"] = float((rgb0 - rgb_o).abs().max())
         mse = float(((rgb0.double() - rgb_o.double()) ** 2).mean())
         base["psnr_hip_vs_oracle_db"] = float("inf") if mse == 0 else -10.0 * float(np.log10(mse))

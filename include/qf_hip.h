@@ -94,11 +94,14 @@ typedef struct qf_sg_head {
 } qf_sg_head;
 
 /* xyz [n,3] world positions, dirs [n,3] unit view directions (may be NULL for HEAD_NONE /
- * HEAD_SG_FEATURES).  Outputs (any may be NULL when not produced by the head):
+ * HEAD_SG_FEATURES).  order: NULL, or a permutation of [0,n) giving the order in which points are PROCESSED
+ * (16 consecutive slots share a wave pass; spatially coherent groups hit the caches better, see
+ * qf_coherent_order); outputs are indexed by point, so results do not depend on it.
+ * Outputs (any may be NULL when not produced by the head):
  *   rgb [n,3]; sigma [n] (density after exp(x-1)*selector); geo [n,15]; features [n,3+7L+1]. */
 int qf_field_forward(const qf_field_desc *desc /* host */, const float *table,
                      const float *base_w, const float *head_ngp_w, const qf_sg_head *head_sg /* host */,
-                     const float *xyz, const float *dirs, int64_t n,
+                     const float *xyz, const float *dirs, int64_t n, const int32_t *order,
                      float *rgb, float *sigma, float *geo, float *features, void *stream);
 
 /* rgb = sigmoid(diffuse + sum_l c_l exp(|lambda_l| (a_l/|a_l| . d - 1))).
@@ -199,6 +202,23 @@ int qf_bvh_intersect(const qf_bvh *bvh, const float *rays_o, const float *rays_d
                      int32_t max_hits, int32_t image_width, int32_t *hit_tri, float *hit_t,
                      int32_t *hit_count, void *stream);
 
+/* Camera-coherent variant for rays that are the row-major pixel grid of ONE pinhole camera in the reference's
+ * convention (nerf_synthetic.py:341-358): camera_dir = ((x - cx + 0.5)/fx, -(y - cy + 0.5)/fy, -1),
+ * ray = normalise(c2w[:3,:3] . camera_dir), origin = c2w[:3,3].  Every triangle is tested only against the pixels
+ * of its projected screen box, with the same hit test on the same (rays_o, rays_d) values, so the result is
+ * bit-identical to qf_bvh_intersect.  *overflow (device int32) is set to the number of hits that found their
+ * ray's list full: when it is non-zero the lists are NOT guaranteed to hold the K nearest hits and the caller must
+ * fall back to qf_bvh_intersect.  The camera is only used to bound the search, never for arithmetic.           */
+typedef struct qf_camera {
+    float c2w[12];      /* row-major 3x4 camera-to-world (OpenGL axes: right, up, back | centre) */
+    float fx, fy;       /* focal lengths in pixels */
+    float cx, cy;       /* principal point (width/2, height/2 in the reference) */
+    int32_t width, height;
+} qf_camera;
+int qf_raster_intersect(const qf_bvh *bvh, const qf_camera *cam /* host */, const float *rays_o,
+                        const float *rays_d, int64_t n_rays, int32_t max_hits, int32_t *hit_tri, float *hit_t,
+                        int32_t *hit_count, int32_t *overflow, void *stream);
+
 /* Packs the per-ray hit lists into the sample arrays sampling_raytrace_numpy returns
  * (mesh_utils.py:359-387), already sorted by (ray, depth): location = o + t d in float64,
  * dirs = d/(|d|+1e-7), depth = |location - o| (float64, rounded to fp32 at the end).
@@ -207,6 +227,16 @@ int qf_pack_samples(const float *rays_o, const float *rays_d, int64_t n_rays, in
                     const int32_t *hit_tri, const float *hit_t, const int32_t *hit_count,
                     const int64_t *ray_offset, float *xyz, float *dirs, int64_t *index_ray,
                     float *depth, int64_t *index_tri, float *origins, void *stream);
+
+/* Spatially coherent PROCESSING order for qf_field_forward when the rays are a row-major width x height image:
+ * (8x8 pixel tile, hit rank, pixel in tile).  Two steps around one exclusive scan the caller does:
+ *   qf_tile_totals    : tile_total[tile] = sum of hit_count over the tile's pixels (tiles row-major, ceil(w/8) per row)
+ *   qf_coherent_order : order[tile_base[tile] + slot] = ray_offset[ray] + k   (tile_base = exclusive scan of totals)
+ * order is a permutation of [0, sum(hit_count)).  New on this platform (no reference counterpart): it only
+ * changes which samples share a wave pass, never a result.                                                    */
+int qf_tile_totals(const int32_t *hit_count, int32_t width, int32_t height, int64_t *tile_total, void *stream);
+int qf_coherent_order(const int32_t *hit_count, const int64_t *ray_offset, const int64_t *tile_base,
+                      int32_t width, int32_t height, int32_t *order, void *stream);
 
 /* Stable per-ray re-sort by depth after deformation (sampling_indexing, mesh_utils.py:394-403):
  * perm[i] = source index of the sample that lands at i.  index_ray must be grouped by ray.   */

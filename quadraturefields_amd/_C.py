@@ -37,6 +37,11 @@ class SGHead(Structure):
                 ("wout", c_void_p), ("bout", c_void_p)]
 
 
+class Camera(Structure):
+    _fields_ = [("c2w", c_float * 12), ("fx", c_float), ("fy", c_float), ("cx", c_float), ("cy", c_float),
+                ("width", c_int32), ("height", c_int32)]
+
+
 class TextureSet(Structure):
     _fields_ = [("alpha", c_void_p), ("diffuse", c_void_p), ("colors", c_void_p * QF_MAX_LOBES),
                 ("lambda_axis", c_void_p * QF_MAX_LOBES), ("texture_size", c_int32), ("n_lobes", c_int32),
@@ -51,7 +56,7 @@ _SIGNATURES = {
     "qf_grid_desc_init": (c_int, [POINTER(GridDesc), c_uint32, c_uint32, c_uint32, c_double]),
     "qf_grid_encode": (c_int, [POINTER(GridDesc), _P, _P, c_int64, _P, _P]),
     "qf_grid_mlp_forward": (c_int, [POINTER(GridDesc), _P, _P, _P, c_int64, _P, _P]),
-    "qf_field_forward": (c_int, [POINTER(FieldDesc), _P, _P, _P, POINTER(SGHead), _P, _P, c_int64, _P, _P, _P, _P, _P]),
+    "qf_field_forward": (c_int, [POINTER(FieldDesc), _P, _P, _P, POINTER(SGHead), _P, _P, c_int64, _P, _P, _P, _P, _P, _P]),
     "qf_sg_features_to_rgb": (c_int, [_P, c_int64, _P, c_int64, c_int32, _P, _P]),
     "qf_deform_field_forward": (c_int, [POINTER(GridDesc), _P, c_float, c_int32, _P, _P, _P, _P, _P, _P, _P, c_int64, _P, _P]),
     "qf_apply_deformation": (c_int, [_P, c_float, _P, _P, _P, c_int64, _P]),
@@ -71,7 +76,10 @@ _SIGNATURES = {
     "qf_bvh_copy_nodes": (c_int, [_P, _P, c_int64]),
     "qf_bvh_copy_tri_ids": (c_int, [_P, _P, c_int64]),
     "qf_bvh_intersect": (c_int, [_P, _P, _P, c_int64, c_int32, c_int32, _P, _P, _P, _P]),
+    "qf_raster_intersect": (c_int, [_P, POINTER(Camera), _P, _P, c_int64, c_int32, _P, _P, _P, _P, _P]),
     "qf_pack_samples": (c_int, [_P, _P, c_int64, c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "qf_tile_totals": (c_int, [_P, c_int32, c_int32, _P, _P]),
+    "qf_coherent_order": (c_int, [_P, _P, _P, c_int32, c_int32, _P, _P]),
     "qf_resort_by_depth": (c_int, [_P, _P, c_int64, _P, _P]),
     "qf_texel_indices": (c_int, [_P, _P, _P, _P, _P, c_int64, c_int32, _P, _P]),
     "qf_texture_fetch": (c_int, [POINTER(TextureSet), _P, c_int64, _P, _P]),

@@ -304,3 +304,75 @@ extern "C" int qf_apply_deformation(const float *f, float scaling, const float *
     QF_SIMPLE_LAUNCH(apply_deformation_kernel, n, f, scaling, dirs, xyz, ts, n);
     return QF_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// Spatially coherent processing order for the field kernel.  Samples are stored ray-major (the reference's
+// layout), so 16 consecutive samples are 1-2 rays' worth of hits strung along the ray: no two of them share a
+// hash-grid cell.  Re-ordering the PROCESSING order as (8x8 pixel tile, hit rank, pixel in tile) puts the
+// rank-k hits of neighbouring pixels -- points on the same surface patch, a pixel footprint apart -- into the
+// same wave pass, so their gathers coalesce / hit L1 on every level whose cells are larger than a pixel.
+// One wave per tile, lane = pixel; ballots give each (pixel, rank) its slot.
+namespace {
+
+__device__ __forceinline__ int tile_lane_ray(int tile, int lane, int w, int h, int tiles_x, int64_t *ray)
+{
+    const int px = (tile % tiles_x) * 8 + (lane & 7);
+    const int py = (tile / tiles_x) * 8 + (lane >> 3);
+    if (px >= w || py >= h) return 0;
+    *ray = (int64_t)py * w + px;
+    return 1;
+}
+
+__global__ __launch_bounds__(64) void tile_totals_kernel(const int32_t *hit_count, int w, int h, int tiles_x,
+                                                         int64_t *tile_total)
+{
+    const int tile = blockIdx.x, lane = threadIdx.x;
+    int64_t ray = 0;
+    int cnt = 0;
+    if (tile_lane_ray(tile, lane, w, h, tiles_x, &ray)) cnt = hit_count[ray];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
+    if (lane == 0) tile_total[tile] = cnt;
+}
+
+__global__ __launch_bounds__(64) void coherent_order_kernel(const int32_t *hit_count, const int64_t *ray_offset,
+                                                            const int64_t *tile_base, int w, int h, int tiles_x,
+                                                            int32_t *order)
+{
+    const int tile = blockIdx.x, lane = threadIdx.x;
+    int64_t ray = 0;
+    int cnt = 0;
+    int64_t first = 0;
+    if (tile_lane_ray(tile, lane, w, h, tiles_x, &ray)) { cnt = hit_count[ray]; first = ray_offset[ray]; }
+    int64_t base = tile_base[tile];
+    const unsigned long long below = (1ull << lane) - 1ull;
+    for (int k = 0;; ++k) {
+        const unsigned long long mask = __ballot(cnt > k);
+        if (mask == 0ull) break;                      // wave-uniform exit
+        if (cnt > k) order[base + __popcll(mask & below)] = (int32_t)(first + k);
+        base += __popcll(mask);
+    }
+}
+
+}  // namespace
+
+extern "C" int qf_tile_totals(const int32_t *hit_count, int32_t width, int32_t height, int64_t *tile_total, void *stream)
+{
+    if (width < 1 || height < 1 || !hit_count || !tile_total) return QF_ERR_INVALID_ARGUMENT;
+    const int tiles_x = (width + 7) / 8, tiles_y = (height + 7) / 8;
+    hipLaunchKernelGGL(tile_totals_kernel, dim3(tiles_x * tiles_y), dim3(64), 0, qf_stream(stream), hit_count, (int)width,
+                       (int)height, tiles_x, tile_total);
+    QF_LAUNCH_CHECK();
+    return QF_OK;
+}
+
+extern "C" int qf_coherent_order(const int32_t *hit_count, const int64_t *ray_offset, const int64_t *tile_base,
+                                 int32_t width, int32_t height, int32_t *order, void *stream)
+{
+    if (width < 1 || height < 1 || !hit_count || !ray_offset || !tile_base || !order) return QF_ERR_INVALID_ARGUMENT;
+    const int tiles_x = (width + 7) / 8, tiles_y = (height + 7) / 8;
+    hipLaunchKernelGGL(coherent_order_kernel, dim3(tiles_x * tiles_y), dim3(64), 0, qf_stream(stream), hit_count,
+                       ray_offset, tile_base, (int)width, (int)height, tiles_x, order);
+    QF_LAUNCH_CHECK();
+    return QF_OK;
+}

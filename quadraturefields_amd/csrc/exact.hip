@@ -186,6 +186,105 @@ __global__ __launch_bounds__(64) void bvh_traverse_kernel(const float4 *__restri
     hit_count[ray] = count;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Camera-coherent intersector: when the rays are the pixel grid of one pinhole camera (every eval frame of the
+// reference: nerf_synthetic.py:310-373), the set of rays that can hit a triangle is bounded by the triangle's
+// projected screen box.  Each triangle is tested only against those pixels -- with the SAME mt_hit() on the SAME
+// (o, d) values as the BVH path, so the hits are bit-identical -- and appended to the pixel's list with one
+// atomic.  No tree, no stack, coalesced triangle reads; the lists are sorted afterwards (sort_hits_kernel).
+struct RasterCam {
+    float r00, r01, r02, r10, r11, r12, r20, r21, r22;   // c2w[:3,:3]: columns = camera right / up / back
+    float cx, cy, cz;                                      // camera centre
+    float fx, fy, px0, py0;                                // pixel = f * (x/z) + p0   (p0 = principal - 0.5)
+    int w, h;
+};
+
+constexpr int kRasterLanes = 8;   // lanes cooperating on one triangle: 4 along x, 2 along y
+
+__global__ __launch_bounds__(256) void raster_kernel(const float4 *__restrict__ tris, int64_t n_tri, RasterCam cam,
+                                                     const float *__restrict__ rays_o, const float *__restrict__ rays_d,
+                                                     int max_hits, int32_t *__restrict__ hit_tri, float *__restrict__ hit_t,
+                                                     int32_t *__restrict__ hit_count, int32_t *__restrict__ overflow)
+{
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t tri_i = gid / kRasterLanes;
+    const int sub = (int)(gid % kRasterLanes);
+    if (tri_i >= n_tri) return;
+    const float4 a = tris[tri_i * 3 + 0], b = tris[tri_i * 3 + 1], c = tris[tri_i * 3 + 2];
+    const int id = __float_as_int(a.w);
+    // conservative screen box of the triangle (projection of a convex set is inside the box of its vertices)
+    float minx = INFINITY, maxx = -INFINITY, miny = INFINITY, maxy = -INFINITY;
+    int behind = 0;
+    const float4 vs[3] = {a, b, c};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float dx = vs[k].x - cam.cx, dy = vs[k].y - cam.cy, dz = vs[k].z - cam.cz;
+        const float xc = cam.r00 * dx + cam.r10 * dy + cam.r20 * dz;    // R^T (v - c)
+        const float yc = cam.r01 * dx + cam.r11 * dy + cam.r21 * dz;
+        const float zc = cam.r02 * dx + cam.r12 * dy + cam.r22 * dz;
+        const float zv = -zc;                                           // depth along the viewing direction
+        if (!(zv > 1e-6f)) { ++behind; continue; }
+        const float sx = cam.fx * (xc / zv) + cam.px0;
+        const float sy = -cam.fy * (yc / zv) + cam.py0;
+        minx = fminf(minx, sx); maxx = fmaxf(maxx, sx);
+        miny = fminf(miny, sy); maxy = fmaxf(maxy, sy);
+    }
+    if (behind == 3) return;                 // entirely behind the camera: t > 0 is impossible
+    int x0, x1, y0, y1;
+    if (behind > 0) {                        // straddles the camera plane: no finite box, test every pixel
+        x0 = 0; y0 = 0; x1 = cam.w - 1; y1 = cam.h - 1;
+    } else {
+        // +-1.5 pixel guard band covers the rounding of the projection and of the ray directions
+        x0 = (int)fmaxf(floorf(minx - 1.5f), 0.0f);
+        y0 = (int)fmaxf(floorf(miny - 1.5f), 0.0f);
+        x1 = (int)fminf(ceilf(maxx + 1.5f), (float)(cam.w - 1));
+        y1 = (int)fminf(ceilf(maxy + 1.5f), (float)(cam.h - 1));
+        if (!(maxx + 1.5f >= 0.0f) || !(maxy + 1.5f >= 0.0f) || !(minx - 1.5f <= (float)(cam.w - 1)) ||
+            !(miny - 1.5f <= (float)(cam.h - 1)))
+            return;
+    }
+    for (int py = y0 + (sub >> 2); py <= y1; py += 2) {
+        for (int px = x0 + (sub & 3); px <= x1; px += 4) {
+            const int64_t ray = (int64_t)py * cam.w + px;
+            const float ox = rays_o[ray * 3], oy = rays_o[ray * 3 + 1], oz = rays_o[ray * 3 + 2];
+            const float dx = rays_d[ray * 3], dy = rays_d[ray * 3 + 1], dz = rays_d[ray * 3 + 2];
+            float t;
+            if (!mt_hit(a, b, c, ox, oy, oz, dx, dy, dz, &t)) continue;
+            const int slot = atomicAdd(&hit_count[ray], 1);
+            if (slot < max_hits) {
+                hit_t[ray * max_hits + slot] = t;
+                hit_tri[ray * max_hits + slot] = id;
+            } else {
+                atomicAdd(overflow, 1);      // more than max_hits candidates: the caller re-runs the exact K-nearest BVH path
+            }
+        }
+    }
+}
+
+// In-place ascending (t, tri) sort of every ray's (unordered) list, padding and count clamp.
+__global__ void sort_hits_kernel(int64_t n_rays, int max_hits, int32_t *hit_tri, float *hit_t, int32_t *hit_count)
+{
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_rays; r += (int64_t)gridDim.x * blockDim.x) {
+        int cnt = hit_count[r];
+        if (cnt > max_hits) { cnt = max_hits; hit_count[r] = cnt; }
+        float *my_t = hit_t + r * max_hits;
+        int32_t *my_tri = hit_tri + r * max_hits;
+        for (int i = 1; i < cnt; ++i) {
+            const float t = my_t[i];
+            const int id = my_tri[i];
+            int j = i - 1;
+            while (j >= 0 && hit_less(t, id, my_t[j], my_tri[j])) {
+                my_t[j + 1] = my_t[j];
+                my_tri[j + 1] = my_tri[j];
+                --j;
+            }
+            my_t[j + 1] = t;
+            my_tri[j + 1] = id;
+        }
+        for (int i = cnt; i < max_hits; ++i) { my_t[i] = INFINITY; my_tri[i] = -1; }
+    }
+}
+
 // sampling_raytrace_numpy (mesh_utils.py:359-387) for rays whose hits are already ascending in (t, tri).
 __global__ void pack_samples_kernel(const float *rays_o, const float *rays_d, int64_t n_rays, int max_hits,
                                     const int32_t *hit_tri, const float *hit_t, const int32_t *hit_count,
@@ -471,5 +570,40 @@ extern "C" int qf_texture_shade(const qf_texture_set *tex, const int64_t *texel,
     if (n == 0) return QF_OK;
     if (!texel || !dirs || !rgb || !sigma) return QF_ERR_INVALID_ARGUMENT;
     QF_SIMPLE_LAUNCH(texture_shade_kernel, n, t, texel, dirs, n, rgb, sigma);
+    return QF_OK;
+}
+
+extern "C" int qf_raster_intersect(const qf_bvh *bvh, const qf_camera *cam, const float *rays_o, const float *rays_d,
+                                   int64_t n_rays, int32_t max_hits, int32_t *hit_tri, float *hit_t, int32_t *hit_count,
+                                   int32_t *overflow, void *stream)
+{
+    if (!bvh || !cam || n_rays < 0 || max_hits < 1 || max_hits > kMaxHits) return QF_ERR_INVALID_ARGUMENT;
+    if (cam->width < 1 || cam->height < 1 || (int64_t)cam->width * cam->height != n_rays) return QF_ERR_INVALID_ARGUMENT;
+    if (!(cam->fx > 0.0f) || !(cam->fy > 0.0f)) return QF_ERR_INVALID_ARGUMENT;
+    if (!rays_o || !rays_d || !hit_tri || !hit_t || !hit_count || !overflow) return QF_ERR_INVALID_ARGUMENT;
+    hipStream_t st = qf_stream(stream);
+    QF_HIP_TRY(hipMemsetAsync(hit_count, 0, (size_t)n_rays * sizeof(int32_t), st));
+    QF_HIP_TRY(hipMemsetAsync(overflow, 0, sizeof(int32_t), st));
+    RasterCam rc;
+    const float *m = cam->c2w;     // row-major 3x4
+    rc.r00 = m[0]; rc.r01 = m[1]; rc.r02 = m[2]; rc.cx = m[3];
+    rc.r10 = m[4]; rc.r11 = m[5]; rc.r12 = m[6]; rc.cy = m[7];
+    rc.r20 = m[8]; rc.r21 = m[9]; rc.r22 = m[10]; rc.cz = m[11];
+    rc.fx = cam->fx; rc.fy = cam->fy;
+    rc.px0 = cam->cx - 0.5f;       // camera_dir.x = (x - cx + 0.5) / fx
+    rc.py0 = cam->cy - 0.5f;
+    rc.w = cam->width; rc.h = cam->height;
+    if (bvh->n_tri > 0) {
+        const int64_t threads = bvh->n_tri * kRasterLanes;
+        const int64_t blocks = qf_div_up(threads, 256);
+        if (blocks > 0x7fffffff) return QF_ERR_UNSUPPORTED;
+        hipLaunchKernelGGL(raster_kernel, dim3((unsigned)blocks), dim3(256), 0, st,
+                           reinterpret_cast<const float4 *>(bvh->d_tris), bvh->n_tri, rc, rays_o, rays_d, (int)max_hits,
+                           hit_tri, hit_t, hit_count, overflow);
+        QF_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(sort_hits_kernel, dim3(qf_grid_1d(n_rays, 256)), dim3(256), 0, st, n_rays, (int)max_hits, hit_tri,
+                       hit_t, hit_count);
+    QF_LAUNCH_CHECK();
     return QF_OK;
 }

@@ -55,6 +55,7 @@ struct FieldArgs {
     float *geo;
     float *features;
     float *raw16;       // optional [n,16]: raw base-MLP outputs (tcnn NetworkWithInputEncoding.forward)
+    const int32_t *order;   // optional [n]: point processed at slot i
     int32_t n_lobes;
     int32_t n_out;      // 3 + 7L
     int32_t nt_out;     // ceil(n_out / 16)
@@ -257,7 +258,8 @@ __global__ __launch_bounds__(kBlock, 4) void field_kernel(const FieldArgs a)
     for (int64_t grp = wave_global; grp < n_groups; grp += wave_stride) {
         const int64_t pt_raw = grp * 16 + p;
         const bool valid = pt_raw < a.n;
-        const int64_t pt = valid ? pt_raw : a.n - 1;
+        int64_t pt = valid ? pt_raw : a.n - 1;
+        if (a.order) pt = a.order[pt];   // processing permutation (spatially coherent groups); results unchanged
 
         const float X = a.xyz[pt * 3 + 0], Y = a.xyz[pt * 3 + 1], Z = a.xyz[pt * 3 + 2];
         // (x - lo) / (hi - lo), ngp.py:761-763
@@ -682,10 +684,10 @@ extern "C" int qf_grid_encode(const qf_grid_desc *desc, const float *table, cons
 
 extern "C" int qf_field_forward(const qf_field_desc *desc, const float *table, const float *base_w,
                                 const float *head_ngp_w, const qf_sg_head *head_sg, const float *xyz,
-                                const float *dirs, int64_t n, float *rgb, float *sigma, float *geo,
-                                float *features, void *stream)
+                                const float *dirs, int64_t n, const int32_t *order, float *rgb, float *sigma,
+                                float *geo, float *features, void *stream)
 {
-    if (!desc || !table || !base_w || n < 0) return QF_ERR_INVALID_ARGUMENT;
+    if (!desc || !table || !base_w || n < 0 || n > 0x7fffffff) return QF_ERR_INVALID_ARGUMENT;
     FieldArgs a = {};
     int rc = fill_grid_args(&desc->grid, &a.grid);
     if (rc != QF_OK) return rc;
@@ -703,6 +705,7 @@ extern "C" int qf_field_forward(const qf_field_desc *desc, const float *table, c
     a.sigma = sigma;
     a.geo = geo;
     a.features = features;
+    a.order = order;
     if (n == 0) return QF_OK;
     if (!xyz) return QF_ERR_INVALID_ARGUMENT;
     hipStream_t st = qf_stream(stream);

@@ -23,6 +23,19 @@ def _as_device_f32(x, device) -> torch.Tensor:
     return x.to(device=device, dtype=torch.float32).contiguous()
 
 
+def make_camera(c2w, focal: float, width: int, height: int) -> _C.Camera:
+    """Pinhole camera in the reference's convention (nerf_synthetic.py:219-226,341-358): K = [[f,0,W/2],[0,f,H/2]],
+    pixel centres at +0.5, OpenGL axes.  ``c2w``: [3,4] or [4,4] (tensor / array)."""
+    m = np.asarray(c2w.detach().cpu() if isinstance(c2w, torch.Tensor) else c2w, dtype=np.float32)[:3, :4]
+    cam = _C.Camera()
+    for i, v in enumerate(m.reshape(-1).tolist()):
+        cam.c2w[i] = v
+    cam.fx = cam.fy = float(focal)
+    cam.cx, cam.cy = width / 2.0, height / 2.0
+    cam.width, cam.height = int(width), int(height)
+    return cam
+
+
 class RayIntersector:
     """Multi-hit ray/mesh intersector.  Duck-types trimesh's ``RayMeshIntersector`` and the reference's OptiX
     adapter (``intersects_id``, ``update_intersector``; mesh_utils.py:75-109)."""
@@ -33,6 +46,7 @@ class RayIntersector:
         self.mesh = mesh
         self.max_hits = int(max_hits)
         self.device = torch.device(device)
+        self.last_order = None           # coherent processing order of the most recent image-shaped sample_device()
         self._handle = ctypes.c_void_p()
         tri = np.ascontiguousarray(mesh.vertices.astype(np.float32)[mesh.faces].reshape(-1, 9))
         with torch.cuda.device(self.device):
@@ -62,21 +76,44 @@ class RayIntersector:
             tri = np.ascontiguousarray(v.reshape(-1, 3)[self.mesh.faces].reshape(-1, 9))
         _C.check(_C.lib().qf_bvh_refit(self._handle, tri.ctypes.data_as(ctypes.c_void_p), tri.shape[0]), "qf_bvh_refit")
 
-    def hits(self, origins, vectors, max_hits: Optional[int] = None, image_width: int = 0):
-        """Device result: (hit_tri [R,K] int32 (-1 pad), hit_t [R,K] fp32 (+inf pad), hit_count [R] int32),
-        each ray's hits ascending in (t, triangle id)."""
+    def _alloc_hits(self, n, k):
+        return (torch.empty((n, k), dtype=torch.int32, device=self.device),
+                torch.empty((n, k), dtype=torch.float32, device=self.device),
+                torch.empty((n,), dtype=torch.int32, device=self.device))
+
+    def _hits_bvh(self, o, d, k, image_width):
+        n = o.shape[0]
+        hit_tri, hit_t, hit_count = self._alloc_hits(n, k)
+        _C.check(_C.lib().qf_bvh_intersect(self._handle, _C.ptr(o), _C.ptr(d), n, k, int(image_width),
+                                           _C.ptr(hit_tri), _C.ptr(hit_t), _C.ptr(hit_count), _C.stream()),
+                 "qf_bvh_intersect")
+        return hit_tri, hit_t, hit_count
+
+    def _hits_raster(self, o, d, k, camera):
+        """Camera-coherent path; returns the lists plus the device overflow counter (unchecked)."""
+        n = o.shape[0]
+        hit_tri, hit_t, hit_count = self._alloc_hits(n, k)
+        overflow = torch.empty((1,), dtype=torch.int32, device=self.device)
+        _C.check(_C.lib().qf_raster_intersect(self._handle, ctypes.byref(camera), _C.ptr(o), _C.ptr(d), n, k,
+                                              _C.ptr(hit_tri), _C.ptr(hit_t), _C.ptr(hit_count), _C.ptr(overflow),
+                                              _C.stream()), "qf_raster_intersect")
+        return hit_tri, hit_t, hit_count, overflow
+
+    def hits(self, origins, vectors, max_hits: Optional[int] = None, image_width: int = 0, camera=None):
+        """Device result: (hit_tri [R,K] int32 (-1 pad), hit_t [R,K] fp32 (+inf pad), hit_count [R] int32, o, d),
+        each ray's hits ascending in (t, triangle id).  ``camera`` (see ``make_camera``) selects the
+        camera-coherent intersector for rays that are that camera's pixel grid; results are identical."""
         k = self.max_hits if max_hits is None else int(max_hits)
         o = _as_device_f32(origins, self.device).reshape(-1, 3)
         d = _as_device_f32(vectors, self.device).reshape(-1, 3)
         if o.shape != d.shape:
             raise ValueError("origins and vectors must have the same shape")
-        n = o.shape[0]
-        hit_tri = torch.empty((n, k), dtype=torch.int32, device=self.device)
-        hit_t = torch.empty((n, k), dtype=torch.float32, device=self.device)
-        hit_count = torch.empty((n,), dtype=torch.int32, device=self.device)
-        _C.check(_C.lib().qf_bvh_intersect(self._handle, _C.ptr(o), _C.ptr(d), n, k, int(image_width),
-                                           _C.ptr(hit_tri), _C.ptr(hit_t), _C.ptr(hit_count), _C.stream()),
-                 "qf_bvh_intersect")
+        if camera is not None:
+            hit_tri, hit_t, hit_count, overflow = self._hits_raster(o, d, k, camera)
+            if int(overflow.item()) == 0:
+                return hit_tri, hit_t, hit_count, o, d
+            image_width = camera.width          # some ray has more than K candidates: exact K-nearest via the BVH
+        hit_tri, hit_t, hit_count = self._hits_bvh(o, d, k, image_width)
         return hit_tri, hit_t, hit_count, o, d
 
     def find_intersections(self, rays) -> np.ndarray:
@@ -85,15 +122,31 @@ class RayIntersector:
         hit_tri, _, _, _, _ = self.hits(r[:, :3], r[:, 3:])
         return hit_tri.reshape(-1).cpu().numpy()
 
-    def sample_device(self, origins, vectors, max_hits: Optional[int] = None, image_width: int = 0):
+    def sample_device(self, origins, vectors, max_hits: Optional[int] = None, image_width: int = 0, camera=None):
         """Packed, sorted samples on the device: [xyzs, dirs, index_ray, ts, index_tri, origins] -- the six
         tensors the reference's DataLoader hands to the renderers (nerf_synthetic.py:256-257) -- or None
         when no ray hits anything."""
         k = self.max_hits if max_hits is None else int(max_hits)
-        hit_tri, hit_t, hit_count, o, d = self.hits(origins, vectors, k, image_width)
+        o = _as_device_f32(origins, self.device).reshape(-1, 3)
+        d = _as_device_f32(vectors, self.device).reshape(-1, 3)
         n = o.shape[0]
+        if n == 0:
+            return None
+        if camera is not None:
+            hit_tri, hit_t, hit_count, overflow = self._hits_raster(o, d, k, camera)
+        else:
+            hit_tri, hit_t, hit_count = self._hits_bvh(o, d, k, image_width)
+            overflow = None
         csum = torch.cumsum(hit_count.to(torch.int64), dim=0)
-        total = int(csum[-1].item()) if n else 0          # output size is data dependent: one sync
+        # output size is data dependent: ONE readback (total samples + raster overflow flag)
+        if overflow is not None:
+            total, ovf = torch.stack([csum[-1], overflow[0].to(torch.int64)]).tolist()
+            if ovf:
+                hit_tri, hit_t, hit_count = self._hits_bvh(o, d, k, camera.width)
+                csum = torch.cumsum(hit_count.to(torch.int64), dim=0)
+                total = int(csum[-1].item())
+        else:
+            total = int(csum[-1].item())
         if total == 0:
             return None
         offset = (csum - hit_count).contiguous()
@@ -108,7 +161,24 @@ class RayIntersector:
                                           _C.ptr(hit_count), _C.ptr(offset), _C.ptr(xyz), _C.ptr(dirs),
                                           _C.ptr(index_ray), _C.ptr(depth), _C.ptr(index_tri), _C.ptr(org),
                                           _C.stream()), "qf_pack_samples")
+        width = camera.width if camera is not None else int(image_width)
+        self.last_order = (self.coherent_order(hit_count, offset, total, width)
+                           if width > 0 and n % width == 0 else None)
         return [xyz, dirs, index_ray, depth, index_tri, org]
+
+    def coherent_order(self, hit_count: torch.Tensor, ray_offset: torch.Tensor, total: int, width: int) -> torch.Tensor:
+        """int32 permutation of the ``total`` packed samples of a row-major ``width``-wide image, ordered
+        (8x8 tile, hit rank, pixel).  Handing it to ``radiance_field(points, dirs, order=...)`` makes the points of
+        one wave pass neighbours on the same surface patch (cache locality only; results are unchanged)."""
+        height = hit_count.shape[0] // width
+        tiles = ((width + 7) // 8) * ((height + 7) // 8)
+        totals = torch.empty((tiles,), dtype=torch.int64, device=hit_count.device)
+        _C.check(_C.lib().qf_tile_totals(_C.ptr(hit_count), width, height, _C.ptr(totals), _C.stream()), "qf_tile_totals")
+        base = (torch.cumsum(totals, dim=0) - totals).contiguous()
+        order = torch.empty((total,), dtype=torch.int32, device=hit_count.device)
+        _C.check(_C.lib().qf_coherent_order(_C.ptr(hit_count), _C.ptr(ray_offset), _C.ptr(base), width, height,
+                                            _C.ptr(order), _C.stream()), "qf_coherent_order")
+        return order
 
     @torch.no_grad()
     def intersects_id(self, origins, vectors, multiple_hits=True, return_locations=True, max_hits=10):
@@ -180,9 +250,10 @@ class MeshIntersection:
         """Constant step for every sample (mesh_utils.py:225-231; B-4)."""
         return torch.full((depth.shape[0],), self.render_step_size, dtype=torch.float32, device=self.device)
 
-    def sampling_raytrace_device(self, vectors, origins, image_width: int = 0):
-        """Fast path of ``sampling_raytrace_numpy``: same six arrays, on the device, no host round trip."""
-        return self.rayintersector.sample_device(origins, vectors, self.num_intersections, image_width)
+    def sampling_raytrace_device(self, vectors, origins, image_width: int = 0, camera=None):
+        """Fast path of ``sampling_raytrace_numpy``: same six arrays, on the device, no host round trip.
+        ``camera`` (``make_camera``): the rays are that camera's full pixel grid -> camera-coherent intersector."""
+        return self.rayintersector.sample_device(origins, vectors, self.num_intersections, image_width, camera)
 
     def sampling_raytrace_numpy(self, vectors, origins, random=0):
         """numpy 7-tuple (points, dirs, index_ray, depth, index_tri, 0, origins) sorted by (ray, depth), or None

@@ -165,7 +165,7 @@ class _FusedFieldBase(nn.Module):
         return selector, x
 
     def _launch(self, head, n_lobes, xyz, dirs, want_rgb=False, want_sigma=False, want_geo=False, want_features=0,
-                head_ngp=None, head_sg=None):
+                head_ngp=None, head_sg=None, order=None):
         xyz = _C.f32c(xyz.reshape(-1, 3))
         n = xyz.shape[0]
         dev = xyz.device
@@ -184,7 +184,7 @@ class _FusedFieldBase(nn.Module):
         _C.check(_C.lib().qf_field_forward(
             ctypes.byref(desc), _C.ptr(self.mlp_base.grid_params()), _C.ptr(self.mlp_base.network_params()),
             _C.ptr(head_ngp), ctypes.byref(sg) if sg is not None else None, _C.ptr(xyz), _C.ptr(dirs), n,
-            _C.ptr(rgb), _C.ptr(sigma), _C.ptr(geo), _C.ptr(feats), _C.stream()), "qf_field_forward")
+            _C.ptr(order, torch.int32), _C.ptr(rgb), _C.ptr(sigma), _C.ptr(geo), _C.ptr(feats), _C.stream()), "qf_field_forward")
         return rgb, sigma, geo, feats
 
     def query_density(self, x, return_feat: bool = False):
@@ -218,14 +218,15 @@ class NGPRadianceField(_FusedFieldBase):
             network_config={"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": "None",
                             "n_neurons": hidden_size, "n_hidden_layers": 2})
 
-    def forward(self, positions: torch.Tensor, directions: torch.Tensor = None):
-        """(rgb [..,3], density [..,1]).  ngp.py:798-809."""
+    def forward(self, positions: torch.Tensor, directions: torch.Tensor = None, order: torch.Tensor = None):
+        """(rgb [..,3], density [..,1]).  ngp.py:798-809.  ``order`` (int32 permutation, optional) only changes the
+        order in which points are processed (cache locality), never the result."""
         if directions is None:
             raise ValueError("NGPRadianceField.forward needs view directions")
         assert positions.shape == directions.shape, f"{positions.shape} v.s. {directions.shape}"
         lead = list(positions.shape[:-1])
         rgb, sigma, _, _ = self._launch(_C.HEAD_NGP, 0, positions, directions, want_rgb=True, want_sigma=True,
-                                        head_ngp=self.mlp_head.params.detach())
+                                        head_ngp=self.mlp_head.params.detach(), order=order)
         return rgb.reshape(lead + [3]), sigma.reshape(lead + [1])
 
 
@@ -275,11 +276,11 @@ class NGPRadianceFieldSGNew(_FusedFieldBase):
                                                 self.num_g_lobes, _C.ptr(rgb), _C.stream()), "qf_sg_features_to_rgb")
         return rgb
 
-    def forward(self, positions: torch.Tensor, directions: torch.Tensor = None):
+    def forward(self, positions: torch.Tensor, directions: torch.Tensor = None, order: torch.Tensor = None):
         """(rgb, density), ngp.py:463-470."""
         if directions is None:
             raise ValueError("NGPRadianceFieldSGNew.forward needs view directions")
         lead = list(positions.shape[:-1])
         rgb, sigma, _, _ = self._launch(_C.HEAD_SG, self.num_g_lobes, positions, directions, want_rgb=True,
-                                        want_sigma=True, head_sg=self._sg_params())
+                                        want_sigma=True, head_sg=self._sg_params(), order=order)
         return rgb.reshape(lead + [3]), sigma.reshape(lead + [1])

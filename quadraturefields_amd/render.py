@@ -23,16 +23,16 @@ class FrameRenderer:
         self.bg_color = bg_color
 
     @torch.no_grad()
-    def quadrature_points(self, origins: torch.Tensor, viewdirs: torch.Tensor, image_width: int = 0):
+    def quadrature_points(self, origins: torch.Tensor, viewdirs: torch.Tensor, image_width: int = 0, camera=None):
         """[xyzs, dirs, index_ray, ts, index_tri, origins] on the device (None if no hit)."""
-        return self.mesh_intersect.sampling_raytrace_device(viewdirs, origins, image_width=image_width)
+        return self.mesh_intersect.sampling_raytrace_device(viewdirs, origins, image_width=image_width, camera=camera)
 
     @torch.no_grad()
     def render(self, origins: torch.Tensor, viewdirs: torch.Tensor, image_width: int = 0, scaling: float = 0.0,
-               render_bkgd: Optional[torch.Tensor] = None):
+               render_bkgd: Optional[torch.Tensor] = None, camera=None):
         """(rgb [R,3], alpha [R,1], depth [R,1], n_samples) for R rays."""
         n_rays = origins.shape[0]
-        data = self.quadrature_points(origins, viewdirs, image_width)
+        data = self.quadrature_points(origins, viewdirs, image_width, camera)
         if data is None:
             dev = origins.device
             fill = 0.0 if self.bg_color == "black" else 1.0
@@ -42,14 +42,14 @@ class FrameRenderer:
         rgb, alpha, depth, n_samples, *_ = utils.render_image_finetune_with_occgrid(
             self.radiance_field, self.field_net, None, rays, data, render_step_size=self.render_step_size,
             render_bkgd=render_bkgd, mesh_intersect=self.mesh_intersect, mesh_finetune=None, scaling=scaling,
-            bg_color=self.bg_color)
+            bg_color=self.bg_color, order=self.mesh_intersect.rayintersector.last_order)
         return rgb, alpha, depth, n_samples
 
     @torch.no_grad()
-    def render_baked(self, origins, viewdirs, uv, compressor, image_width: int = 0):
+    def render_baked(self, origins, viewdirs, uv, compressor, image_width: int = 0, camera=None):
         """Baked-texture variant (test_baking_texture_images.py:355-371)."""
         n_rays = origins.shape[0]
-        data = self.quadrature_points(origins, viewdirs, image_width)
+        data = self.quadrature_points(origins, viewdirs, image_width, camera)
         if data is None:
             dev = origins.device
             return (torch.ones((n_rays, 3), device=dev), torch.zeros((n_rays, 1), device=dev),

@@ -108,9 +108,10 @@ def render_image_finetune_with_occgrid(
     near_plane: float = 0.0, far_plane: float = 1e10, render_step_size: float = 1e-3,
     render_bkgd: Optional[torch.Tensor] = None, cone_angle: float = 0.0, alpha_thre: float = 0.0,
     test_chunk_size: int = 8192, timestamps: Optional[torch.Tensor] = None, mesh_intersect=None,
-    mesh_finetune=None, scaling=1 / 128, bg_color="white",
+    mesh_finetune=None, scaling=1 / 128, bg_color="white", order=None,
 ):
     """Render the samples of one split through the (deformed) quadrature points -- utils.py:465-607.
+    ``order`` (extension, optional): coherent processing order from ``RayIntersector.coherent_order``.
 
     Returns the reference's 9-tuple (colors, opacities, depths, n_samples, weights, positions, index_ray,
     loss, index_tri).  ``loss`` is the deformation regulariser of :583 and is returned as zeros: it needs the
@@ -130,7 +131,10 @@ def render_image_finetune_with_occgrid(
     # scaling == 0 multiplies the displacement by zero in the reference (utils.py:566-571): skipping is exact.
     points, deltas, boundary, dirs, index_ray, depth, index_tri_s, _ = mesh_intersect.sampling_indexing(
         xyzs, origins, dirs, index_ray, ts, index_tri)
-    rgbs, sigmas = radiance_field(points, dirs)
+    if order is not None and order.shape[0] == points.shape[0]:
+        rgbs, sigmas = radiance_field(points, dirs, order=order)    # coherent processing order: locality only
+    else:
+        rgbs, sigmas = radiance_field(points, dirs)
     rgb, opacity, _, depth_img, weights = derive_properties(
         rgbs, sigmas.reshape(-1), depth, deltas, boundary, index_ray, bg_color=bg_color, render_bkgd=render_bkgd,
         N=num_rays)

@@ -191,3 +191,77 @@ def test_full_size_mesh_sampled_against_bruteforce(device):
     same = index_ray[1:] == index_ray[:-1]
     assert bool((ts[1:][same] >= ts[:-1][same]).all())
     assert torch.allclose((xyz - org).norm(dim=-1), ts, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("w,h,max_hits", [(96, 64, 25), (40, 40, 3)])
+def test_raster_intersector_identical_to_bvh(device, w, h, max_hits):
+    """Camera-coherent intersector == BVH traversal == brute force, bit for bit; overflow falls back to the BVH."""
+    from quadraturefields_amd import synthetic
+    from quadraturefields_amd.mesh_utils import RayIntersector, make_camera
+    mesh = _scene(3, 4)
+    ri = RayIntersector(mesh, max_hits=max_hits)
+    for seed in (0, 7):
+        c2w = synthetic.orbit_cameras(1, seed=seed)[0]
+        focal = synthetic.lego_focal(800) * w / 800.0
+        o, d = synthetic.camera_rays(c2w, focal, w, h)
+        cam = make_camera(c2w, focal, w, h)
+        a = ri.hits(o, d, image_width=w)
+        b = ri.hits(o, d, camera=cam)                      # max_hits=3 overflows -> exercises the fallback
+        for x, y in zip(a[:3], b[:3]):
+            assert torch.equal(x, y)
+        tri_o, t_o, cnt_o = om.BruteForceIntersector(mesh.vertices, mesh.faces).hits(o.numpy(), d.numpy(), max_hits)
+        assert np.array_equal(b[0].cpu().numpy(), tri_o) and np.array_equal(b[2].cpu().numpy(), cnt_o)
+        assert np.array_equal(b[1].cpu().numpy(), t_o)
+        if max_hits == 25:
+            raw = ri._hits_raster(a[3], a[4], max_hits, cam)
+            assert int(raw[3].item()) == 0
+            s1 = ri.sample_device(o, d, image_width=w)
+            s2 = ri.sample_device(o, d, camera=cam)
+            for x, y in zip(s1, s2):
+                assert torch.equal(x, y)
+        else:
+            assert int(ri._hits_raster(a[3], a[4], max_hits, cam)[3].item()) > 0
+    # camera inside the object and a camera whose image plane cuts triangles: still identical
+    c2w = synthetic.orbit_cameras(1, seed=3)[0].clone()
+    c2w[:, 3] *= 0.12
+    focal = 30.0
+    o, d = synthetic.camera_rays(c2w, focal, w, h)
+    a = ri.hits(o, d, image_width=w)
+    b = ri.hits(o, d, camera=make_camera(c2w, focal, w, h))
+    for x, y in zip(a[:3], b[:3]):
+        assert torch.equal(x, y)
+
+
+def test_coherent_order_is_the_tile_rank_pixel_permutation(device):
+    """qf_coherent_order == argsort of (8x8 tile, hit rank, pixel in tile); the field result does not depend on it."""
+    from quadraturefields_amd import synthetic
+    from quadraturefields_amd.mesh_utils import MeshIntersection, make_camera
+    from quadraturefields_amd.radiance_fields.ngp import NGPRadianceField
+    mesh = _scene(3, 4)
+    mi = MeshIntersection(mesh, simplify_mesh=False, scale=1.0, num_intersections=25)
+    for w, h in ((64, 48), (37, 21)):                       # second case: ragged tiles at the right/bottom edge
+        c2w = synthetic.orbit_cameras(1, seed=w)[0]
+        focal = synthetic.lego_focal(800) * w / 800.0
+        o, d = synthetic.camera_rays(c2w, focal, w, h)
+        data = mi.sampling_raytrace_device(d, o, camera=make_camera(c2w, focal, w, h))
+        order = mi.rayintersector.last_order
+        ray = data[2].cpu()
+        n = ray.shape[0]
+        assert order.dtype == torch.int32 and order.shape == (n,)
+        first = torch.zeros(w * h + 1, dtype=torch.int64)
+        first[1:] = torch.cumsum(torch.bincount(ray, minlength=w * h), 0)
+        k = torch.arange(n) - first[ray]
+        px, py = ray % w, ray // w
+        tiles_x = (w + 7) // 8
+        key = ((py // 8) * tiles_x + px // 8) * (64 * 64) + k * 64 + (py % 8) * 8 + px % 8
+        assert torch.equal(order.cpu().long(), torch.argsort(key))
+        field = NGPRadianceField(aabb=[-1.5] * 3 + [1.5] * 3, log2_hashmap_size=12)
+        field.load_state_dict(synthetic.seeded_ngp_state(12, field.mlp_base.grid.n_rows), strict=False)
+        field = field.to(device)
+        a = field(data[0], data[1])
+        b = field(data[0], data[1], order=order)
+        c = field(data[0], data[1], order=torch.randperm(n, device=device).to(torch.int32))
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[0], c[0]) and torch.equal(a[1], c[1])
+    # rays that are not an image: no order
+    mi.sampling_raytrace_device(d[:100], o[:100])
+    assert mi.rayintersector.last_order is None

@@ -15,27 +15,47 @@ import bench
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=10)
-    ap.add_argument("--stage", default="field", choices=["field", "traverse", "pack", "composite", "frame"])
+    ap.add_argument("--order", default="ray", choices=["ray", "tile", "tile4", "random"])
+    ap.add_argument("--stage", default="field", choices=["field", "traverse", "raster", "pack", "composite", "frame"])
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     from quadraturefields_amd import synthetic
     mesh, mi, field = bench.build_scene(dev)
     o, d = synthetic.camera_rays(synthetic.orbit_cameras(1, seed=42)[0], synthetic.lego_focal(bench.W), bench.W, bench.H, device=dev)
     st = bench.Stages(mi, field)
-    hits = mi.rayintersector.hits(o, d, bench.MAX_HITS, image_width=bench.W)
+    from quadraturefields_amd.mesh_utils import make_camera
+    cam = make_camera(synthetic.orbit_cameras(1, seed=42)[0], synthetic.lego_focal(bench.W), bench.W, bench.H)
+    ri = mi.rayintersector
+    hits = ri._hits_bvh(o, d, bench.MAX_HITS, bench.W) + (None, o, d)
     data = st._pack(hits)
     xyz, dirs, index_ray, ts, index_tri, org = data
     n = xyz.shape[0]
+    order = None
+    if args.order != "ray":
+        ray = index_ray
+        first = torch.zeros(o.shape[0] + 1, dtype=torch.int64, device=dev)
+        first[1:] = torch.cumsum(torch.bincount(ray, minlength=o.shape[0]), 0)
+        k = torch.arange(n, device=dev) - first[ray]
+        px, py = ray % bench.W, ray // bench.W
+        if args.order == "tile":      # (8x8 tile, hit rank, pixel in tile)
+            key = ((py // 8) * (bench.W // 8) + px // 8) * (64 * 64) + k * 64 + (py % 8) * 8 + px % 8
+        elif args.order == "tile4":   # (4x4 tile, hit rank, pixel in tile): one wave pass = one 4x4 patch at one rank
+            key = ((py // 4) * (bench.W // 4) + px // 4) * (64 * 16) + k * 16 + (py % 4) * 4 + px % 4
+        else:
+            key = torch.randperm(n, device=dev)
+        order = torch.argsort(key).to(torch.int32).contiguous()
 
     def run():
         if args.stage == "field":
-            return field(xyz, dirs)
+            return field(xyz, dirs, order=order)
         if args.stage == "traverse":
-            return mi.rayintersector.hits(o, d, bench.MAX_HITS, image_width=bench.W)
+            return ri._hits_bvh(o, d, bench.MAX_HITS, bench.W)
+        if args.stage == "raster":
+            return ri._hits_raster(o, d, bench.MAX_HITS, cam)
         if args.stage == "pack":
             return st._pack(hits)
         if args.stage == "frame":
-            return st.frame(o, d)
+            return st.frame(o, d, cam)
         from quadraturefields_amd import utils
         return utils.derive_properties(rgbs, sig.reshape(-1), ts, bench.STEP, None, index_ray, N=o.shape[0])
 
