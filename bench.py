@@ -72,7 +72,7 @@ class Stages:
         n_rays = o.shape[0]
         ri = self.mi.rayintersector
         if cam is not None:
-            hits = self._timed("traverse", lambda: ri._hits_raster(o, d, MAX_HITS, cam) + (o, d), record)
+            hits = self._timed("traverse", lambda: ri._hits_raster(o, d, MAX_HITS, cam, sort_lists=False) + (o, d), record)
         else:
             hits = self._timed("traverse", lambda: ri._hits_bvh(o, d, MAX_HITS, W) + (None, o, d), record)
         data = self._timed("pack", lambda: self._pack(hits), record)

@@ -208,7 +208,9 @@ int qf_bvh_intersect(const qf_bvh *bvh, const float *rays_o, const float *rays_d
  * of its projected screen box, with the same hit test on the same (rays_o, rays_d) values, so the result is
  * bit-identical to qf_bvh_intersect.  *overflow (device int32) is set to the number of hits that found their
  * ray's list full: when it is non-zero the lists are NOT guaranteed to hold the K nearest hits and the caller must
- * fall back to qf_bvh_intersect.  The camera is only used to bound the search, never for arithmetic.           */
+ * fall back to qf_bvh_intersect.  The camera is only used to bound the search, never for arithmetic.
+ * sort_lists != 0: lists come out ascending in (t, tri) and padded like qf_bvh_intersect; 0: left in arrival
+ * order with raw counts, for qf_pack_samples (which sorts while it packs).                                      */
 typedef struct qf_camera {
     float c2w[12];      /* row-major 3x4 camera-to-world (OpenGL axes: right, up, back | centre) */
     float fx, fy;       /* focal lengths in pixels */
@@ -217,12 +219,13 @@ typedef struct qf_camera {
 } qf_camera;
 int qf_raster_intersect(const qf_bvh *bvh, const qf_camera *cam /* host */, const float *rays_o,
                         const float *rays_d, int64_t n_rays, int32_t max_hits, int32_t *hit_tri, float *hit_t,
-                        int32_t *hit_count, int32_t *overflow, void *stream);
+                        int32_t *hit_count, int32_t *overflow, int32_t sort_lists, void *stream);
 
 /* Packs the per-ray hit lists into the sample arrays sampling_raytrace_numpy returns
  * (mesh_utils.py:359-387), already sorted by (ray, depth): location = o + t d in float64,
  * dirs = d/(|d|+1e-7), depth = |location - o| (float64, rounded to fp32 at the end).
- * ray_offset [n_rays] = exclusive prefix sum of hit_count.                                     */
+ * The per-ray lists may be in any order (they are sorted by (t, tri) first); counts above max_hits are clamped.
+ * ray_offset [n_rays] = exclusive prefix sum of min(hit_count, max_hits).                       */
 int qf_pack_samples(const float *rays_o, const float *rays_d, int64_t n_rays, int32_t max_hits,
                     const int32_t *hit_tri, const float *hit_t, const int32_t *hit_count,
                     const int64_t *ray_offset, float *xyz, float *dirs, int64_t *index_ray,

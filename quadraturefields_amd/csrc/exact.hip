@@ -285,53 +285,120 @@ __global__ void sort_hits_kernel(int64_t n_rays, int max_hits, int32_t *hit_tri,
     }
 }
 
-// sampling_raytrace_numpy (mesh_utils.py:359-387) for rays whose hits are already ascending in (t, tri).
-__global__ void pack_samples_kernel(const float *rays_o, const float *rays_d, int64_t n_rays, int max_hits,
-                                    const int32_t *hit_tri, const float *hit_t, const int32_t *hit_count,
-                                    const int64_t *ray_offset, float *xyz, float *dirs, int64_t *index_ray, float *depth,
-                                    int64_t *index_tri, float *origins)
+// sampling_raytrace_numpy (mesh_utils.py:359-387): per-ray hit lists (in ANY order) -> packed samples sorted by
+// (ray, depth).  A workgroup owns 128 consecutive rays, i.e. one contiguous slice of every output array:
+//   1. the rays' [K] rows of hit_t / hit_tri are loaded into LDS with coalesced reads;
+//   2. lane = ray: in-LDS insertion sort by (t, tri) -- the intersector's pass order -- then the stable sort by the
+//      float64 depth |o + t d - o| of mesh_utils.py:371-375 (a no-op unless rounding reverses two near-equal hits);
+//      each (ray, rank) drops its id into a slot map of the slice;
+//   3. lane = output sample: coalesced writes of the six sample arrays.
+constexpr int kPackRays = 128;
+
+__device__ __forceinline__ double sample_depth64(float t, const double o[3], const double d[3], double p[3])
 {
-    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_rays; r += (int64_t)gridDim.x * blockDim.x) {
-        const int cnt = hit_count[r];
-        if (cnt <= 0) continue;
-        const float ox = rays_o[r * 3], oy = rays_o[r * 3 + 1], oz = rays_o[r * 3 + 2];
-        const float dx = rays_d[r * 3], dy = rays_d[r * 3 + 1], dz = rays_d[r * 3 + 2];
-        // vectors / (|vectors| + 1e-7) in float32 (mesh_utils.py:369-370)
-        const float nrm = sqrtf((dx * dx + dy * dy) + dz * dz) + 1e-7f;
-        const float ux = dx / nrm, uy = dy / nrm, uz = dz / nrm;
+    const double td = (double)t;
+    p[0] = o[0] + td * d[0];
+    p[1] = o[1] + td * d[1];
+    p[2] = o[2] + td * d[2];
+    const double qx = p[0] - o[0], qy = p[1] - o[1], qz = p[2] - o[2];
+    return sqrt((qx * qx + qy * qy) + qz * qz);      // np.linalg.norm(points - origins, axis=1)
+}
+
+__global__ __launch_bounds__(kPackRays) void pack_samples_kernel(
+    const float *__restrict__ rays_o, const float *__restrict__ rays_d, int64_t n_rays, int max_hits,
+    const int32_t *__restrict__ hit_tri, const float *__restrict__ hit_t, const int32_t *__restrict__ hit_count,
+    const int64_t *__restrict__ ray_offset, float *__restrict__ xyz, float *__restrict__ dirs,
+    int64_t *__restrict__ index_ray, float *__restrict__ depth, int64_t *__restrict__ index_tri,
+    float *__restrict__ origins)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int K = max_hits, Kp = max_hits | 1;            // odd row stride: conflict-free column access
+    float *s_t = reinterpret_cast<float *>(smem);
+    int32_t *s_tri = reinterpret_cast<int32_t *>(s_t + kPackRays * Kp);
+    uint16_t *s_map = reinterpret_cast<uint16_t *>(s_tri + kPackRays * Kp);
+    __shared__ int s_region;
+
+    const int tid = threadIdx.x;
+    const int64_t ray0 = (int64_t)blockIdx.x * kPackRays;
+    const int nr = (int)((n_rays - ray0) < kPackRays ? (n_rays - ray0) : kPackRays);
+    for (int i = tid; i < nr * K; i += kPackRays) {
+        const int r = i / K, k = i - r * K;
+        s_t[r * Kp + k] = hit_t[ray0 * K + i];
+        s_tri[r * Kp + k] = hit_tri[ray0 * K + i];
+    }
+    if (tid == 0) s_region = 0;
+    __syncthreads();
+
+    const int64_t block_base = ray_offset[ray0];
+    if (tid < nr) {
+        const int64_t ray = ray0 + tid;
+        int cnt = hit_count[ray];
+        if (cnt > K) cnt = K;
+        float *row_t = s_t + tid * Kp;
+        int32_t *row_i = s_tri + tid * Kp;
+        for (int i = 1; i < cnt; ++i) {                       // (t, tri) ascending
+            const float t = row_t[i];
+            const int id = row_i[i];
+            int j = i - 1;
+            while (j >= 0 && hit_less(t, id, row_t[j], row_i[j])) { row_t[j + 1] = row_t[j]; row_i[j + 1] = row_i[j]; --j; }
+            row_t[j + 1] = t;
+            row_i[j + 1] = id;
+        }
+        if (cnt > 1) {
+            const double o64[3] = {(double)rays_o[ray * 3], (double)rays_o[ray * 3 + 1], (double)rays_o[ray * 3 + 2]};
+            const double d64[3] = {(double)rays_d[ray * 3], (double)rays_d[ray * 3 + 1], (double)rays_d[ray * 3 + 2]};
+            double p[3];
+            double prev = sample_depth64(row_t[0], o64, d64, p);
+            bool sorted = true;
+            for (int k = 1; k < cnt; ++k) {
+                const double dk = sample_depth64(row_t[k], o64, d64, p);
+                sorted = sorted && !(prev > dk);
+                prev = dk;
+            }
+            if (!sorted) {                                     // rare: stable insertion by depth, depths recomputed
+                for (int i = 1; i < cnt; ++i) {
+                    const float t = row_t[i];
+                    const int id = row_i[i];
+                    const double di = sample_depth64(t, o64, d64, p);
+                    int j = i - 1;
+                    while (j >= 0 && sample_depth64(row_t[j], o64, d64, p) > di) { row_t[j + 1] = row_t[j]; row_i[j + 1] = row_i[j]; --j; }
+                    row_t[j + 1] = t;
+                    row_i[j + 1] = id;
+                }
+            }
+        }
+        const int local = (int)(ray_offset[ray] - block_base);
+        for (int k = 0; k < cnt; ++k) s_map[local + k] = (uint16_t)((tid << 8) | k);
+        if (tid == nr - 1) s_region = local + cnt;
+    }
+    __syncthreads();
+
+    const int region = s_region;
+    for (int j = tid; j < region; j += kPackRays) {
+        const int m = s_map[j];
+        const int rl = m >> 8, k = m & 255;
+        const int64_t ray = ray0 + rl;
+        const float ox = rays_o[ray * 3], oy = rays_o[ray * 3 + 1], oz = rays_o[ray * 3 + 2];
+        const float dx = rays_d[ray * 3], dy = rays_d[ray * 3 + 1], dz = rays_d[ray * 3 + 2];
         const double o64[3] = {(double)ox, (double)oy, (double)oz};
         const double d64[3] = {(double)dx, (double)dy, (double)dz};
-        double dep[kMaxHits];
-        int order[kMaxHits];
-        for (int k = 0; k < cnt; ++k) {
-            const double t = (double)hit_t[r * max_hits + k];
-            const double qx = (o64[0] + t * d64[0]) - o64[0];
-            const double qy = (o64[1] + t * d64[1]) - o64[1];
-            const double qz = (o64[2] + t * d64[2]) - o64[2];
-            const double dk = sqrt((qx * qx + qy * qy) + qz * qz);   // |location - origin| (mesh_utils.py:371)
-            int j = k - 1;                                           // stable insertion: lexsort((depth, ray))
-            while (j >= 0 && dep[j] > dk) { dep[j + 1] = dep[j]; order[j + 1] = order[j]; --j; }
-            dep[j + 1] = dk;
-            order[j + 1] = k;
-        }
-        const int64_t base = ray_offset[r];
-        for (int k = 0; k < cnt; ++k) {
-            const int src = order[k];
-            const double t = (double)hit_t[r * max_hits + src];
-            const int64_t o = base + k;
-            xyz[o * 3 + 0] = (float)(o64[0] + t * d64[0]);
-            xyz[o * 3 + 1] = (float)(o64[1] + t * d64[1]);
-            xyz[o * 3 + 2] = (float)(o64[2] + t * d64[2]);
-            dirs[o * 3 + 0] = ux;
-            dirs[o * 3 + 1] = uy;
-            dirs[o * 3 + 2] = uz;
-            origins[o * 3 + 0] = ox;
-            origins[o * 3 + 1] = oy;
-            origins[o * 3 + 2] = oz;
-            index_ray[o] = r;
-            depth[o] = (float)dep[k];
-            index_tri[o] = (int64_t)hit_tri[r * max_hits + src];
-        }
+        double p[3];
+        const double dep = sample_depth64(s_t[rl * Kp + k], o64, d64, p);
+        // vectors / (|vectors| + 1e-7) in float32 (mesh_utils.py:369-370)
+        const float nrm = sqrtf((dx * dx + dy * dy) + dz * dz) + 1e-7f;
+        const int64_t o = block_base + j;
+        xyz[o * 3 + 0] = (float)p[0];
+        xyz[o * 3 + 1] = (float)p[1];
+        xyz[o * 3 + 2] = (float)p[2];
+        dirs[o * 3 + 0] = dx / nrm;
+        dirs[o * 3 + 1] = dy / nrm;
+        dirs[o * 3 + 2] = dz / nrm;
+        origins[o * 3 + 0] = ox;
+        origins[o * 3 + 1] = oy;
+        origins[o * 3 + 2] = oz;
+        index_ray[o] = ray;
+        depth[o] = (float)dep;
+        index_tri[o] = (int64_t)s_tri[rl * Kp + k];
     }
 }
 
@@ -524,8 +591,14 @@ extern "C" int qf_pack_samples(const float *rays_o, const float *rays_d, int64_t
     if (n_rays < 0 || max_hits < 1 || max_hits > kMaxHits) return QF_ERR_INVALID_ARGUMENT;
     if (n_rays == 0) return QF_OK;
     if (!rays_o || !rays_d || !hit_tri || !hit_t || !hit_count || !ray_offset) return QF_ERR_INVALID_ARGUMENT;
-    QF_SIMPLE_LAUNCH(pack_samples_kernel, n_rays, rays_o, rays_d, n_rays, (int)max_hits, hit_tri, hit_t, hit_count,
-                     ray_offset, xyz, dirs, index_ray, depth, index_tri, origins);
+    const int Kp = max_hits | 1;
+    const size_t lds = (size_t)kPackRays * Kp * 8 + (size_t)kPackRays * max_hits * 2 + 64;
+    const int64_t blocks = qf_div_up(n_rays, kPackRays);
+    if (blocks > 0x7fffffff) return QF_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(pack_samples_kernel, dim3((unsigned)blocks), dim3(kPackRays), lds, qf_stream(stream), rays_o, rays_d,
+                       n_rays, (int)max_hits, hit_tri, hit_t, hit_count, ray_offset, xyz, dirs, index_ray, depth, index_tri,
+                       origins);
+    QF_LAUNCH_CHECK();
     return QF_OK;
 }
 
@@ -575,7 +648,7 @@ extern "C" int qf_texture_shade(const qf_texture_set *tex, const int64_t *texel,
 
 extern "C" int qf_raster_intersect(const qf_bvh *bvh, const qf_camera *cam, const float *rays_o, const float *rays_d,
                                    int64_t n_rays, int32_t max_hits, int32_t *hit_tri, float *hit_t, int32_t *hit_count,
-                                   int32_t *overflow, void *stream)
+                                   int32_t *overflow, int32_t sort_lists, void *stream)
 {
     if (!bvh || !cam || n_rays < 0 || max_hits < 1 || max_hits > kMaxHits) return QF_ERR_INVALID_ARGUMENT;
     if (cam->width < 1 || cam->height < 1 || (int64_t)cam->width * cam->height != n_rays) return QF_ERR_INVALID_ARGUMENT;
@@ -602,8 +675,10 @@ extern "C" int qf_raster_intersect(const qf_bvh *bvh, const qf_camera *cam, cons
                            hit_tri, hit_t, hit_count, overflow);
         QF_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(sort_hits_kernel, dim3(qf_grid_1d(n_rays, 256)), dim3(256), 0, st, n_rays, (int)max_hits, hit_tri,
-                       hit_t, hit_count);
-    QF_LAUNCH_CHECK();
+    if (sort_lists) {
+        hipLaunchKernelGGL(sort_hits_kernel, dim3(qf_grid_1d(n_rays, 256)), dim3(256), 0, st, n_rays, (int)max_hits,
+                           hit_tri, hit_t, hit_count);
+        QF_LAUNCH_CHECK();
+    }
     return QF_OK;
 }

@@ -89,14 +89,15 @@ class RayIntersector:
                  "qf_bvh_intersect")
         return hit_tri, hit_t, hit_count
 
-    def _hits_raster(self, o, d, k, camera):
-        """Camera-coherent path; returns the lists plus the device overflow counter (unchecked)."""
+    def _hits_raster(self, o, d, k, camera, sort_lists=True):
+        """Camera-coherent path; returns the lists plus the device overflow counter (unchecked).
+        sort_lists=False leaves the lists in arrival order for qf_pack_samples (which sorts while packing)."""
         n = o.shape[0]
         hit_tri, hit_t, hit_count = self._alloc_hits(n, k)
         overflow = torch.empty((1,), dtype=torch.int32, device=self.device)
         _C.check(_C.lib().qf_raster_intersect(self._handle, ctypes.byref(camera), _C.ptr(o), _C.ptr(d), n, k,
                                               _C.ptr(hit_tri), _C.ptr(hit_t), _C.ptr(hit_count), _C.ptr(overflow),
-                                              _C.stream()), "qf_raster_intersect")
+                                              1 if sort_lists else 0, _C.stream()), "qf_raster_intersect")
         return hit_tri, hit_t, hit_count, overflow
 
     def hits(self, origins, vectors, max_hits: Optional[int] = None, image_width: int = 0, camera=None):
@@ -133,7 +134,7 @@ class RayIntersector:
         if n == 0:
             return None
         if camera is not None:
-            hit_tri, hit_t, hit_count, overflow = self._hits_raster(o, d, k, camera)
+            hit_tri, hit_t, hit_count, overflow = self._hits_raster(o, d, k, camera, sort_lists=False)
         else:
             hit_tri, hit_t, hit_count = self._hits_bvh(o, d, k, image_width)
             overflow = None
