@@ -212,6 +212,15 @@ def main():
     if rank != 0:
         return
     ms = stages.stage_ms()
+    # HBM-side bytes of the dominant kernel come from PMC counters (separate rocprofv3 --pmc passes over this same
+    # command, see profiles/r1/README.md); bench.py cannot sample them itself, so the committed measurement is scaled
+    # to this run's points per launch.
+    traffic = traffic_src = None
+    tpath = os.path.join(ROOT, "profiles", "r1", "field_traffic.json")
+    if os.path.exists(tpath):
+        tj = json.load(open(tpath))
+        traffic_src = "profiles/r1/field_traffic.json (FETCH_SIZE + WRITE_SIZE, bytes per point x points per launch)"
+        traffic = (tj["fetch_bytes_per_launch"] + tj["write_bytes_per_launch"]) / tj["points_per_launch"]
     rays_total = W * H * args.steps * world
     pts_per_launch = pts / args.steps
     field_s = (ms["field"] or 0.0) * 1e-3
@@ -242,7 +251,9 @@ def main():
         "stage_ms": ms,
         "roofline": {
             "kernel": "field_kernel<NGP> (hash-grid gather + MLPs)", "bound": "hbm", "achieved": achieved,
-            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": None if traffic is None else traffic * pts_per_launch, "traffic_unit": "bytes per launch",
+            "traffic_source": traffic_src,
             "algorithmic_bytes_per_point": ALG_BYTES_PER_POINT, "points_per_launch": pts_per_launch,
             "avg_launch_ms": ms["field"],
         },

@@ -236,20 +236,17 @@ __global__ __launch_bounds__(kBlock, 4) void field_kernel(const FieldArgs a)
         if (tid < 64) bias_lds[tid] = a.sg.b2[tid];
         else if (tid < 128) bias_lds[tid] = (tid - 64 < a.n_out) ? a.sg.bout[tid - 64] : 0.0f;
     }
+    // level table (8 words per level) behind the biases: re-read from LDS every pass instead of pinning 20 VGPRs
+    uint32_t *lvl_lds = reinterpret_cast<uint32_t *>(bias_lds + 128);
+    if (tid < QF_MAX_LEVELS) {
+        lvl_lds[tid * 8 + 0] = a.grid.offset[tid];
+        lvl_lds[tid * 8 + 1] = a.grid.rows[tid];
+        lvl_lds[tid * 8 + 2] = a.grid.res[tid];
+        lvl_lds[tid * 8 + 3] = (a.grid.hashed_mask >> tid) & 1u;
+        lvl_lds[tid * 8 + 4] = __float_as_uint(a.grid.scale[tid]);
+    }
     __syncthreads();
     const f32x4 *img_base = reinterpret_cast<const f32x4 *>(lds);   // img_base[(m>>2)*64 + lane]
-
-    // ---- per-lane constants: the four levels this lane quartet owns
-    LevelConst lc[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int level = 4 * j + g;
-        lc[j].offset = a.grid.offset[level];
-        lc[j].rows = a.grid.rows[level];
-        lc[j].res = a.grid.res[level];
-        lc[j].scale = a.grid.scale[level];
-        lc[j].hashed = (a.grid.hashed_mask >> level) & 1u;
-    }
 
     const int64_t n_groups = (a.n + 15) >> 4;
     const int64_t wave_global = (int64_t)blockIdx.x * (kBlock / 64) + (tid >> 6);
@@ -269,24 +266,31 @@ __global__ __launch_bounds__(kBlock, 4) void field_kernel(const FieldArgs a)
         const bool selector = x01 > 0.0f && x01 < 1.0f && y01 > 0.0f && y01 < 1.0f && z01 > 0.0f && z01 < 1.0f;
 
         // ---- hash grid: issue all 32 gathers, then blend
+        // LDS contents are loop-invariant; opaque offsets keep the compiler from hoisting the level table and
+        // all 160 weight operand registers out of the point loop
+        int loff = lane, goff = g * 8;
+        asm volatile("" : "+v"(loff), "+v"(goff));
+        const f32x4 *img = img_base + loff;
+
         float frac[4][3];
         float2 val[4][8];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
+            const uint32_t *lv = lvl_lds + 32 * j + goff;     // level 4j + g
+            LevelConst lc;
+            lc.offset = lv[0];
+            lc.rows = lv[1];
+            lc.res = lv[2];
+            lc.hashed = lv[3];
+            lc.scale = __uint_as_float(lv[4]);
             uint32_t idx[8];
-            level_indices(lc[j], x01, y01, z01, idx, frac[j]);
+            level_indices(lc, x01, y01, z01, idx, frac[j]);
 #pragma unroll
             for (int c = 0; c < 8; ++c) val[j][c] = a.table[idx[c]];
         }
         float feat[8];
 #pragma unroll
         for (int j = 0; j < 4; ++j) level_blend(val[j], frac[j], &feat[2 * j], &feat[2 * j + 1]);
-
-        // weights are loop-invariant in LDS; an opaque lane offset keeps the compiler from hoisting
-        // all 160 operand registers out of the point loop
-        int loff = lane;
-        asm volatile("" : "+v"(loff));
-        const f32x4 *img = img_base + loff;
 
         // ---- base MLP 32 -> 64 (ReLU) -> 16
         f32x4 h[4];
@@ -656,7 +660,7 @@ int launch_field(const FieldArgs &a, hipStream_t st)
     int n_m = kBaseMfma;
     if (HEAD == QF_HEAD_NGP) n_m += kNgpHeadMfma;
     if (HEAD == QF_HEAD_SG || HEAD == QF_HEAD_SG_FEATURES) n_m += kSgHeadMfmaFixed + 16 * a.nt_out;
-    const size_t lds_bytes = (size_t)(n_m * 64 + 128) * sizeof(float);
+    const size_t lds_bytes = (size_t)(n_m * 64 + 128 + 8 * QF_MAX_LEVELS) * sizeof(float);
     const int64_t n_groups = (a.n + 15) / 16;
     int64_t blocks = qf_div_up(n_groups, kBlock / 64);
     const int64_t cap = (int64_t)qf_cu_count_cached() * 2;

@@ -15,7 +15,7 @@ import bench
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=10)
-    ap.add_argument("--order", default="ray", choices=["ray", "tile", "tile4", "random"])
+    ap.add_argument("--order", default="coherent", choices=["ray", "tile", "tile4", "random", "coherent"])
     ap.add_argument("--stage", default="field", choices=["field", "traverse", "raster", "pack", "composite", "frame"])
     args = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -31,7 +31,11 @@ def main():
     xyz, dirs, index_ray, ts, index_tri, org = data
     n = xyz.shape[0]
     order = None
-    if args.order != "ray":
+    if args.order == "coherent":
+        hc = hits[2]
+        cs = torch.cumsum(hc.to(torch.int64), 0)
+        order = ri.coherent_order(hc, (cs - hc).contiguous(), int(cs[-1]), bench.W)
+    elif args.order != "ray":
         ray = index_ray
         first = torch.zeros(o.shape[0] + 1, dtype=torch.int64, device=dev)
         first[1:] = torch.cumsum(torch.bincount(ray, minlength=o.shape[0]), 0)
