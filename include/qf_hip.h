@@ -104,6 +104,22 @@ int qf_field_forward(const qf_field_desc *desc /* host */, const float *table,
                      const float *xyz, const float *dirs, int64_t n, const int32_t *order,
                      float *rgb, float *sigma, float *geo, float *features, void *stream);
 
+/* bf16 variant (BASELINE config 3): hash tables as bf16x2 rows, MLP weights as bf16 (round-to-nearest-even copies of
+ * the fp32 parameters, same layouts), activations rounded to bf16 between layers, fp32 accumulate on
+ * v_mfma_f32_16x16x32_bf16.  tcnn itself runs these networks in fp16 (ngp.py:340-358), so this is the reduced
+ * precision mode of the same calls.  Heads: QF_HEAD_NONE, QF_HEAD_NGP, QF_HEAD_SG.  SG biases b2 / bout stay fp32
+ * (they initialise the accumulator); b1 rides in the first weight tile and is bf16.                              */
+typedef struct qf_sg_head_bf16 {
+    const uint16_t *w1, *b1, *w2;
+    const float *b2;
+    const uint16_t *wout;
+    const float *bout;
+} qf_sg_head_bf16;
+int qf_field_forward_bf16(const qf_field_desc *desc /* host */, const uint16_t *table /* [rows,2] bf16 */,
+                          const uint16_t *base_w, const uint16_t *head_ngp_w,
+                          const qf_sg_head_bf16 *head_sg /* host */, const float *xyz, const float *dirs,
+                          int64_t n, const int32_t *order, float *rgb, float *sigma, float *geo, void *stream);
+
 /* rgb = sigmoid(diffuse + sum_l c_l exp(|lambda_l| (a_l/|a_l| . d - 1))).
  * Replaces NGPRadianceFieldSGNew.features_to_rgb (ngp.py:456-461, discretize=False).
  * features [n, 3+7L] (row stride `feat_stride` floats), dirs [n,3] -> rgb [n,3].              */

@@ -263,3 +263,42 @@ def field_per_level_scale(max_res: int, scale: float, n_min: int, n_levels: int)
 def ngp_per_level_scale(max_resolution: int, base_resolution: int, n_levels: int) -> float:
     """ngp.py:320-322 / 689-691."""
     return float(np.exp((np.log(max_resolution) - np.log(base_resolution)) / (n_levels - 1)))
+
+
+# ---------------------------------------------------------------------------- bf16 mode (BASELINE config 3)
+def bf16_round(t: Tensor) -> Tensor:
+    """Round-to-nearest-even to bfloat16, returned as fp32 (what an fp32-accumulating bf16 MFMA consumes)."""
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def _mlp_nobias_bf16(x: Tensor, weights: List[Tensor]) -> Tensor:
+    h = x
+    for w in weights[:-1]:
+        h = F.relu(F.linear(bf16_round(h), bf16_round(w)))
+    return F.linear(bf16_round(h), bf16_round(weights[-1]))
+
+
+def query_density_bf16(x: Tensor, wts: NGPWeights):
+    """query_density with bf16 table / weights / inter-layer activations and fp32 accumulation."""
+    selector, x01 = normalize_to_aabb(x, wts.aabb)
+    enc = hash_encode(x01.reshape(-1, 3), bf16_round(wts.table), wts.levels)      # blend in fp32
+    out = _mlp_nobias_bf16(enc, wts.base)
+    raw, feat = out[:, :1], out[:, 1:16]
+    return torch.exp(raw - 1.0) * selector[:, None], feat
+
+
+def ngp_forward_bf16(x: Tensor, d: Tensor, wts: NGPWeights):
+    density, feat = query_density_bf16(x, wts)
+    sh = sh4(((d + 1.0) / 2.0) * 2.0 - 1.0)
+    h = torch.cat([sh, feat, torch.ones_like(feat[:, :1])], dim=-1)
+    return torch.sigmoid(_mlp_nobias_bf16(h, wts.head_tcnn)[:, :3]), density
+
+
+def sg_forward_bf16(x: Tensor, d: Tensor, wts: NGPWeights):
+    """SG head in bf16: w1/b1/w2/wout and the layer inputs are bf16, b2/bout stay fp32 (accumulator init)."""
+    density, feat = query_density_bf16(x, wts)
+    (w1, b1), (w2, b2), (wo, bo) = wts.head_layers
+    h = F.relu(F.linear(bf16_round(feat), bf16_round(w1), bf16_round(b1)))
+    h = F.relu(F.linear(bf16_round(h), bf16_round(w2), b2))
+    f = F.linear(bf16_round(h), bf16_round(wo), bo)
+    return features_to_rgb(f, d, wts.n_lobes), density

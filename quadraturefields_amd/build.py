@@ -19,6 +19,7 @@ ARCH = "gfx950"
 # (source, extra flags).  exact.hip carries every integer-deciding comparison: no FMA contraction.
 SOURCES = [
     ("field_eval.hip", []),
+    ("field_eval_bf16.hip", []),
     ("composite.hip", []),
     ("exact.hip", ["-ffp-contract=off"]),
     ("bvh_build.cpp", ["-x", "hip"]),

@@ -157,6 +157,26 @@ class _FusedFieldBase(nn.Module):
         d.head, d.n_lobes = head, n_lobes
         return d
 
+    #: "fp32" (default; parity with the fp32 oracle to ~1e-6) or "bf16" (bf16 tables + MLPs, fp32 accumulate --
+    #: BASELINE config 3; tcnn runs the same networks in fp16).  ``features()`` always evaluates in fp32.
+    compute_dtype = "fp32"
+
+    def _bf16_copies(self, head_ngp, head_sg):
+        """Round-to-nearest-even bf16 copies of the fp32 master parameters, refreshed when a parameter changes."""
+        params = [self.mlp_base.params] + ([head_ngp] if head_ngp is not None else []) + list(head_sg or [])
+        key = tuple((t.data_ptr(), t._version) for t in params)
+        cache = getattr(self, "_bf16_cache", None)
+        if cache is None or cache[0] != key:
+            bf = lambda t: t.detach().to(torch.bfloat16).contiguous()
+            c = {"base": bf(self.mlp_base.network_params()), "table": bf(self.mlp_base.grid_params())}
+            if head_ngp is not None:
+                c["head"] = bf(head_ngp)
+            if head_sg is not None:
+                c["sg"] = [bf(head_sg[0]), bf(head_sg[1]), bf(head_sg[2]), bf(head_sg[4])]
+            cache = (key, c)
+            self._bf16_cache = cache
+        return cache[1]
+
     def normalize(self, x):
         """(selector, x01) -- ngp.py:748-755; elementwise, kept in torch."""
         aabb_min, aabb_max = torch.split(self.aabb, self.num_dim, dim=-1)
@@ -179,6 +199,16 @@ class _FusedFieldBase(nn.Module):
         feats = torch.empty((n, want_features), dtype=torch.float32, device=dev) if want_features else None
         desc = self._field_desc(head, n_lobes)
         sg = None
+        if self.compute_dtype == "bf16" and head in (_C.HEAD_NONE, _C.HEAD_NGP, _C.HEAD_SG):
+            c = self._bf16_copies(head_ngp, head_sg)
+            if head_sg is not None:   # w1, b1, w2 bf16 | b2 fp32 | wout bf16 | bout fp32
+                sg = _C.SGHead(_C.ptr(c["sg"][0]), _C.ptr(c["sg"][1]), _C.ptr(c["sg"][2]), _C.ptr(head_sg[3]),
+                               _C.ptr(c["sg"][3]), _C.ptr(head_sg[5]))
+            _C.check(_C.lib().qf_field_forward_bf16(
+                ctypes.byref(desc), _C.ptr(c["table"]), _C.ptr(c["base"]), _C.ptr(c.get("head")),
+                ctypes.byref(sg) if sg is not None else None, _C.ptr(xyz), _C.ptr(dirs), n,
+                _C.ptr(order, torch.int32), _C.ptr(rgb), _C.ptr(sigma), _C.ptr(geo), _C.stream()), "qf_field_forward_bf16")
+            return rgb, sigma, geo, feats
         if head_sg is not None:
             sg = _C.SGHead(*[_C.ptr(t) for t in head_sg])
         _C.check(_C.lib().qf_field_forward(

@@ -151,3 +151,46 @@ def test_errors(device):
         f(torch.zeros(4, 3, device=device), torch.zeros(5, 3, device=device))
     rgb, den = f(torch.zeros(0, 3, device=device), torch.zeros(0, 3, device=device))
     assert rgb.shape == (0, 3) and den.shape == (0, 1)
+
+
+@pytest.mark.parametrize("n", [1, 17, 5000])
+def test_bf16_ngp_matches_bf16_oracle(device, n):
+    """BASELINE config 3 (bf16 tables + MLPs, fp32 accumulate on v_mfma_f32_16x16x32_bf16).  The oracle rounds the
+    same quantities to bf16 at the same places, so the two differ only by fp32 summation order -- except where a
+    value sits on a bf16 rounding boundary and the 1-ulp-of-fp32 difference flips it (one bf16 step = 2^-8 relative).
+    Stated tolerance: 2e-3 + 2e-3*|x| on rgb / features, 1e-2 relative on densities; fp32-vs-bf16 itself is ~1e-2."""
+    from quadraturefields_amd.radiance_fields.ngp import NGPRadianceField
+    f = _make(NGPRadianceField, device, log2_T=14)
+    f.compute_dtype = "bf16"
+    x, d = helpers.random_points(n, seed=n + 100)
+    w = helpers.oracle_ngp_weights(f)
+    rgb_o, den_o = ofields.ngp_forward_bf16(x, d, w)
+    rgb, den = f(x.to(device), d.to(device))
+    _close(rgb, rgb_o, 2e-3, 2e-3)
+    _close(den, den_o, 1e-6, 1e-2)
+    den2, feat = f.query_density(x.to(device), return_feat=True)
+    _close(feat, ofields.query_density_bf16(x, w)[1], 2e-3, 2e-3)
+    assert torch.equal(den2, den)
+    # and it is close to (but not the same as) the fp32 evaluation
+    f.compute_dtype = "fp32"
+    rgb32, _ = f(x.to(device), d.to(device))
+    assert float((rgb32 - rgb).abs().max()) < 0.08
+    if n > 100:
+        assert float((rgb32 - rgb).abs().max()) > 1e-5
+
+
+@pytest.mark.parametrize("lobes", [3, 6])
+def test_bf16_sg_matches_bf16_oracle(device, lobes):
+    from quadraturefields_amd.radiance_fields.ngp import NGPRadianceFieldSGNew
+    f = _make(NGPRadianceFieldSGNew, device, log2_T=14, use_viewdirs=False, num_g_lobes=lobes)
+    f.compute_dtype = "bf16"
+    x, d = helpers.random_points(3000, seed=lobes + 50)
+    w = helpers.oracle_ngp_weights(f)
+    rgb_o, den_o = ofields.sg_forward_bf16(x, d, w)
+    rgb, den = f(x.to(device), d.to(device))
+    _close(den, den_o, 1e-6, 1e-2)
+    _close(rgb, rgb_o, 5e-3, 5e-3)
+    # order does not change bf16 results either
+    order = torch.randperm(3000, device=device).to(torch.int32)
+    rgb2, den2 = f(x.to(device), d.to(device), order=order)
+    assert torch.equal(rgb, rgb2) and torch.equal(den, den2)

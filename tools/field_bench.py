@@ -15,6 +15,7 @@ import bench
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"])
     ap.add_argument("--order", default="coherent", choices=["ray", "tile", "tile4", "random", "coherent"])
     ap.add_argument("--stage", default="field", choices=["field", "traverse", "raster", "pack", "composite", "frame"])
     args = ap.parse_args()
@@ -22,6 +23,7 @@ def main():
     from quadraturefields_amd import synthetic
     mesh, mi, field = bench.build_scene(dev)
     o, d = synthetic.camera_rays(synthetic.orbit_cameras(1, seed=42)[0], synthetic.lego_focal(bench.W), bench.W, bench.H, device=dev)
+    field.compute_dtype = args.dtype
     st = bench.Stages(mi, field)
     from quadraturefields_amd.mesh_utils import make_camera
     cam = make_camera(synthetic.orbit_cameras(1, seed=42)[0], synthetic.lego_focal(bench.W), bench.W, bench.H)
