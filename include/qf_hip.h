@@ -237,6 +237,15 @@ int qf_raster_intersect(const qf_bvh *bvh, const qf_camera *cam /* host */, cons
                         const float *rays_d, int64_t n_rays, int32_t max_hits, int32_t *hit_tri, float *hit_t,
                         int32_t *hit_count, int32_t *overflow, int32_t sort_lists, void *stream);
 
+/* Full-image rays of a pinhole camera, row-major [H*W,3] origins and unit viewdirs, with the arithmetic of
+ * SubjectLoader.fetch_data (datasets/nerf_synthetic.py:341-373).  opengl != 0: -y / -z camera axes (the
+ * reference's NeRF-synthetic loader).                                                                            */
+int qf_generate_rays(const qf_camera *cam /* host */, int32_t opengl, float *origins, float *viewdirs, void *stream);
+
+/* out[index[i]] = max(out[index[i]], values[i]) for i < n; `out` [n_out] is read-modify-written (initialise it).
+ * torch_scatter.scatter_max as used for triangle pruning (prune_mesh_after_finetuning.py:355-357).              */
+int qf_scatter_max(const float *values, const int64_t *index, int64_t n, int64_t n_out, float *out, void *stream);
+
 /* Packs the per-ray hit lists into the sample arrays sampling_raytrace_numpy returns
  * (mesh_utils.py:359-387), already sorted by (ray, depth): location = o + t d in float64,
  * dirs = d/(|d|+1e-7), depth = |location - o| (float64, rounded to fp32 at the end).

@@ -376,3 +376,70 @@ extern "C" int qf_coherent_order(const int32_t *hit_count, const int64_t *ray_of
     QF_LAUNCH_CHECK();
     return QF_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// Callers on either side of the path.
+namespace {
+
+// Full-image rays, SubjectLoader.fetch_data (datasets/nerf_synthetic.py:341-373): pixel centres, OpenGL axes
+// (-y, -z), directions = sum_j camera_dir[j] * c2w[i][j], viewdirs = directions / |directions|.
+__global__ void generate_rays_kernel(qf_camera cam, int opengl, float *origins, float *viewdirs)
+{
+#pragma clang fp contract(off)   // individually rounded products and sums, as torch evaluates them
+    const int64_t n = (int64_t)cam.width * cam.height;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % cam.width), y = (int)(i / cam.width);
+        const float sgn = opengl ? -1.0f : 1.0f;
+        const float cdx = ((float)x - cam.cx + 0.5f) / cam.fx;
+        const float cdy = ((float)y - cam.cy + 0.5f) / cam.fy * sgn;
+        const float cdz = sgn;
+        float d[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) d[k] = (cdx * cam.c2w[4 * k + 0] + cdy * cam.c2w[4 * k + 1]) + cdz * cam.c2w[4 * k + 2];
+        const float nrm = sqrtf((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            origins[i * 3 + k] = cam.c2w[4 * k + 3];
+            viewdirs[i * 3 + k] = d[k] / nrm;
+        }
+    }
+}
+
+// out[index[i]] = max(out[index[i]], values[i]) -- torch_scatter.scatter_max as used for triangle pruning
+// (prune_mesh_after_finetuning.py:355-357).  Float max through integer atomics on the IEEE bit pattern.
+__global__ void scatter_max_kernel(const float *values, const int64_t *index, int64_t n, int64_t n_out, float *out)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t j = index[i];
+        if (j < 0 || j >= n_out) continue;
+        const float v = values[i];
+        if (v != v) continue;
+        if (v >= 0.0f) atomicMax(reinterpret_cast<int *>(out + j), __float_as_int(v));
+        else atomicMin(reinterpret_cast<unsigned int *>(out + j), __float_as_uint(v));
+    }
+}
+
+}  // namespace
+
+extern "C" int qf_generate_rays(const qf_camera *cam, int32_t opengl, float *origins, float *viewdirs, void *stream)
+{
+    if (!cam || cam->width < 1 || cam->height < 1 || !(cam->fx > 0.0f) || !(cam->fy > 0.0f) || !origins || !viewdirs)
+        return QF_ERR_INVALID_ARGUMENT;
+    const int64_t n = (int64_t)cam->width * cam->height;
+    hipLaunchKernelGGL(generate_rays_kernel, dim3(qf_grid_1d(n, 256)), dim3(256), 0, qf_stream(stream), *cam,
+                       (int)opengl, origins, viewdirs);
+    QF_LAUNCH_CHECK();
+    return QF_OK;
+}
+
+extern "C" int qf_scatter_max(const float *values, const int64_t *index, int64_t n, int64_t n_out, float *out,
+                              void *stream)
+{
+    if (n < 0 || n_out < 0) return QF_ERR_INVALID_ARGUMENT;
+    if (n == 0) return QF_OK;
+    if (!values || !index || !out) return QF_ERR_INVALID_ARGUMENT;
+    hipLaunchKernelGGL(scatter_max_kernel, dim3(qf_grid_1d(n, 256)), dim3(256), 0, qf_stream(stream), values, index, n,
+                       n_out, out);
+    QF_LAUNCH_CHECK();
+    return QF_OK;
+}
