@@ -237,6 +237,20 @@ int qf_raster_intersect(const qf_bvh *bvh, const qf_camera *cam /* host */, cons
                         const float *rays_d, int64_t n_rays, int32_t max_hits, int32_t *hit_tri, float *hit_t,
                         int32_t *hit_count, int32_t *overflow, int32_t sort_lists, void *stream);
 
+/* Occupancy-grid ray marching: nerfacc 0.5.3 OccGridEstimator.sampling -> traverse_grids for one grid level and
+ * cone_angle = 0 (examples/utils.py:137-147,266-285).  Samples are [t0 + k*step, t0 + (k+1)*step],
+ * t0 = the ray's entry into `aabb` clipped to [near_plane (or t_min[r]), far_plane (or t_max[r])], kept iff the
+ * sample's midpoint lies before the exit and inside an occupied cell of `binaries` [rx,ry,rz] (bool bytes, x-major).
+ * Two passes around the caller's exclusive scan: _count fills count[n_rays]; _write fills t_starts / t_ends /
+ * ray_indices at offsets[r].  aabb (6 floats) and resolution (3 ints) are HOST pointers; t_min / t_max may be NULL. */
+int qf_grid_march_count(const float *aabb, const int32_t *resolution, const uint8_t *binaries,
+                        const float *rays_o, const float *rays_d, const float *t_min, const float *t_max,
+                        int64_t n_rays, float near_plane, float far_plane, float step, int32_t *count, void *stream);
+int qf_grid_march_write(const float *aabb, const int32_t *resolution, const uint8_t *binaries,
+                        const float *rays_o, const float *rays_d, const float *t_min, const float *t_max,
+                        int64_t n_rays, float near_plane, float far_plane, float step, const int64_t *offsets,
+                        float *t_starts, float *t_ends, int64_t *ray_indices, void *stream);
+
 /* Full-image rays of a pinhole camera, row-major [H*W,3] origins and unit viewdirs, with the arithmetic of
  * SubjectLoader.fetch_data (datasets/nerf_synthetic.py:341-373).  opengl != 0: -y / -z camera axes (the
  * reference's NeRF-synthetic loader).                                                                            */

@@ -682,3 +682,130 @@ extern "C" int qf_raster_intersect(const qf_bvh *bvh, const qf_camera *cam, cons
     }
     return QF_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// Occupancy-grid ray marching (nerfacc 0.5.3 OccGridEstimator.sampling -> traverse_grids, one
+// level, cone_angle = 0).  nerfacc walks the cells with a DDA but keeps the step phase through empty cells, so its
+// samples are [t0 + k dt, t0 + (k+1) dt] with t0 the clipped aabb entry, kept iff the sample's MIDPOINT lies before
+// the aabb exit and in an occupied cell.  That rule is evaluated directly here (one byte of grid per step, the
+// 2 MiB grid is L2 resident), with every operation individually rounded so the oracle reproduces counts exactly.
+namespace {
+
+struct MarchArgs {
+    float lo[3], hi[3];
+    int res[3];
+    float near_plane, far_plane, step;
+};
+
+__device__ __forceinline__ bool march_range(const MarchArgs &m, const float *o, const float *d, float t_near_ray,
+                                            float t_far_ray, float *t0, float *t1)
+{
+    float tn = -INFINITY, tf = INFINITY;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float inv = safe_inv(d[k]);
+        const float a = (m.lo[k] - o[k]) * inv, b = (m.hi[k] - o[k]) * inv;
+        tn = fmaxf(tn, fminf(a, b));
+        tf = fminf(tf, fmaxf(a, b));
+    }
+    *t0 = fmaxf(tn, t_near_ray);
+    *t1 = fminf(tf, t_far_ray);
+    return tn <= tf && *t0 < *t1;
+}
+
+__device__ __forceinline__ bool march_occupied(const MarchArgs &m, const uint8_t *binaries, const float *o,
+                                               const float *d, float tm)
+{
+    int c[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float p = o[k] + d[k] * tm;
+        const float u = (p - m.lo[k]) / (m.hi[k] - m.lo[k]) * (float)m.res[k];
+        const float f = floorf(u);
+        if (!(f >= 0.0f && f < (float)m.res[k])) return false;
+        c[k] = (int)f;
+    }
+    return binaries[((int64_t)c[0] * m.res[1] + c[1]) * m.res[2] + c[2]] != 0;
+}
+
+// count != nullptr: pass 1 (count per ray); else pass 2 (write at offsets)
+__global__ void grid_march_kernel(MarchArgs m, const uint8_t *binaries, const float *rays_o, const float *rays_d,
+                                  const float *t_min, const float *t_max, int64_t n_rays, int32_t *count,
+                                  const int64_t *offsets, float *t_starts, float *t_ends, int64_t *ray_indices)
+{
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_rays; r += (int64_t)gridDim.x * blockDim.x) {
+        const float o[3] = {rays_o[r * 3], rays_o[r * 3 + 1], rays_o[r * 3 + 2]};
+        const float d[3] = {rays_d[r * 3], rays_d[r * 3 + 1], rays_d[r * 3 + 2]};
+        const float near_r = t_min ? fmaxf(m.near_plane, t_min[r]) : m.near_plane;
+        const float far_r = t_max ? fminf(m.far_plane, t_max[r]) : m.far_plane;
+        float t0, t1;
+        int n = 0;
+        int64_t w = count ? 0 : offsets[r];
+        if (march_range(m, o, d, near_r, far_r, &t0, &t1)) {
+            for (int k = 0; k < (1 << 22); ++k) {      // hard cap: a degenerate ray can never spin
+                const float ts = t0 + (float)k * m.step;
+                const float te = t0 + (float)(k + 1) * m.step;
+                const float tm = (ts + te) * 0.5f;
+                if (!(tm < t1)) break;
+                if (!march_occupied(m, binaries, o, d, tm)) continue;
+                if (!count) { t_starts[w] = ts; t_ends[w] = te; ray_indices[w] = r; ++w; }
+                ++n;
+            }
+        }
+        if (count) count[r] = n;
+    }
+}
+
+int fill_march_args(const float *aabb, const int32_t *res, float near_plane, float far_plane, float step, MarchArgs *m)
+{
+    if (!aabb || !res || !(step > 0.0f) || !(far_plane > near_plane)) return QF_ERR_INVALID_ARGUMENT;
+    for (int k = 0; k < 3; ++k) {
+        m->lo[k] = aabb[k];
+        m->hi[k] = aabb[3 + k];
+        m->res[k] = res[k];
+        if (!(aabb[3 + k] > aabb[k]) || res[k] < 1) return QF_ERR_INVALID_ARGUMENT;
+        // bound the per-ray step count so the march loop always terminates quickly
+        if ((aabb[3 + k] - aabb[k]) / step > 1.0e7f) return QF_ERR_UNSUPPORTED;
+    }
+    m->near_plane = near_plane;
+    m->far_plane = far_plane;
+    m->step = step;
+    return QF_OK;
+}
+
+}  // namespace
+
+extern "C" int qf_grid_march_count(const float *aabb, const int32_t *resolution, const uint8_t *binaries,
+                                   const float *rays_o, const float *rays_d, const float *t_min, const float *t_max,
+                                   int64_t n_rays, float near_plane, float far_plane, float step, int32_t *count,
+                                   void *stream)
+{
+    MarchArgs m;
+    int rc = fill_march_args(aabb, resolution, near_plane, far_plane, step, &m);
+    if (rc != QF_OK) return rc;
+    if (n_rays < 0) return QF_ERR_INVALID_ARGUMENT;
+    if (n_rays == 0) return QF_OK;
+    if (!binaries || !rays_o || !rays_d || !count) return QF_ERR_INVALID_ARGUMENT;
+    hipLaunchKernelGGL(grid_march_kernel, dim3(qf_grid_1d(n_rays, 64, 64)), dim3(64), 0, qf_stream(stream), m, binaries,
+                       rays_o, rays_d, t_min, t_max, n_rays, count, (const int64_t *)nullptr, (float *)nullptr,
+                       (float *)nullptr, (int64_t *)nullptr);
+    QF_LAUNCH_CHECK();
+    return QF_OK;
+}
+
+extern "C" int qf_grid_march_write(const float *aabb, const int32_t *resolution, const uint8_t *binaries,
+                                   const float *rays_o, const float *rays_d, const float *t_min, const float *t_max,
+                                   int64_t n_rays, float near_plane, float far_plane, float step, const int64_t *offsets,
+                                   float *t_starts, float *t_ends, int64_t *ray_indices, void *stream)
+{
+    MarchArgs m;
+    int rc = fill_march_args(aabb, resolution, near_plane, far_plane, step, &m);
+    if (rc != QF_OK) return rc;
+    if (n_rays < 0) return QF_ERR_INVALID_ARGUMENT;
+    if (n_rays == 0) return QF_OK;
+    if (!binaries || !rays_o || !rays_d || !offsets) return QF_ERR_INVALID_ARGUMENT;
+    hipLaunchKernelGGL(grid_march_kernel, dim3(qf_grid_1d(n_rays, 64, 64)), dim3(64), 0, qf_stream(stream), m, binaries,
+                       rays_o, rays_d, t_min, t_max, n_rays, (int32_t *)nullptr, offsets, t_starts, t_ends, ray_indices);
+    QF_LAUNCH_CHECK();
+    return QF_OK;
+}

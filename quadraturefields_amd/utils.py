@@ -192,3 +192,44 @@ def texel_indices(mesh_intersect, uv, points, index_tri, texture_size: int) -> t
     _C.check(_C.lib().qf_texel_indices(_C.ptr(v64), _C.ptr(faces), _C.ptr(uv), _C.ptr(points), _C.ptr(index_tri), n,
                                        int(texture_size), _C.ptr(texel), _C.stream()), "qf_texel_indices")
     return texel
+
+
+@torch.no_grad()
+def render_image_with_occgrid(
+    radiance_field: torch.nn.Module, estimator, rays: Rays, near_plane: float = 0.0, far_plane: float = 1e10,
+    render_step_size: float = 1e-3, render_bkgd: Optional[torch.Tensor] = None, cone_angle: float = 0.0,
+    alpha_thre: float = 0.0, test_chunk_size: int = 8192, timestamps: Optional[torch.Tensor] = None,
+    use_eps_loss: bool = False,
+):
+    """Occupancy-grid ray marching + nerfacc ``rendering`` -- utils.py:65-172 of the reference (the stage-1/2 renderer
+    and the ``rgb_full`` branch of finetuning).  Returns (colors, opacities, depths, n_samples, extras) with the
+    image shape of ``rays``.  The reference splits evaluation into ``test_chunk_size`` ray chunks to bound memory;
+    one chunk of any size gives the same result here, so the whole image is marched at once."""
+    from .field_rendering import rendering
+    if timestamps is not None:
+        raise NotImplementedError("dynamic (D-NeRF) fields are out of scope")
+    rays, rays_shape, num_rays = _flatten_rays(rays)
+    device = estimator.aabbs.device
+    origins = _C.f32c(rays.origins.to(device))
+    viewdirs = _C.f32c(rays.viewdirs.to(device))
+
+    def positions_of(t_starts, t_ends, ray_indices):
+        return origins[ray_indices] + viewdirs[ray_indices] * (t_starts + t_ends)[:, None] / 2.0
+
+    def sigma_fn(t_starts, t_ends, ray_indices):
+        return radiance_field.query_density(positions_of(t_starts, t_ends, ray_indices)).squeeze(-1)
+
+    def rgb_sigma_fn(t_starts, t_ends, ray_indices):
+        rgbs, sigmas = radiance_field(positions_of(t_starts, t_ends, ray_indices), viewdirs[ray_indices])
+        return rgbs, sigmas.squeeze(-1)
+
+    ray_indices, t_starts, t_ends = estimator.sampling(
+        origins, viewdirs, sigma_fn=sigma_fn, near_plane=near_plane, far_plane=far_plane,
+        render_step_size=render_step_size, stratified=radiance_field.training, cone_angle=cone_angle,
+        alpha_thre=alpha_thre)
+    rgb, opacity, depth, extras = rendering(t_starts, t_ends, ray_indices, n_rays=num_rays, rgb_sigma_fn=rgb_sigma_fn,
+                                            render_bkgd=render_bkgd)
+    extras["t_starts"], extras["t_ends"], extras["ray_indices"] = t_starts, t_ends, ray_indices
+    extras["t_origins"] = origins
+    return (rgb.view((*rays_shape[:-1], -1)), opacity.view((*rays_shape[:-1], -1)), depth.view((*rays_shape[:-1], -1)),
+            int(t_starts.shape[0]), extras)

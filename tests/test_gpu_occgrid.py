@@ -1,0 +1,105 @@
+"""Occupancy-grid ray marching: kernel vs the numpy oracle, bit-exact sample
+lists; the visibility filter and ``render_image_with_occgrid`` against the oracle's nerfacc-style ``rendering``."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import fields as ofields
+from oracle import occgrid as oocc
+from oracle import volrend as ov
+from tests import helpers
+
+
+def _grid(res=32, seed=0, fill=0.15):
+    rng = np.random.default_rng(seed)
+    coarse = rng.random((res // 4, res // 4, res // 4)) < fill
+    return np.kron(coarse, np.ones((4, 4, 4), dtype=bool))
+
+
+def test_oracle_march_closed_form():
+    """CPU: a ray along +x through a 4^3 grid over [-1,1]^3 with two occupied cells."""
+    b = np.zeros((4, 4, 4), dtype=bool)
+    b[1, 2, 2] = b[3, 2, 2] = True
+    o = np.array([[-2.0, 0.25, 0.25]], dtype=np.float32)
+    d = np.array([[1.0, 0.0, 0.0]], dtype=np.float32)
+    r, ts, te = oocc.march([-1, -1, -1, 1, 1, 1], b, o, d, 0.0, 1e10, 0.125)
+    # entry at t = 1; cell 1 spans t in [1.5, 2), cell 3 spans [2.5, 3): four steps of 0.125 each
+    assert r.tolist() == [0] * 8
+    assert np.allclose(ts, [1.5, 1.625, 1.75, 1.875, 2.5, 2.625, 2.75, 2.875])
+    assert np.allclose(te - ts, 0.125)
+    # near / far planes clip; a ray that misses the box yields nothing
+    r2, ts2, _ = oocc.march([-1, -1, -1, 1, 1, 1], b, o, d, 1.7, 2.7, 0.125)
+    # t0 = 1.7: midpoints 1.7625, 1.8875 fall in cell 1; 2.5125, 2.6375 in cell 3; the next one (2.7625) is past far
+    assert np.allclose(ts2, [1.7 + 0.125 * k for k in (0, 1, 6, 7)], atol=1e-6)
+    assert oocc.march([-1, -1, -1, 1, 1, 1], b, o + 5, d, 0.0, 1e10, 0.125)[0].size == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("res,step", [(32, 0.02), (128, 5e-3)])
+def test_march_bit_exact_vs_oracle(device, res, step):
+    from quadraturefields_amd.estimators import OccGridEstimator
+    est = OccGridEstimator(roi_aabb=[-1.5] * 3 + [1.5] * 3, resolution=res, levels=1).to(device)
+    b = _grid(res, seed=res)
+    est.binaries.copy_(torch.from_numpy(b)[None].to(device))
+    assert list(est.state_dict().keys()) == ["resolution", "aabbs", "occs", "binaries"]
+    rng = np.random.default_rng(1)
+    n = 600
+    o = rng.normal(size=(n, 3))
+    o = (o / np.linalg.norm(o, axis=1, keepdims=True) * 4.0).astype(np.float32)
+    d = rng.uniform(-1.2, 1.2, size=(n, 3)).astype(np.float32) - o
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    o[:20] = rng.uniform(-1, 1, size=(20, 3)).astype(np.float32)         # origins inside the box
+    d[20:23] = np.array([[1, 0, 0], [0, 1, 0], [0, 0, -1]], np.float32)    # axis-aligned
+    o[23:30] += 50                                                         # misses
+    for near, far in ((0.0, 1e10), (3.0, 4.5)):
+        ridx_o, ts_o, te_o = oocc.march([-1.5] * 3 + [1.5] * 3, b, o, d, near, far, step)
+        ridx, ts, te = est.sampling(torch.from_numpy(o).to(device), torch.from_numpy(d).to(device), near_plane=near,
+                                    far_plane=far, render_step_size=step)
+        assert ridx.dtype == torch.int64 and ridx.shape[0] == ridx_o.shape[0] > 1000
+        assert np.array_equal(ridx.cpu().numpy(), ridx_o)
+        assert np.array_equal(ts.cpu().numpy(), ts_o) and np.array_equal(te.cpu().numpy(), te_o)
+    # empty grid -> no samples; full grid -> contiguous samples along the chord
+    est.binaries.zero_()
+    assert est.sampling(torch.from_numpy(o).to(device), torch.from_numpy(d).to(device), render_step_size=step)[0].numel() == 0
+
+
+@pytest.mark.gpu
+def test_sampling_filter_and_render_image_with_occgrid(device):
+    from quadraturefields_amd import synthetic, utils
+    from quadraturefields_amd.datasets.utils import Rays
+    from quadraturefields_amd.estimators import OccGridEstimator
+    from quadraturefields_amd.radiance_fields.ngp import NGPRadianceField
+    aabb = [-1.5] * 3 + [1.5] * 3
+    field = NGPRadianceField(aabb=aabb, log2_hashmap_size=12)
+    field.load_state_dict(synthetic.seeded_ngp_state(12, field.mlp_base.grid.n_rows), strict=False)
+    field = field.to(device).eval()
+    est = OccGridEstimator(roi_aabb=aabb, resolution=32, levels=1).to(device)
+    est.set_occupancy_from_density(lambda p: field.query_density(p), threshold=5.0)
+    assert 0.02 < float(est.binaries.float().mean()) < 0.98
+    w = h = 24
+    c2w = synthetic.orbit_cameras(1, seed=2)[0]
+    o, d = synthetic.camera_rays(c2w, synthetic.lego_focal(800) * w / 800.0, w, h)
+    step = 0.02
+    wts = helpers.oracle_ngp_weights(field)
+
+    def sigma_fn_o(ts, te, ridx):
+        return ofields.query_density(o[ridx] + d[ridx] * (ts + te)[:, None] / 2.0, wts).squeeze(-1)
+
+    def rgb_sigma_fn_o(ts, te, ridx):
+        rgb, sig = ofields.ngp_forward(o[ridx] + d[ridx] * (ts + te)[:, None] / 2.0, d[ridx], wts)
+        return rgb, sig.squeeze(-1)
+
+    b = est.binaries[0].cpu().numpy()
+    ridx_o, ts_o, te_o = oocc.sampling(aabb, b, float(est.occs.mean()), o.numpy(), d.numpy(), sigma_fn=sigma_fn_o,
+                                       render_step_size=step, alpha_thre=0.0)
+    bk = torch.tensor([1.0, 1.0, 1.0])
+    c_o, a_o, dep_o, _ = ov.rendering(ts_o, te_o, ridx_o, n_rays=w * h, rgb_sigma_fn=rgb_sigma_fn_o, render_bkgd=bk)
+    rays = Rays(origins=o.reshape(h, w, 3).to(device), viewdirs=d.reshape(h, w, 3).to(device))
+    colors, opac, depths, n_samples, extras = utils.render_image_with_occgrid(
+        field, est, rays, render_step_size=step, render_bkgd=bk.to(device))
+    assert colors.shape == (h, w, 3) and opac.shape == (h, w, 1)
+    # the visibility filter thresholds a float (T >= 1e-4): allow a handful of boundary flips, none in practice
+    assert abs(n_samples - ts_o.shape[0]) <= 3
+    assert (colors.reshape(-1, 3).cpu() - c_o).abs().max().item() <= 5e-4
+    assert torch.allclose(opac.reshape(-1, 1).cpu(), a_o, atol=5e-4)
+    assert set(["weights", "trans", "alphas", "t_starts", "t_ends", "ray_indices"]) <= set(extras)
