@@ -155,6 +155,7 @@ def main():
     ap.add_argument("--intersector", default="raster", choices=["raster", "bvh"],
                     help="raster: camera-coherent intersector (BVH fallback on overflow); bvh: BVH traversal only")
     args = ap.parse_args()
+    torch.set_grad_enabled(False)          # inference: the fields take the fused kernels
 
     from quadraturefields_amd import parallel, synthetic
     rank, local_rank, world = parallel.init_from_env("nccl")

@@ -63,6 +63,13 @@ int qf_grid_desc_init(qf_grid_desc *desc /* host, out */, uint32_t n_levels,
 int qf_grid_encode(const qf_grid_desc *desc /* host */, const float *table /* [rows,2] */,
                    const float *x01, int64_t n, float *out /* [n,32] */, void *stream);
 
+/* Backward of qf_grid_encode (training side).  Replaces tcnn GridEncoding's backward that torch autograd
+ * reaches when the reference trains the field (examples/train_finetune.py:465-533, examples/field.py:229-238).
+ * dfeat [n,32] = dL/d(encoding).  grad_table [rows,2] is ACCUMULATED into (zero it first) with fp32 atomics; pass
+ * NULL to skip.  grad_x01 [n,3] is overwritten; pass NULL to skip.                               */
+int qf_grid_encode_backward(const qf_grid_desc *desc /* host */, const float *table, const float *x01,
+                            const float *dfeat, int64_t n, float *grad_table, float *grad_x01, void *stream);
+
 /* Grid + 1-hidden-layer 64-wide MLP: x01 [n,3] -> raw [n,16].  Replaces
  * tcnn.NetworkWithInputEncoding.forward for mlp_base (ngp.py:764-768); base_w as below.       */
 int qf_grid_mlp_forward(const qf_grid_desc *grid /* host */, const float *table, const float *base_w,
@@ -167,6 +174,16 @@ int qf_derive_properties(const float *rgb_s /* [n,3] */, const float *sigma /* [
                          int64_t n_rays, int32_t bg_mode, const float *bkgd /* [3] or NULL */,
                          float *out_rgb, float *out_alpha, float *out_depth, float *weights,
                          void *stream);
+
+/* Backward of qf_derive_properties (training side: the loss of examples/train_finetune.py:489-533 back-propagates
+ * through utils.py:139-186).  g_rgb [n_rays,3], g_alpha / g_depth [n_rays] or NULL -> grad_rgb_s [n,3],
+ * grad_sigma [n], grad_depth [n] or NULL.  Same inputs as the forward; one thread per ray.       */
+int qf_derive_properties_backward(const float *rgb_s, const float *sigma, const float *depth,
+                                  const float *deltas /* [n] or NULL */, float delta_const,
+                                  const int64_t *index_ray, int64_t n, int32_t bg_mode,
+                                  const float *bkgd /* [3] or NULL */, const float *g_rgb,
+                                  const float *g_alpha, const float *g_depth, float *grad_rgb_s,
+                                  float *grad_sigma, float *grad_depth, void *stream);
 
 /* nerfacc duck-types (nerfacc.pack / nerfacc.scan, imported at field_rendering.py:10-11).     */
 int qf_pack_info(const int64_t *ray_indices /* sorted, [n] */, int64_t n, int64_t n_rays,

@@ -20,6 +20,7 @@ ARCH = "gfx950"
 SOURCES = [
     ("field_eval.hip", []),
     ("field_eval_bf16.hip", []),
+    ("grid_backward.hip", []),
     ("composite.hip", []),
     ("exact.hip", ["-ffp-contract=off"]),
     ("bvh_build.cpp", ["-x", "hip"]),

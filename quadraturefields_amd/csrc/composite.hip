@@ -443,3 +443,77 @@ extern "C" int qf_scatter_max(const float *values, const int64_t *index, int64_t
     QF_LAUNCH_CHECK();
     return QF_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// Backward of derive_properties (training side): gradients of the per-ray outputs
+// (rgb, alpha, depth) w.r.t. the per-sample colour, density and depth.  With C = sum w c, A = sum w, D = sum w t:
+//   white: rgb = (1-A) + A C ; black: rgb = A C ; custom: rgb = A C + (1-A) bg
+//   gC = A g_rgb ; gA = g_alpha + sum_ch g_rgb (C - {1, 0, bg}) ; gw_i = gC.c_i + gA + gD t_i
+//   w_i = T_i (1 - exp(-tau_i)), dw_i/dtau_i = T_i exp(-tau_i), dw_k/dtau_i = -w_k for k > i
+//   => gtau_i = gw_i T_i exp(-tau_i) - sum_{k>i} gw_k w_k ; gsigma_i = gtau_i delta_i ; gc_i = w_i gC ; gt_i = w_i gD
+namespace {
+
+__global__ void derive_properties_backward_kernel(const float *rgb_s, const float *sigma, const float *depth_s,
+                                                  const float *deltas, float delta_const, const int64_t *index_ray,
+                                                  int64_t n, int bg_mode, const float *bkgd, const float *g_rgb,
+                                                  const float *g_alpha, const float *g_depth, float *grad_rgb_s,
+                                                  float *grad_sigma, float *grad_depth_s)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t ray = index_ray[i];
+        if (i != 0 && index_ray[i - 1] == ray) continue;
+        // forward pass over the ray: totals and the index just past its last sample
+        float cum = 0.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f, ca = 0.0f;
+        int64_t end = i;
+        for (; end < n && index_ray[end] == ray; ++end) {
+            const float tau = sigma[end] * (deltas ? deltas[end] : delta_const);
+            const float w = expf(-cum) * (1.0f - expf(-tau));
+            cum += tau;
+            cr += w * rgb_s[end * 3 + 0];
+            cg += w * rgb_s[end * 3 + 1];
+            cb += w * rgb_s[end * 3 + 2];
+            ca += w;
+        }
+        const float gr = g_rgb[ray * 3 + 0], gg = g_rgb[ray * 3 + 1], gb = g_rgb[ray * 3 + 2];
+        const float gD = g_depth ? g_depth[ray] : 0.0f;
+        const float b0 = bg_mode == QF_BG_WHITE ? 1.0f : (bg_mode == QF_BG_BLACK ? 0.0f : bkgd[0]);
+        const float b1 = bg_mode == QF_BG_WHITE ? 1.0f : (bg_mode == QF_BG_BLACK ? 0.0f : bkgd[1]);
+        const float b2 = bg_mode == QF_BG_WHITE ? 1.0f : (bg_mode == QF_BG_BLACK ? 0.0f : bkgd[2]);
+        const float gA = (g_alpha ? g_alpha[ray] : 0.0f) + gr * (cr - b0) + gg * (cg - b1) + gb * (cb - b2);
+        const float gCr = ca * gr, gCg = ca * gg, gCb = ca * gb;
+        // backward sweep: cum holds the total optical depth; peel samples off the far end
+        float suffix = 0.0f;
+        for (int64_t j = end - 1; j >= i; --j) {
+            const float dl = deltas ? deltas[j] : delta_const;
+            const float tau = sigma[j] * dl;
+            cum -= tau;                                   // exclusive optical depth of sample j (up to rounding)
+            const float T = expf(-cum), e = expf(-tau);
+            const float w = T * (1.0f - e);
+            const float gw = gCr * rgb_s[j * 3 + 0] + gCg * rgb_s[j * 3 + 1] + gCb * rgb_s[j * 3 + 2] + gA + gD * depth_s[j];
+            grad_sigma[j] = (gw * T * e - suffix) * dl;
+            suffix += gw * w;
+            grad_rgb_s[j * 3 + 0] = w * gCr;
+            grad_rgb_s[j * 3 + 1] = w * gCg;
+            grad_rgb_s[j * 3 + 2] = w * gCb;
+            if (grad_depth_s) grad_depth_s[j] = w * gD;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int qf_derive_properties_backward(const float *rgb_s, const float *sigma, const float *depth,
+                                             const float *deltas, float delta_const, const int64_t *index_ray,
+                                             int64_t n, int32_t bg_mode, const float *bkgd, const float *g_rgb,
+                                             const float *g_alpha, const float *g_depth, float *grad_rgb_s,
+                                             float *grad_sigma, float *grad_depth, void *stream)
+{
+    if (n < 0 || bg_mode < 0 || bg_mode > 2 || (bg_mode == QF_BG_CUSTOM && !bkgd)) return QF_ERR_INVALID_ARGUMENT;
+    if (n == 0) return QF_OK;
+    if (!rgb_s || !sigma || !depth || !index_ray || !g_rgb || !grad_rgb_s || !grad_sigma) return QF_ERR_INVALID_ARGUMENT;
+    hipLaunchKernelGGL(derive_properties_backward_kernel, dim3(qf_grid_1d(n, 256)), dim3(256), 0, qf_stream(stream),
+                       rgb_s, sigma, depth, deltas, delta_const, index_ray, n, (int)bg_mode, bkgd, g_rgb, g_alpha, g_depth,
+                       grad_rgb_s, grad_sigma, grad_depth);
+    QF_LAUNCH_CHECK();
+    return QF_OK;
+}

@@ -1,0 +1,104 @@
+// Backward of the multi-resolution hash-grid encoding (training side).
+//
+// Replaces the backward of tcnn GridEncoding (kernel_grid_backward / kernel_grid_backward_input) that the
+// reference reaches through torch autograd when it trains NGPRadianceField / Field
+// (examples/train_finetune.py:465-533, examples/field.py:229-238).
+//   * table gradient: every (point, level) scatter-adds weight_c * dL/dfeat into the 8 corner rows with no-return
+//     fp32 atomics (global_atomic_add_f32).  Atomic sums depend on arrival order: results are reproducible to fp32
+//     rounding, not bitwise.  Budget: 256 B of atomics per point-level, chip rate ~1.3 TB/s.
+//   * input gradient: dL/dx = sum_levels scale_l * sum_f dL/dfeat_f * sum_c (d weight_c / d frac) * table[c][f]
+//     (linear interpolation: d pos / d x = scale), one lane per point, no atomics.
+#include "field_common.h"
+
+namespace {
+
+__device__ __forceinline__ LevelConst level_const(const GridArgs &ga, int level)
+{
+    LevelConst lc;
+    lc.offset = ga.offset[level];
+    lc.rows = ga.rows[level];
+    lc.res = ga.res[level];
+    lc.scale = ga.scale[level];
+    lc.hashed = (ga.hashed_mask >> level) & 1u;
+    return lc;
+}
+
+__global__ void grid_backward_table_kernel(GridArgs ga, const float *x01, const float *dfeat, int64_t n, float *grad_table)
+{
+    const int64_t total = n * QF_MAX_LEVELS;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t pt = e >> 4;
+        const int level = (int)(e & 15);
+        const float g0 = dfeat[pt * 32 + 2 * level], g1 = dfeat[pt * 32 + 2 * level + 1];
+        if (g0 == 0.0f && g1 == 0.0f) continue;
+        const LevelConst lc = level_const(ga, level);
+        uint32_t idx[8];
+        float frac[3];
+        level_indices(lc, x01[pt * 3], x01[pt * 3 + 1], x01[pt * 3 + 2], idx, frac);
+        const float wx = frac[0], wy = frac[1], wz = frac[2];
+        const float wxy[4] = {(1.0f - wx) * (1.0f - wy), wx * (1.0f - wy), (1.0f - wx) * wy, wx * wy};
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const float w = wxy[c & 3] * ((c & 4) ? wz : 1.0f - wz);
+            atomicAdd(grad_table + 2 * (int64_t)idx[c], w * g0);
+            atomicAdd(grad_table + 2 * (int64_t)idx[c] + 1, w * g1);
+        }
+    }
+}
+
+__global__ void grid_backward_input_kernel(GridArgs ga, const float2 *table, const float *x01, const float *dfeat,
+                                           int64_t n, float *dx)
+{
+    for (int64_t pt = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; pt < n; pt += (int64_t)gridDim.x * blockDim.x) {
+        const float x = x01[pt * 3], y = x01[pt * 3 + 1], z = x01[pt * 3 + 2];
+        float gx = 0.0f, gy = 0.0f, gz = 0.0f;
+        for (int level = 0; level < QF_MAX_LEVELS; ++level) {
+            const float g0 = dfeat[pt * 32 + 2 * level], g1 = dfeat[pt * 32 + 2 * level + 1];
+            const LevelConst lc = level_const(ga, level);
+            uint32_t idx[8];
+            float frac[3];
+            level_indices(lc, x, y, z, idx, frac);
+            const float wx = frac[0], wy = frac[1], wz = frac[2];
+            float sx = 0.0f, sy = 0.0f, sz = 0.0f;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const float2 v = table[idx[c]];
+                const float s = g0 * v.x + g1 * v.y;
+                const float ax = (c & 1) ? wx : 1.0f - wx, ay = (c & 2) ? wy : 1.0f - wy, az = (c & 4) ? wz : 1.0f - wz;
+                sx += ((c & 1) ? 1.0f : -1.0f) * ay * az * s;
+                sy += ((c & 2) ? 1.0f : -1.0f) * ax * az * s;
+                sz += ((c & 4) ? 1.0f : -1.0f) * ax * ay * s;
+            }
+            gx += lc.scale * sx;
+            gy += lc.scale * sy;
+            gz += lc.scale * sz;
+        }
+        dx[pt * 3 + 0] = gx;
+        dx[pt * 3 + 1] = gy;
+        dx[pt * 3 + 2] = gz;
+    }
+}
+
+}  // namespace
+
+extern "C" int qf_grid_encode_backward(const qf_grid_desc *desc, const float *table, const float *x01,
+                                       const float *dfeat, int64_t n, float *grad_table, float *grad_x01, void *stream)
+{
+    if (!desc || n < 0) return QF_ERR_INVALID_ARGUMENT;
+    GridArgs ga;
+    int rc = fill_grid_args(desc, &ga);
+    if (rc != QF_OK) return rc;
+    if (n == 0) return QF_OK;
+    if (!x01 || !dfeat || (!grad_table && !grad_x01) || (grad_x01 && !table)) return QF_ERR_INVALID_ARGUMENT;
+    if (grad_table) {
+        hipLaunchKernelGGL(grid_backward_table_kernel, dim3(qf_grid_1d(n * 16, 256)), dim3(256), 0, qf_stream(stream), ga,
+                           x01, dfeat, n, grad_table);
+        QF_LAUNCH_CHECK();
+    }
+    if (grad_x01) {
+        hipLaunchKernelGGL(grid_backward_input_kernel, dim3(qf_grid_1d(n, 256)), dim3(256), 0, qf_stream(stream), ga,
+                           reinterpret_cast<const float2 *>(table), x01, dfeat, n, grad_x01);
+        QF_LAUNCH_CHECK();
+    }
+    return QF_OK;
+}

@@ -2,8 +2,9 @@
 
 Mirrors ``Field`` of ``examples/field.py:130-270`` as the render path uses it
 (``examples/utils.py:555-566``: ``field_net(x, return_grad=False)[0]``): hash grid (tcnn ``Encoding``)
-followed by ``cat[x01, h] -> BasicDecoder``.  Forward only; gradients of the field w.r.t. its input
-(``field_grad`` and the training losses) belong to training and are not implemented.
+followed by ``cat[x01, h] -> BasicDecoder``.  Inference is one fused launch; when autograd is recording the
+differentiable route (HIP grid forward/backward + library GEMMs) is taken, which also serves ``field_grad``
+(first order; ``create_graph=True`` through the grid is not implemented).
 """
 import numpy as np
 import torch
@@ -60,6 +61,10 @@ class Field(nn.Module):
 
     def density(self, x):
         """[N,3] in [-scale, scale] -> [N,1].  field.py:186-203, one fused launch."""
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            x01 = (x.reshape(-1, 3) - self.xyz_min) / (self.xyz_max - self.xyz_min)
+            h = self.xyz_encoder(x01 if self.back_prop else x01.detach())
+            return self.decoder_field(torch.cat([x01, h], 1))
         x = _C.f32c(x.reshape(-1, 3))
         n = x.shape[0]
         out = torch.empty((n,), dtype=torch.float32, device=x.device)
@@ -75,7 +80,17 @@ class Field(nn.Module):
         return self.density(x)[:, 0:self.output_dim]
 
     def forward(self, x, return_grad=True):
-        """(field [N,1], None).  field.py:206-223 with return_grad=False."""
-        if return_grad:
-            raise NotImplementedError("field gradients are a training feature (SURVEY.md section 8f item 1)")
-        return self.field(x), None
+        """(field [N,1], field_grad [N,3] or None).  field.py:206-223."""
+        if not return_grad:
+            return self.field(x), None
+        if not x.requires_grad:
+            x.requires_grad = True
+        field = self.field(x)
+        return field, self.field_grad(x, field, create_graph=False)
+
+    def field_grad(self, coords, field, create_graph=False):
+        """d field / d coords, field.py:229-238.  First order only: the grid backward is once-differentiable."""
+        if create_graph:
+            raise NotImplementedError("second-order gradients through the hash grid are not implemented")
+        field = field.flatten()
+        return torch.autograd.grad(field, [coords], grad_outputs=torch.ones_like(field), retain_graph=True)[0]

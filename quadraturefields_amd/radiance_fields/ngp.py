@@ -6,7 +6,9 @@ Same classes, constructor arguments, methods and state-dict keys as
 reference's checkpoints load and its renderers (``examples/utils.py``) can call them unchanged.  Each
 ``forward`` / ``query_density`` / ``features`` is ONE launch of ``qf_field_forward``: hash-grid gather,
 both MLPs on the fp32 matrix cores and the SH / spherical-Gaussian head never leave registers.
-Inference only: the kernels have no backward.
+Training: when autograd is recording and something wants a gradient the same methods
+take a differentiable route -- HIP hash-grid forward/backward, library GEMMs for the MLPs -- with identical values
+to fp32 rounding; ``torch.no_grad()`` / frozen parameters select the fused kernel.
 """
 import ctypes
 from typing import Callable, List, Union
@@ -217,9 +219,26 @@ class _FusedFieldBase(nn.Module):
             _C.ptr(order, torch.int32), _C.ptr(rgb), _C.ptr(sigma), _C.ptr(geo), _C.ptr(feats), _C.stream()), "qf_field_forward")
         return rgb, sigma, geo, feats
 
+    def _recording(self, *inputs) -> bool:
+        """Autograd is recording and a parameter or input wants a gradient: take the differentiable route
+        (HIP grid forward/backward + library GEMMs) instead of the fused inference kernel."""
+        return torch.is_grad_enabled() and (any(t is not None and t.requires_grad for t in inputs)
+                                            or any(p.requires_grad for p in self.parameters()))
+
+    def _query_density_train(self, x):
+        selector, x01 = self.normalize(x)
+        out = self.mlp_base(x01.reshape(-1, self.num_dim))
+        raw, feat = out[:, :1], out[:, 1:1 + self.geo_feat_dim]
+        density = torch.exp(raw - 1.0) * selector.reshape(-1, 1)
+        return density, feat
+
     def query_density(self, x, return_feat: bool = False):
         """density = exp(raw - 1) * selector, [..,1] (+ the 15 geometry features).  ngp.py:757-779."""
         lead = list(x.shape[:-1])
+        if self._recording(x):
+            density, feat = self._query_density_train(x)
+            density = density.reshape(lead + [1])
+            return (density, feat.reshape(lead + [self.geo_feat_dim])) if return_feat else density
         _, sigma, geo, _ = self._launch(_C.HEAD_NONE, 0, x, None, want_sigma=True, want_geo=return_feat)
         density = sigma.reshape(lead + [1])
         if return_feat:
@@ -255,6 +274,11 @@ class NGPRadianceField(_FusedFieldBase):
             raise ValueError("NGPRadianceField.forward needs view directions")
         assert positions.shape == directions.shape, f"{positions.shape} v.s. {directions.shape}"
         lead = list(positions.shape[:-1])
+        if self._recording(positions, directions):
+            density, feat = self._query_density_train(positions)
+            sh = self.direction_encoding((directions.reshape(-1, 3) + 1.0) / 2.0)
+            rgb = torch.sigmoid(self.mlp_head(torch.cat([sh, feat], dim=-1)))
+            return rgb.reshape(lead + [3]), density.reshape(lead + [1])
         rgb, sigma, _, _ = self._launch(_C.HEAD_NGP, 0, positions, directions, want_rgb=True, want_sigma=True,
                                         head_ngp=self.mlp_head.params.detach(), order=order)
         return rgb.reshape(lead + [3]), sigma.reshape(lead + [1])
@@ -292,12 +316,23 @@ class NGPRadianceFieldSGNew(_FusedFieldBase):
     def features(self, x):
         """[head(3+7L) | density], ngp.py:445-454."""
         width = 3 + 7 * self.num_g_lobes + 1
+        if self._recording(x):
+            density, feat = self._query_density_train(x)
+            return torch.cat([self.mlp_head(feat), density], dim=-1)
         _, _, _, feats = self._launch(_C.HEAD_SG_FEATURES, self.num_g_lobes, x, None, want_features=width,
                                       head_sg=self._sg_params())
         return feats
 
     def features_to_rgb(self, features, dir):
         """sigmoid(diffuse + SG mixture), ngp.py:456-461.  features [n, >= 3+7L] (extra columns ignored)."""
+        if torch.is_grad_enabled() and (features.requires_grad or dir.requires_grad):
+            dir = dir.reshape(-1, 3)
+            rgb = features[:, :3]
+            for lobe in torch.chunk(features[:, 3:3 + 7 * self.num_g_lobes], self.num_g_lobes, dim=-1):
+                axis = lobe[:, :3] / torch.linalg.norm(lobe[:, :3], dim=-1, keepdim=True)
+                sharp = torch.abs(lobe[:, 3])
+                rgb = rgb + lobe[:, 4:7] * torch.exp(sharp * (torch.sum(axis * dir, -1) - 1.0))[:, None]
+            return torch.sigmoid(rgb)
         features = _C.f32c(features)
         dir = _C.f32c(dir.reshape(-1, 3))
         n = features.shape[0]
@@ -311,6 +346,10 @@ class NGPRadianceFieldSGNew(_FusedFieldBase):
         if directions is None:
             raise ValueError("NGPRadianceFieldSGNew.forward needs view directions")
         lead = list(positions.shape[:-1])
+        if self._recording(positions, directions):
+            f = self.features(positions)
+            rgb = self.features_to_rgb(f[:, :-1], directions)
+            return rgb.reshape(lead + [3]), f[:, -1:].reshape(lead + [1])
         rgb, sigma, _, _ = self._launch(_C.HEAD_SG, self.num_g_lobes, positions, directions, want_rgb=True,
                                         want_sigma=True, head_sg=self._sg_params(), order=order)
         return rgb.reshape(lead + [3]), sigma.reshape(lead + [1])

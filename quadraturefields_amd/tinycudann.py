@@ -6,12 +6,20 @@ The reference builds its fields from ``tcnn.Encoding``, ``tcnn.Network`` and
 and keep ONE flat fp32 ``params`` Parameter in tcnn's order (network weights, then grid rows; SURVEY.md
 A.1-A.2), so the reference's checkpoints load with ``load_state_dict``.  Parameters are stored and
 evaluated in fp32 (tcnn computes in fp16); outputs are fp32.
+
+Training: when autograd is recording and a parameter or the input requires a
+gradient, ``forward`` takes the differentiable route -- the hash grid through ``grid_encode`` (HIP forward +
+HIP backward, ``qf_grid_encode_backward``) and the 64-wide MLPs as ``F.linear`` on views of the flat parameter
+vector, so ``params.grad`` has tcnn's layout and the reference's optimiser / checkpoint code keeps working.
+Inference (``torch.no_grad`` or frozen parameters) stays on the fused kernels.
 """
 import math
 
 import numpy as np
 import torch
+import torch.nn.functional as F
 from torch import nn
+from torch.autograd.function import once_differentiable
 
 from . import _C
 
@@ -66,6 +74,73 @@ def _xavier_flat(dims, generator=None) -> torch.Tensor:
     return torch.cat(chunks)
 
 
+class _GridEncodeFn(torch.autograd.Function):
+    """feat = grid(x01; table).  Backward: table gradient by atomic scatter, input gradient by the analytic
+    derivative of the trilinear blend (tcnn's kernel_grid_backward / kernel_grid_backward_input)."""
+
+    @staticmethod
+    def forward(ctx, x01, table, desc):
+        x01 = _C.f32c(x01.detach().reshape(-1, 3))
+        table = _C.f32c(table.detach())
+        n = x01.shape[0]
+        out = torch.empty((n, 32), dtype=torch.float32, device=x01.device)
+        _C.check(_C.lib().qf_grid_encode(desc, _C.ptr(table), _C.ptr(x01), n, _C.ptr(out), _C.stream()), "qf_grid_encode")
+        ctx.save_for_backward(x01, table)
+        ctx.desc = desc
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dfeat):
+        x01, table = ctx.saved_tensors
+        need_x, need_t = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        dfeat = _C.f32c(dfeat)
+        n = x01.shape[0]
+        gx = torch.empty_like(x01) if need_x else None
+        gt = torch.zeros_like(table) if need_t else None
+        if n and (need_x or need_t):
+            _C.check(_C.lib().qf_grid_encode_backward(ctx.desc, _C.ptr(table), _C.ptr(x01), _C.ptr(dfeat), n,
+                                                      _C.ptr(gt), _C.ptr(gx), _C.stream()), "qf_grid_encode_backward")
+        return gx, gt, None
+
+
+def grid_encode(x01: torch.Tensor, table: torch.Tensor, desc) -> torch.Tensor:
+    """Differentiable hash-grid encoding: x01 [n,3], flat table [rows*2] -> [n,32]."""
+    return _GridEncodeFn.apply(x01, table, desc)
+
+
+def recording(*tensors) -> bool:
+    """True when autograd would record an op on these tensors (the switch between the fused inference kernels
+    and the differentiable route)."""
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
+
+
+def _mlp_nobias(x: torch.Tensor, flat: torch.Tensor, dims) -> torch.Tensor:
+    """FullyFusedMLP as library GEMMs on views of the flat row-major [out,in] parameter vector."""
+    o, h = 0, x
+    last = len(dims) - 2
+    for k, (a, b) in enumerate(zip(dims[:-1], dims[1:])):
+        h = F.linear(h, flat[o:o + a * b].view(b, a))
+        if k != last:
+            h = F.relu(h)
+        o += a * b
+    return h
+
+
+def sh4(d: torch.Tensor) -> torch.Tensor:
+    """Real spherical harmonics up to degree 4 (16 values) of unit vectors [n,3], tcnn's sign convention."""
+    x, y, z = d.unbind(-1)
+    xy, xz, yz, x2, y2, z2 = x * y, x * z, y * z, x * x, y * y, z * z
+    return torch.stack([
+        torch.full_like(x, 0.28209479177387814), -0.48860251190291987 * y, 0.48860251190291987 * z,
+        -0.48860251190291987 * x, 1.0925484305920792 * xy, -1.0925484305920792 * yz,
+        0.94617469575755997 * z2 - 0.31539156525251999, -1.0925484305920792 * xz,
+        0.54627421529603959 * (x2 - y2), 0.59004358992664352 * y * (y2 - 3.0 * x2), 2.8906114426405538 * xy * z,
+        0.45704579946446572 * y * (1.0 - 5.0 * z2), 0.3731763325901154 * z * (5.0 * z2 - 3.0),
+        0.45704579946446572 * x * (1.0 - 5.0 * z2), 1.4453057213202769 * z * (x2 - y2),
+        0.59004358992664352 * x * (3.0 * y2 - x2)], dim=-1)
+
+
 class Encoding(nn.Module):
     """tcnn.Encoding: hash grid (field.py:157-171) or the SH-degree-4 composite (ngp.py:325-338)."""
 
@@ -89,8 +164,9 @@ class Encoding(nn.Module):
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if self.grid is None:
-            raise NotImplementedError(
-                "the SH encoding is evaluated inside the fused field kernel (NGPRadianceField.forward)")
+            return sh4(x.reshape(-1, 3) * 2.0 - 1.0)      # tcnn maps its [0,1] input back to [-1,1]
+        if recording(x, self.params):
+            return grid_encode(x.reshape(-1, 3), self.params, self.grid.desc)
         x = _C.f32c(x.reshape(-1, 3))
         n = x.shape[0]
         out = torch.empty((n, 32), dtype=torch.float32, device=x.device)
@@ -112,7 +188,13 @@ class Network(nn.Module):
         self.params = nn.Parameter(_xavier_flat(self.dims))
 
     def forward(self, x):
-        raise NotImplementedError("tcnn.Network is evaluated inside the fused field kernel")
+        """Library-GEMM evaluation (training route); inference runs inside the fused field kernel.  tcnn pads the
+        input to a multiple of 16 with ones and returns the first n_output_dims columns."""
+        x = x.reshape(-1, self.n_input_dims).to(torch.float32)
+        pad = self.dims[0] - self.n_input_dims
+        if pad:
+            x = torch.cat([x, torch.ones((x.shape[0], pad), dtype=x.dtype, device=x.device)], dim=-1)
+        return _mlp_nobias(x, self.params, self.dims)[:, : self.n_output_dims]
 
 
 class NetworkWithInputEncoding(nn.Module):
@@ -141,6 +223,9 @@ class NetworkWithInputEncoding(nn.Module):
         return self.params.detach()[self.n_network_params:]
 
     def forward(self, x01: torch.Tensor) -> torch.Tensor:
+        if recording(x01, self.params):
+            enc = grid_encode(x01.reshape(-1, 3), self.params[self.n_network_params:], self.grid.desc)
+            return _mlp_nobias(enc, self.params, self.dims)[:, : self.n_output_dims]
         x01 = _C.f32c(x01.reshape(-1, 3))
         n = x01.shape[0]
         out = torch.empty((n, 16), dtype=torch.float32, device=x01.device)

@@ -51,36 +51,67 @@ def generate_splits(data, num_rays, chunk_size=160000):
 _BG = {"white": _C.BG_WHITE, "black": _C.BG_BLACK}
 
 
+class _DerivePropertiesFn(torch.autograd.Function):
+    """Differentiable compositing: forward = qf_derive_properties, backward = qf_derive_properties_backward
+    (gradients w.r.t. per-sample colour, density and depth; the returned weights are not differentiated, the
+    reference only uses them detached -- examples/field.py:246-252)."""
+
+    @staticmethod
+    def forward(ctx, color, density, depths, deltas_t, delta_c, index_ray, N, mode, bk):
+        n = color.shape[0]
+        dev = color.device
+        rgb = torch.empty((N, 3), dtype=torch.float32, device=dev)
+        alpha = torch.empty((N, 1), dtype=torch.float32, device=dev)
+        depth_out = torch.empty((N, 1), dtype=torch.float32, device=dev)
+        weights = torch.empty((n, 1), dtype=torch.float32, device=dev)
+        _C.check(_C.lib().qf_derive_properties(
+            _C.ptr(color), _C.ptr(density), _C.ptr(depths), _C.ptr(deltas_t), delta_c, _C.ptr(index_ray), n, N, mode,
+            _C.ptr(bk), _C.ptr(rgb), _C.ptr(alpha), _C.ptr(depth_out), _C.ptr(weights), _C.stream()),
+            "qf_derive_properties")
+        ctx.save_for_backward(color, density, depths, deltas_t, index_ray, bk)
+        ctx.delta_c, ctx.mode = delta_c, mode
+        ctx.mark_non_differentiable(weights)
+        return rgb, alpha, depth_out, weights
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_alpha, g_depth, _g_weights):
+        color, density, depths, deltas_t, index_ray, bk = ctx.saved_tensors
+        n = color.shape[0]
+        g_color = torch.empty_like(color)
+        g_sigma = torch.empty_like(density)
+        g_t = torch.empty_like(depths) if ctx.needs_input_grad[2] else None
+        if n:
+            _C.check(_C.lib().qf_derive_properties_backward(
+                _C.ptr(color), _C.ptr(density), _C.ptr(depths), _C.ptr(deltas_t), ctx.delta_c, _C.ptr(index_ray), n,
+                ctx.mode, _C.ptr(bk), _C.ptr(_C.f32c(g_rgb)), _C.ptr(_C.f32c(g_alpha)), _C.ptr(_C.f32c(g_depth)),
+                _C.ptr(g_color), _C.ptr(g_sigma), _C.ptr(g_t), _C.stream()), "qf_derive_properties_backward")
+        return g_color, g_sigma, g_t, None, None, None, None, None, None
+
+
 def derive_properties(color, density, depths, deltas, boundary, index_ray, render_bkgd=None, bg_color="white", N=0):
     """Per-ray colour / alpha / depth buffers from packed samples sorted by (ray, depth): one fused launch
     (the reference runs three kaolin scans + three scatters, utils.py:863-898).
 
     Returns (rgb [N,3], alpha [N,1], index_ray[boundary], Depth [N,1], weights [S,1]).  Background handling
     follows the reference, quirks included: white (or any non-"black" name) fills untouched rays with 1 and
-    blends ``(1-a) + a*sum(w c)``; "black" uses ``a*sum(w c)``; other names blend with ``render_bkgd``."""
+    blends ``(1-a) + a*sum(w c)``; "black" uses ``a*sum(w c)``; other names blend with ``render_bkgd``.
+    Differentiable w.r.t. colour, density and depths when autograd is recording (training)."""
     color = _C.f32c(color.reshape(-1, 3))
-    n = color.shape[0]
     dev = color.device
     density = _C.f32c(density.reshape(-1))
     depths = _C.f32c(depths.reshape(-1))
     index_ray = _C.i64c(index_ray.reshape(-1))
     deltas_t, delta_c = None, 0.0
     if isinstance(deltas, torch.Tensor):
-        deltas_t = _C.f32c(deltas.reshape(-1))
+        deltas_t = _C.f32c(deltas.detach().reshape(-1))
     else:
         delta_c = float(deltas)
     mode = _BG.get(bg_color, _C.BG_CUSTOM)
     bk = None
     if mode == _C.BG_CUSTOM:
-        bk = _C.f32c(render_bkgd.reshape(3).to(dev))
-    rgb = torch.empty((N, 3), dtype=torch.float32, device=dev)
-    alpha = torch.empty((N, 1), dtype=torch.float32, device=dev)
-    depth_out = torch.empty((N, 1), dtype=torch.float32, device=dev)
-    weights = torch.empty((n, 1), dtype=torch.float32, device=dev)
-    _C.check(_C.lib().qf_derive_properties(
-        _C.ptr(color), _C.ptr(density), _C.ptr(depths), _C.ptr(deltas_t), delta_c, _C.ptr(index_ray), n, N, mode,
-        _C.ptr(bk), _C.ptr(rgb), _C.ptr(alpha), _C.ptr(depth_out), _C.ptr(weights), _C.stream()),
-        "qf_derive_properties")
+        bk = _C.f32c(render_bkgd.detach().reshape(3).to(dev))
+    rgb, alpha, depth_out, weights = _DerivePropertiesFn.apply(color, density, depths, deltas_t, delta_c, index_ray,
+                                                               N, mode, bk)
     hit_rays = index_ray[boundary] if boundary is not None else None
     return rgb, alpha, hit_rays, depth_out, weights
 

@@ -1,0 +1,249 @@
+"""Training side: gradients of the differentiable route -- HIP hash-grid
+forward/backward, library-GEMM MLPs, HIP compositing backward -- against torch autograd through the CPU oracle on
+the same seeded inputs.  Tolerances are fp32 rounding (the table gradient is an atomic sum: order-dependent)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import fields as ofields
+from oracle import volrend as ov
+from tests import helpers
+
+
+def _leaf(t):
+    return t.detach().clone().requires_grad_(True)
+
+
+def _close(a, b, rtol=2e-4, atol=None):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    atol = atol if atol is not None else rtol * float(b.abs().max())
+    return float((a - b).abs().max()) <= atol, float((a - b).abs().max()), float(b.abs().max())
+
+
+def test_oracle_grid_input_gradient_matches_finite_differences():
+    """CPU: pins the autograd of the oracle's hash_encode (the checker of the HIP backward) against central
+    differences at points away from cell faces."""
+    lv = ofields.grid_levels(16, 12, 16, 1.3819)
+    g = torch.Generator().manual_seed(3)
+    table = (torch.rand(lv.n_entries, 2, generator=g) * 2 - 1).float()
+    x = (torch.rand(64, 3, generator=g) * 0.9 + 0.05).float()
+    proj = torch.randn(32, generator=g).double()
+    with torch.enable_grad():
+        xr = _leaf(x)
+        (ofields.hash_encode(xr, table, lv)[:, :8].double() @ proj[:8]).sum().backward()   # coarse levels: h << cell
+    h = 1e-4
+    for d in range(3):
+        e = torch.zeros(3)
+        e[d] = h
+        fd = ((ofields.hash_encode(x + e, table, lv)[:, :8].double() - ofields.hash_encode(x - e, table, lv)[:, :8].double())
+              @ proj[:8]) / (2 * h)
+        ok = (fd - xr.grad[:, d].double()).abs() <= 2e-2 * fd.abs().max()
+        assert ok.float().mean() > 0.9        # the few points whose +-h straddles a cell face are excluded
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("log2_t", [12, 16])
+def test_grid_encode_backward_vs_oracle_autograd(device, log2_t):
+    from quadraturefields_amd import tinycudann as tcnn
+    cfg = {"otype": "HashGrid", "n_levels": 16, "n_features_per_level": 2, "log2_hashmap_size": log2_t,
+           "base_resolution": 16, "per_level_scale": 1.4472692012786865}
+    enc = tcnn.Encoding(3, cfg)
+    g = torch.Generator().manual_seed(log2_t)
+    with torch.no_grad():
+        enc.params.copy_((torch.rand(enc.params.shape, generator=g) * 2 - 1) * 0.5)
+    lv = ofields.grid_levels(16, log2_t, 16, cfg["per_level_scale"])
+    n = 3000
+    x = torch.rand(n, 3, generator=g).float()
+    x[:8] = torch.tensor([0.0, 0.5, 1.0])[None]                       # cell faces and the box boundary
+    gout = torch.randn(n, 32, generator=g).float()
+    gout[10:20] = 0.0                                                 # rows the scatter may skip
+    with torch.enable_grad():
+        xo, to = _leaf(x), _leaf(enc.params.reshape(-1, 2))
+        fo = ofields.hash_encode(xo, to, lv)
+        fo.backward(gout)
+        enc = enc.to(device)
+        xd = _leaf(x.to(device))
+        fd = enc(xd)
+        assert fd.requires_grad
+        fd.backward(gout.to(device))
+    assert torch.equal(fd.detach().cpu(), fo.detach()) or _close(fd, fo, 1e-6)[0]
+    ok, err, ref = _close(enc.params.grad.reshape(-1, 2), to.grad, 1e-5)
+    assert ok, (err, ref)
+    ok, err, ref = _close(xd.grad, xo.grad, 1e-5)
+    assert ok, (err, ref)
+    # input-only / table-only requests
+    with torch.enable_grad():
+        enc.params.requires_grad_(False)
+        x2 = _leaf(x.to(device))
+        enc(x2).backward(gout.to(device))
+        assert _close(x2.grad, xo.grad, 1e-5)[0] and enc.params.grad is not None
+        enc.params.requires_grad_(True)
+        enc.params.grad = None
+        enc(x.to(device)).backward(gout.to(device))
+        assert _close(enc.params.grad.reshape(-1, 2), to.grad, 1e-5)[0]
+
+
+def _oracle_leaves(wts):
+    wts.table = _leaf(wts.table)
+    wts.base = [_leaf(w) for w in wts.base]
+    if wts.head_tcnn is not None:
+        wts.head_tcnn = [_leaf(w) for w in wts.head_tcnn]
+    if getattr(wts, "head_layers", None):
+        wts.head_layers = [(_leaf(w), _leaf(b)) for w, b in wts.head_layers]
+    return wts
+
+
+@pytest.mark.gpu
+def test_ngp_field_training_route_matches_fused_forward_and_oracle_gradients(device):
+    from quadraturefields_amd import synthetic
+    from quadraturefields_amd.radiance_fields.ngp import NGPRadianceField
+    field = NGPRadianceField(aabb=[-1.5] * 3 + [1.5] * 3, log2_hashmap_size=14)
+    field.load_state_dict(synthetic.seeded_ngp_state(14, field.mlp_base.grid.n_rows), strict=False)
+    wts = _oracle_leaves(helpers.oracle_ngp_weights(field))
+    field = field.to(device)
+    x, d = helpers.random_points(4000, seed=5)
+    g = torch.Generator().manual_seed(9)
+    t_rgb, t_sig = torch.rand(4000, 3, generator=g), torch.rand(4000, 1, generator=g)
+
+    def loss_fn(rgb, sigma, t_rgb, t_sig):
+        return ((rgb - t_rgb) ** 2).mean() + 1e-2 * ((torch.log1p(sigma) - t_sig) ** 2).mean()
+
+    rgb_f, sig_f = field(x.to(device), d.to(device))                  # fused kernel (autograd off by default)
+    with torch.enable_grad():
+        rgb_t, sig_t = field(x.to(device), d.to(device))
+        assert rgb_t.requires_grad and sig_t.requires_grad
+        loss_fn(rgb_t, sig_t, t_rgb.to(device), t_sig.to(device)).backward()
+        rgb_o, sig_o = ofields.ngp_forward(x, d, wts)
+        loss_fn(rgb_o, sig_o, t_rgb, t_sig).backward()
+    assert _close(rgb_t, rgb_f, atol=2e-6, rtol=0)[0]
+    assert torch.allclose(sig_t, sig_f, rtol=2e-5, atol=1e-6)
+    assert _close(rgb_t, rgb_o, atol=2e-6, rtol=0)[0]
+    gb = field.mlp_base.params.grad
+    n_net = field.mlp_base.n_network_params
+    for name, got, want in [
+        ("base mlp", gb[:n_net], torch.cat([w.grad.reshape(-1) for w in wts.base])),
+        ("table", gb[n_net:], wts.table.grad.reshape(-1)),
+        ("head mlp", field.mlp_head.params.grad, torch.cat([w.grad.reshape(-1) for w in wts.head_tcnn])),
+    ]:
+        ok, err, ref = _close(got, want, 3e-4)
+        assert ok and ref > 0, (name, err, ref)
+    # one optimiser step on the flat parameters lowers the loss (the reference trains these with Adam)
+    opt = torch.optim.Adam(field.parameters(), lr=1e-2)
+    with torch.enable_grad():
+        losses = []
+        for _ in range(5):
+            opt.zero_grad()
+            rgb_t, sig_t = field(x.to(device), d.to(device))
+            loss = loss_fn(rgb_t, sig_t, t_rgb.to(device), t_sig.to(device))
+            loss.backward()
+            opt.step()
+            losses.append(float(loss.detach()))
+    assert losses[-1] < losses[0]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bg", ["white", "black", "custom"])
+def test_sg_field_through_compositing_backward_vs_oracle(device, bg):
+    """The finetune loss path (train_finetune.py:489-533): SG field -> derive_properties -> image loss."""
+    from quadraturefields_amd import synthetic, utils
+    from quadraturefields_amd.radiance_fields.ngp import NGPRadianceFieldSGNew
+    field = NGPRadianceFieldSGNew(aabb=[-1.5] * 3 + [1.5] * 3, log2_hashmap_size=13, use_viewdirs=False)
+    field.load_state_dict(synthetic.seeded_ngp_state(13, field.mlp_base.grid.n_rows, sg_lobes=field.num_g_lobes), strict=False)
+    wts = _oracle_leaves(helpers.oracle_ngp_weights(field))
+    field = field.to(device)
+    n_rays = 300
+    ridx, _ = helpers.packed_segments(n_rays, 12, seed=4)
+    n = ridx.shape[0]
+    x, d = helpers.random_points(n, seed=6, outside_frac=0.02)
+    g = torch.Generator().manual_seed(2)
+    depth = torch.rand(n, generator=g).float() * 4
+    target = torch.rand(n_rays, 3, generator=g)
+    bk = torch.tensor([0.2, 0.5, 0.7])
+    boundary = ov.mark_pack_boundaries(ridx)
+    scale = 30.0                                                     # sigma * 0.005 of order 1
+
+    def image_loss(rgb, alpha, dep, tgt):
+        return ((rgb - tgt) ** 2).mean() + 0.1 * (alpha ** 2).mean() + 0.05 * dep.mean()
+
+    with torch.enable_grad():
+        rgb_s, sig = field(x.to(device), d.to(device))
+        dep_d = _leaf(depth.to(device))
+        rgb, alpha, _, dep, w = utils.derive_properties(rgb_s, sig * scale, dep_d, 0.005, boundary.to(device),
+                                                        ridx.to(device), render_bkgd=bk.to(device), bg_color=bg, N=n_rays)
+        assert rgb.requires_grad and not w.requires_grad
+        image_loss(rgb, alpha, dep, target.to(device)).backward()
+        rgb_so, sig_o = ofields.sg_forward(x, d, wts)
+        dep_o = _leaf(depth)
+        rgb_o, alpha_o, _, depo, _ = ov.derive_properties(rgb_so, sig_o.reshape(-1) * scale, dep_o, 0.005, boundary, ridx,
+                                                          render_bkgd=bk, bg_color=bg, N=n_rays)
+        image_loss(rgb_o, alpha_o, depo, target).backward()
+    assert _close(rgb, rgb_o, atol=3e-6, rtol=0)[0]
+    ok, err, ref = _close(dep_d.grad, dep_o.grad, 1e-4)
+    assert ok and ref > 0, (err, ref)
+    n_net = field.mlp_base.n_network_params
+    gb = field.mlp_base.params.grad
+    pairs = [("table", gb[n_net:], wts.table.grad.reshape(-1)),
+             ("base mlp", gb[:n_net], torch.cat([w_.grad.reshape(-1) for w_ in wts.base]))]
+    for k, (wo, bo) in zip(("layers.0", "layers.1", "lout"), wts.head_layers):
+        mod = dict(field.mlp_head.named_modules())[k]
+        pairs += [(k + ".weight", mod.weight.grad, wo.grad), (k + ".bias", mod.bias.grad, bo.grad)]
+    for name, got, want in pairs:
+        ok, err, ref = _close(got, want, 5e-4)
+        assert ok and ref > 0, (name, err, ref)
+
+
+@pytest.mark.gpu
+def test_derive_properties_backward_direct(device):
+    """Compositing backward alone, with per-sample deltas, empty rays and a zero-density ray."""
+    from quadraturefields_amd import utils
+    n_rays = 500
+    ridx, counts = helpers.packed_segments(n_rays, 25, seed=11)
+    n = ridx.shape[0]
+    g = torch.Generator().manual_seed(1)
+    color, sigma = torch.rand(n, 3, generator=g), torch.rand(n, generator=g) * 60
+    first = int(torch.nonzero(counts)[0])
+    sigma[ridx == first] = 0.0
+    depth, deltas = torch.rand(n, generator=g) * 5, torch.rand(n, generator=g) * 0.02
+    boundary = ov.mark_pack_boundaries(ridx)
+    g_rgb, g_a, g_d = torch.randn(n_rays, 3, generator=g), torch.randn(n_rays, 1, generator=g), torch.randn(n_rays, 1, generator=g)
+    with torch.enable_grad():
+        co, so, do = _leaf(color), _leaf(sigma), _leaf(depth)
+        r, a, _, dd, _ = ov.derive_properties(co, so, do, deltas, boundary, ridx, bg_color="white", N=n_rays)
+        torch.autograd.backward([r, a, dd], [g_rgb, g_a, g_d])
+        cd, sd, dd_ = _leaf(color.to(device)), _leaf(sigma.to(device)), _leaf(depth.to(device))
+        r2, a2, _, d2, _ = utils.derive_properties(cd, sd, dd_, deltas.to(device), boundary.to(device), ridx.to(device),
+                                                   bg_color="white", N=n_rays)
+        torch.autograd.backward([r2, a2, d2], [g_rgb.to(device), g_a.to(device), g_d.to(device)])
+    for name, got, want in (("color", cd.grad, co.grad), ("sigma", sd.grad, so.grad), ("depth", dd_.grad, do.grad)):
+        ok, err, ref = _close(got, want, 2e-5)
+        assert ok and ref > 0, (name, err, ref)
+
+
+@pytest.mark.gpu
+def test_deformation_field_gradients(device):
+    """Field.forward(return_grad=True) (examples/field.py:206-238): d field / d x and parameter gradients."""
+    from quadraturefields_amd import synthetic
+    from quadraturefields_amd.field import Field
+    f = Field(scale=1.5, back_prop=1, log2_T=13, L=16, max_res=512, hidden_size=32, nl="relu")
+    f.load_state_dict(synthetic.seeded_deform_state(f.xyz_encoder.grid.n_params), strict=False)
+    wts = helpers.oracle_deform_weights(f)
+    wts.table = _leaf(wts.table)
+    wts.layers = [(_leaf(w), _leaf(b)) for w, b in wts.layers]
+    f = f.to(device)
+    x, _ = helpers.random_points(2000, aabb_half=1.4, seed=8, outside_frac=0.0)
+    fused = f(x.to(device), return_grad=False)[0]
+    with torch.enable_grad():
+        xd = x.to(device)
+        val, grad = f(xd, return_grad=True)
+        (val.sum() + (grad ** 2).sum().detach()).backward()
+        xo = _leaf(x)
+        vo = ofields.deform_field(xo, wts)
+        go = torch.autograd.grad(vo.sum(), xo, retain_graph=True)[0]
+        vo.sum().backward()
+    assert _close(val, fused, atol=2e-6, rtol=0)[0] and _close(val, vo, atol=2e-6, rtol=0)[0]
+    ok, err, ref = _close(grad, go, 1e-4)
+    assert ok and ref > 0, (err, ref)
+    ok, err, ref = _close(f.xyz_encoder.params.grad.reshape(-1, 2), wts.table.grad, 1e-4)
+    assert ok and ref > 0, (err, ref)
+    ok, err, ref = _close(f.decoder_field.lout.weight.grad, wts.layers[2][0].grad, 1e-4)
+    assert ok and ref > 0, (err, ref)

@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--order", default="coherent", choices=["ray", "tile", "tile4", "random", "coherent"])
     ap.add_argument("--stage", default="field", choices=["field", "traverse", "raster", "pack", "composite", "frame"])
     args = ap.parse_args()
+    torch.set_grad_enabled(False)
     dev = torch.device("cuda:0")
     from quadraturefields_amd import synthetic
     mesh, mi, field = bench.build_scene(dev)
