@@ -153,7 +153,7 @@ def to_loader_tensors(sample):
 
 def sampling_indexing(points, origins, vectors, index_ray, depth, index_tri, render_step_size=0.005):
     """mesh_utils.py:389-412: lexsort by (ray, depth), boundaries, constant deltas (B-4)."""
-    order = torch.from_numpy(np.lexsort((depth.numpy(), index_ray.numpy())))
+    order = torch.from_numpy(np.lexsort((depth.detach().numpy(), index_ray.numpy())))
     index_tri, index_ray = index_tri[order], index_ray[order]
     points, depth, origins, vectors = points[order], depth[order], origins[order], vectors[order]
     boundary = volrend.mark_pack_boundaries(index_ray)
@@ -197,6 +197,22 @@ def render_image_finetune(ngp: fields.NGPWeights, deform: Optional[fields.Deform
         rgbs, sigmas.squeeze(-1), depth, deltas, boundary, index_ray,
         bg_color=bg_color, render_bkgd=render_bkgd, N=n_rays)
     return rgb, alpha, dep, xyzs.shape[0], weights, points, index_ray, index_tri
+
+
+def barycentric_vertex_samples(tri_vertices: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+    """utils.py:543-546: a random point of each sample's triangle, weights w [S,3] ~ U(0,1) (not normalised
+    beforehand): sum(v * w) / (sum(w) + 1e-6).  tri_vertices [S,3,3]."""
+    w = w[..., None]
+    return torch.sum(tri_vertices * w, dim=1) / (torch.sum(w, dim=1) + 1e-6)
+
+
+def finetune_regulariser(deform: fields.DeformWeights, xyzs: torch.Tensor, vertex_points: torch.Tensor,
+                         scaling: float) -> torch.Tensor:
+    """utils.py:549-566,583: mean(dv^2) + mean((dv_vertex - dv.detach())^2), dv = tanh(field)*scaling broadcast
+    into 3 components (B-15).  Training only; differentiable w.r.t. the deformation field's weights."""
+    dv_v = torch.tanh(fields.deform_field(vertex_points, deform)).expand(-1, 3) * scaling
+    dv = torch.tanh(fields.deform_field(xyzs, deform)).expand(-1, 3) * scaling
+    return ((dv ** 2).mean() + ((dv_v - dv.detach()) ** 2).mean()).reshape(1)
 
 
 def render_image_bake_texture(data, n_rays: int, vertices64: np.ndarray, faces: np.ndarray,

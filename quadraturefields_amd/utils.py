@@ -133,7 +133,18 @@ def _to_device(data, device):
             index_tri.to(device).long(), origins.to(device))
 
 
-@torch.no_grad()
+def _module_trains(module) -> bool:
+    return module is not None and torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters())
+
+
+def _faces_on_device(mesh_intersect) -> torch.Tensor:
+    cache = getattr(mesh_intersect, "_faces_dev", None)
+    if cache is None or cache[0] is not mesh_intersect.mesh.faces:
+        faces = torch.from_numpy(np.ascontiguousarray(mesh_intersect.mesh.faces, dtype=np.int64)).to(mesh_intersect.device)
+        mesh_intersect._faces_dev = cache = (mesh_intersect.mesh.faces, faces)
+    return cache[1]
+
+
 def render_image_finetune_with_occgrid(
     radiance_field: torch.nn.Module, field_net: Optional[torch.nn.Module], estimator, rays: Rays, data,
     near_plane: float = 0.0, far_plane: float = 1e10, render_step_size: float = 1e-3,
@@ -145,15 +156,33 @@ def render_image_finetune_with_occgrid(
     ``order`` (extension, optional): coherent processing order from ``RayIntersector.coherent_order``.
 
     Returns the reference's 9-tuple (colors, opacities, depths, n_samples, weights, positions, index_ray,
-    loss, index_tri).  ``loss`` is the deformation regulariser of :583 and is returned as zeros: it needs the
-    random barycentric vertex samples of :543-546, which only matter for training."""
+    loss, index_tri).
+
+    Inference (``torch.no_grad()``, as the reference's eval loop runs it): fused kernels throughout; ``loss`` is
+    returned as zeros (the regulariser needs the random barycentric samples of :543-546, which only matter for
+    training, and the ``torch.rand`` call of :545 is not made).
+    Training (autograd recording and ``field_net`` / ``radiance_field`` have trainable parameters): the
+    deformation, the re-sort gather, the field and the compositing stay in the autograd graph and ``loss`` is the
+    regulariser of :583, ``mean(dv^2) + mean((dv_vertex - dv.detach())^2)``."""
     rays, rays_shape, num_rays = _flatten_rays(rays)
     device = mesh_intersect.device
     xyzs, dirs, index_ray, ts, index_tri, origins = _to_device(data, device)
-    xyzs, ts = xyzs.clone(), ts.clone()
     dh = None
-    if field_net is not None and scaling != 0:
-        f = field_net(xyzs, return_grad=False)[0].reshape(-1).contiguous()
+    loss = torch.zeros(1, device=device)
+    if _module_trains(field_net):
+        tri_v = mesh_intersect.vertices[_faces_on_device(mesh_intersect)[index_tri]][:, :, 0:3]        # [S,3,3]
+        w = torch.rand((xyzs.shape[0], 3), device=device)[..., None]
+        verts = torch.sum(tri_v * w, dim=1) / (torch.sum(w, dim=1) + 1e-6)
+        del_vector_v = torch.tanh(field_net(verts, return_grad=False)[0]).expand(-1, 3) * scaling
+        del_vector = torch.tanh(field_net(xyzs, return_grad=False)[0]).expand(-1, 3) * scaling     # [S,1] -> 3 (B-15)
+        del_delta = (del_vector * dirs).sum(-1, keepdim=True)
+        dh = del_delta * dirs
+        xyzs = xyzs + dh
+        ts = ts + del_delta.view(-1)
+        loss = ((del_vector ** 2).mean() + ((del_vector_v - del_vector.detach()) ** 2).mean()).reshape(1)
+    elif field_net is not None and scaling != 0:
+        xyzs, ts = xyzs.clone(), ts.clone()
+        f = field_net(xyzs, return_grad=False)[0].detach().reshape(-1).contiguous()
         before = xyzs.clone() if mesh_finetune is not None else None
         _C.check(_C.lib().qf_apply_deformation(_C.ptr(f), float(scaling), _C.ptr(_C.f32c(dirs)), _C.ptr(xyzs),
                                                _C.ptr(ts), xyzs.shape[0], _C.stream()), "qf_apply_deformation")
@@ -172,8 +201,7 @@ def render_image_finetune_with_occgrid(
     if mesh_finetune is not None:
         if dh is None:
             dh = torch.zeros_like(xyzs)
-        mesh_finetune.update_d(dh, weights[:, 0], index_tri)
-    loss = torch.zeros(1, device=device)
+        mesh_finetune.update_d(dh.detach(), weights[:, 0].detach(), index_tri)
     return (rgb.view((*rays_shape[:-1], -1)), opacity.view((*rays_shape[:-1], -1)),
             depth_img.view((*rays_shape[:-1], -1)), xyzs.shape[0], weights, points, index_ray, loss, index_tri)
 

@@ -247,3 +247,74 @@ def test_deformation_field_gradients(device):
     assert ok and ref > 0, (err, ref)
     ok, err, ref = _close(f.decoder_field.lout.weight.grad, wts.layers[2][0].grad, 1e-4)
     assert ok and ref > 0, (err, ref)
+
+
+@pytest.mark.gpu
+def test_finetune_training_step_matches_oracle(device):
+    """One optimisation step of the finetune stage (train_finetune.py:465-533): random barycentric samples,
+    deformation along the rays, re-sort, SH field, compositing, image loss + regulariser; gradients of both
+    networks against autograd through the oracle's restatement; MeshFinetune.update_d bookkeeping."""
+    from oracle import meshpath as om
+    from quadraturefields_amd import synthetic, utils
+    from quadraturefields_amd.datasets.utils import Rays
+    from quadraturefields_amd.field import Field
+    from quadraturefields_amd.mesh_utils import MeshFinetune, MeshIntersection
+    from quadraturefields_amd.radiance_fields.ngp import NGPRadianceField
+    mesh = synthetic.shell_mesh(n_shells=3, subdivisions=3)
+    mi = MeshIntersection(mesh, simplify_mesh=False, scale=1.0, num_intersections=25)
+    field = NGPRadianceField(aabb=[-1.5] * 3 + [1.5] * 3, log2_hashmap_size=13)
+    field.load_state_dict(synthetic.seeded_ngp_state(13, field.mlp_base.grid.n_rows), strict=False)
+    net = Field(scale=1.5, precision=16, log2_T=13, L=16, max_res=512, min_res=16, output_dim=1, hidden_size=32,
+                num_features=2, back_prop=False, nl="relu")
+    net.load_state_dict(synthetic.seeded_deform_state(net.xyz_encoder.grid.n_params), strict=False)
+    wts = _oracle_leaves(helpers.oracle_ngp_weights(field))
+    dwts = helpers.oracle_deform_weights(net)
+    dwts.table = _leaf(dwts.table)
+    dwts.layers = [(_leaf(w_), _leaf(b_)) for w_, b_ in dwts.layers]
+    field, net = field.to(device), net.to(device)
+    w = h = 48
+    c2w = synthetic.orbit_cameras(1, seed=3)[0]
+    o, d = synthetic.camera_rays(c2w, synthetic.lego_focal(800) * w / 800.0, w, h)
+    data = om.to_loader_tensors(mi.sampling_raytrace_numpy(d.numpy(), o.numpy(), 0))
+    n = data[0].shape[0]
+    scaling = 0.0434
+    target = torch.rand(w * h, 3, generator=torch.Generator().manual_seed(1))
+    finetune = MeshFinetune(mesh.vertices, mesh.faces, scaling, device=device)
+    rays = Rays(origins=o, viewdirs=d)
+    with torch.enable_grad():
+        torch.manual_seed(123)
+        out = utils.render_image_finetune_with_occgrid(field, net, None, rays, data, render_step_size=5e-3,
+                                                       mesh_intersect=mi, mesh_finetune=finetune, scaling=scaling)
+        rgb, loss_reg = out[0].reshape(-1, 3), out[7]
+        assert rgb.requires_grad and loss_reg.requires_grad and loss_reg.shape == (1,)
+        (torch.nn.functional.smooth_l1_loss(rgb, target.to(device)) + loss_reg.sum()).backward()
+        # the same uniform draws the product made (same device generator, same seed, same shape)
+        torch.manual_seed(123)
+        bw = torch.rand((n, 3), device=device).cpu()
+        xyzs, dirs, index_ray, ts, index_tri, origins = data
+        tri_v = torch.from_numpy(mesh.vertices.astype(np.float32))[torch.from_numpy(mesh.faces.astype(np.int64))[index_tri]]
+        verts = om.barycentric_vertex_samples(tri_v, bw)
+        reg_o = om.finetune_regulariser(dwts, xyzs, verts, scaling)
+        rgb_o = om.render_image_finetune(wts, dwts, data, w * h, scaling=scaling)[0]
+        (torch.nn.functional.smooth_l1_loss(rgb_o, target) + reg_o.sum()).backward()
+    assert (rgb.detach().cpu() - rgb_o.detach()).abs().max().item() <= 3e-4
+    assert abs(float(loss_reg.detach()) - float(reg_o.detach())) <= 1e-6 * max(1.0, abs(float(reg_o.detach())))
+    n_net = field.mlp_base.n_network_params
+    pairs = [("ngp table", field.mlp_base.params.grad[n_net:], wts.table.grad.reshape(-1)),
+             ("ngp base", field.mlp_base.params.grad[:n_net], torch.cat([w_.grad.reshape(-1) for w_ in wts.base])),
+             ("ngp head", field.mlp_head.params.grad, torch.cat([w_.grad.reshape(-1) for w_ in wts.head_tcnn])),
+             ("deform table", net.xyz_encoder.params.grad.reshape(-1, 2), dwts.table.grad),
+             ("deform l0", net.decoder_field.layers[0].weight.grad, dwts.layers[0][0].grad),
+             ("deform out bias", net.decoder_field.lout.bias.grad, dwts.layers[2][1].grad)]
+    # The deformed positions differ by an ulp between the two sides, so a handful of points next to a cell face
+    # scatter into neighbouring rows: compare in the L2 norm (and the maximum loosely), not entry by entry.
+    for name, got, want in pairs:
+        got, want = got.detach().cpu().double(), want.detach().double()
+        rel = float((got - want).norm() / want.norm())
+        assert rel <= 1e-2 and float((got - want).abs().max()) <= 2e-2 * float(want.abs().max()), (name, rel)
+    # update_d accumulated |dh| * w per triangle (mesh_utils.py:126-134)
+    assert float(finetune.cache_w.sum()) > 1.0 and float(finetune.cache_d.abs().sum()) > 0.0
+    # inference through the same entry point is unchanged by the training step's bookkeeping
+    img = utils.render_image_finetune_with_occgrid(field, net, None, rays, data, render_step_size=5e-3,
+                                                   mesh_intersect=mi, scaling=scaling)
+    assert not img[0].requires_grad and (img[0].reshape(-1, 3).cpu() - rgb_o.detach()).abs().max().item() <= 3e-4
