@@ -71,7 +71,7 @@ class Stages:
         from quadraturefields_amd import utils
         n_rays = o.shape[0]
         ri = self.mi.rayintersector
-        if cam is not None:
+        if ri.want_raster(cam):
             hits = self._timed("traverse", lambda: ri._hits_raster(o, d, MAX_HITS, cam, sort_lists=False) + (o, d), record)
         else:
             hits = self._timed("traverse", lambda: ri._hits_bvh(o, d, MAX_HITS, W) + (None, o, d), record)
@@ -91,6 +91,7 @@ class Stages:
         if overflow is not None:      # one readback: sample total + raster overflow flag
             total, ovf = torch.stack([csum[-1], overflow[0].to(torch.int64)]).tolist()
             if ovf:
+                self.mi.rayintersector.raster_overflowed()
                 hit_tri, hit_t, hit_count = self.mi.rayintersector._hits_bvh(o, d, MAX_HITS, W)
                 csum = torch.cumsum(hit_count.to(torch.int64), dim=0)
                 total = int(csum[-1].item())

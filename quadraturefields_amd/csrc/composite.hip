@@ -28,46 +28,95 @@ __global__ void fill_background_kernel(int64_t n_rays, float bg, float *rgb, flo
     }
 }
 
-// One lane per sample; the lane that sits on a ray's first sample integrates the whole ray.
-__global__ void derive_properties_kernel(const float *rgb_s, const float *sigma, const float *depth_s,
-                                         const float *deltas, float delta_const, const int64_t *index_ray,
-                                         int64_t n, int bg_mode, const float *bkgd, float *out_rgb,
-                                         float *out_alpha, float *out_depth, float *weights)
+// derive_properties: a block owns DP_CHUNK consecutive samples.  It stages them (plus a halo, so that rays starting
+// near the end of the chunk finish without leaving LDS) with coalesced loads; the lane that sits on a ray's first
+// sample then integrates the whole ray sequentially out of LDS -- same summation order as a plain per-ray loop, so
+// the result does not depend on the chunking -- and the weights go back coalesced.  Rays longer than the halo
+// (occupancy-grid marching) finish from global memory.
+constexpr int DP_THREADS = 256;
+constexpr int DP_CHUNK = 1024;
+constexpr int DP_HALO = 64;
+constexpr int DP_STAGE = DP_CHUNK + DP_HALO;
+
+__global__ __launch_bounds__(DP_THREADS) void derive_properties_kernel(
+    const float *rgb_s, const float *sigma, const float *depth_s, const float *deltas, float delta_const,
+    const int64_t *index_ray, int64_t n, int bg_mode, const float *bkgd, float *out_rgb, float *out_alpha,
+    float *out_depth, float *weights)
 {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t ray = index_ray[i];
-        if (i != 0 && index_ray[i - 1] == ray) continue;
-        float cum = 0.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f, cd = 0.0f, ca = 0.0f;
-        for (int64_t j = i; j < n && index_ray[j] == ray; ++j) {
-            const float tau = sigma[j] * (deltas ? deltas[j] : delta_const);
-            const float w = expf(-cum) * (1.0f - expf(-tau));
-            cum += tau;
-            weights[j] = w;
-            cr += w * rgb_s[j * 3 + 0];
-            cg += w * rgb_s[j * 3 + 1];
-            cb += w * rgb_s[j * 3 + 2];
-            cd += w * depth_s[j];
-            ca += w;
+    __shared__ float s_tau[DP_STAGE];
+    __shared__ float s_rgb[3 * DP_STAGE];
+    __shared__ float s_dep[DP_STAGE];
+    __shared__ float s_w[DP_STAGE];
+    __shared__ int64_t s_ray[DP_STAGE + 1];          // [0]: the sample just before the chunk
+    __shared__ uint8_t s_mine[DP_STAGE];             // weight computed by this block
+    const int64_t n_chunks = (n + DP_CHUNK - 1) / DP_CHUNK;
+    for (int64_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+        const int64_t b0 = chunk * DP_CHUNK;
+        const int staged = (int)((n - b0 < DP_STAGE) ? (n - b0) : DP_STAGE);
+        const int own = (int)((n - b0 < DP_CHUNK) ? (n - b0) : DP_CHUNK);
+        for (int k = threadIdx.x; k < staged; k += DP_THREADS) {
+            s_tau[k] = sigma[b0 + k] * (deltas ? deltas[b0 + k] : delta_const);
+            s_dep[k] = depth_s[b0 + k];
+            s_ray[k + 1] = index_ray[b0 + k];
+            s_mine[k] = 0;
         }
-        float r, g, b;
-        if (bg_mode == QF_BG_WHITE) {          // (1 - a) + a * sum(w c): the double-alpha quirk (B-1)
-            r = (1.0f - ca) + ca * cr;
-            g = (1.0f - ca) + ca * cg;
-            b = (1.0f - ca) + ca * cb;
-        } else if (bg_mode == QF_BG_BLACK) {
-            r = ca * cr;
-            g = ca * cg;
-            b = ca * cb;
-        } else {
-            r = ca * cr + (1.0f - ca) * bkgd[0];
-            g = ca * cg + (1.0f - ca) * bkgd[1];
-            b = ca * cb + (1.0f - ca) * bkgd[2];
+        for (int k = threadIdx.x; k < 3 * staged; k += DP_THREADS) s_rgb[k] = rgb_s[b0 * 3 + k];
+        if (threadIdx.x == 0) s_ray[0] = b0 > 0 ? index_ray[b0 - 1] : 0;
+        __syncthreads();
+        for (int k = threadIdx.x; k < own; k += DP_THREADS) {
+            const int64_t ray = s_ray[k + 1];
+            if (b0 + k != 0 && s_ray[k] == ray) continue;
+            float cum = 0.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f, cd = 0.0f, ca = 0.0f;
+            int j = k;
+            for (; j < staged && s_ray[j + 1] == ray; ++j) {
+                const float tau = s_tau[j];
+                const float w = expf(-cum) * (1.0f - expf(-tau));
+                cum += tau;
+                s_w[j] = w;
+                s_mine[j] = 1;
+                cr += w * s_rgb[j * 3 + 0];
+                cg += w * s_rgb[j * 3 + 1];
+                cb += w * s_rgb[j * 3 + 2];
+                cd += w * s_dep[j];
+                ca += w;
+            }
+            if (j == staged) {                       // the ray runs past the staged window
+                for (int64_t g = b0 + staged; g < n && index_ray[g] == ray; ++g) {
+                    const float tau = sigma[g] * (deltas ? deltas[g] : delta_const);
+                    const float w = expf(-cum) * (1.0f - expf(-tau));
+                    cum += tau;
+                    weights[g] = w;
+                    cr += w * rgb_s[g * 3 + 0];
+                    cg += w * rgb_s[g * 3 + 1];
+                    cb += w * rgb_s[g * 3 + 2];
+                    cd += w * depth_s[g];
+                    ca += w;
+                }
+            }
+            float r, g, b;
+            if (bg_mode == QF_BG_WHITE) {          // (1 - a) + a * sum(w c): the double-alpha quirk (B-1)
+                r = (1.0f - ca) + ca * cr;
+                g = (1.0f - ca) + ca * cg;
+                b = (1.0f - ca) + ca * cb;
+            } else if (bg_mode == QF_BG_BLACK) {
+                r = ca * cr;
+                g = ca * cg;
+                b = ca * cb;
+            } else {
+                r = ca * cr + (1.0f - ca) * bkgd[0];
+                g = ca * cg + (1.0f - ca) * bkgd[1];
+                b = ca * cb + (1.0f - ca) * bkgd[2];
+            }
+            out_rgb[ray * 3 + 0] = r;
+            out_rgb[ray * 3 + 1] = g;
+            out_rgb[ray * 3 + 2] = b;
+            out_alpha[ray] = ca;
+            out_depth[ray] = cd;
         }
-        out_rgb[ray * 3 + 0] = r;
-        out_rgb[ray * 3 + 1] = g;
-        out_rgb[ray * 3 + 2] = b;
-        out_alpha[ray] = ca;
-        out_depth[ray] = cd;
+        __syncthreads();
+        for (int k = threadIdx.x; k < staged; k += DP_THREADS)
+            if (s_mine[k]) weights[b0 + k] = s_w[k];
+        __syncthreads();
     }
 }
 
@@ -247,8 +296,11 @@ extern "C" int qf_derive_properties(const float *rgb_s, const float *sigma, cons
     }
     if (n == 0) return QF_OK;
     if (!rgb_s || !sigma || !depth || !index_ray || !weights) return QF_ERR_INVALID_ARGUMENT;
-    QF_SIMPLE_LAUNCH(derive_properties_kernel, n, rgb_s, sigma, depth, deltas, delta_const, index_ray, n, (int)bg_mode,
-                     bkgd, out_rgb, out_alpha, out_depth, weights);
+    const int64_t n_chunks = (n + DP_CHUNK - 1) / DP_CHUNK;
+    hipLaunchKernelGGL(derive_properties_kernel, dim3((unsigned)(n_chunks < 65536 ? n_chunks : 65536)), dim3(DP_THREADS), 0,
+                       qf_stream(stream), rgb_s, sigma, depth, deltas, delta_const, index_ray, n, (int)bg_mode, bkgd, out_rgb,
+                       out_alpha, out_depth, weights);
+    QF_LAUNCH_CHECK();
     return QF_OK;
 }
 

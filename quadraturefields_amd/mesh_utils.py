@@ -47,6 +47,7 @@ class RayIntersector:
         self.max_hits = int(max_hits)
         self.device = torch.device(device)
         self.last_order = None           # coherent processing order of the most recent image-shaped sample_device()
+        self._raster_backoff = 0         # frames left to skip the camera-coherent intersector after an overflow
         self._handle = ctypes.c_void_p()
         tri = np.ascontiguousarray(mesh.vertices.astype(np.float32)[mesh.faces].reshape(-1, 9))
         with torch.cuda.device(self.device):
@@ -75,6 +76,21 @@ class RayIntersector:
         else:
             tri = np.ascontiguousarray(v.reshape(-1, 3)[self.mesh.faces].reshape(-1, 9))
         _C.check(_C.lib().qf_bvh_refit(self._handle, tri.ctypes.data_as(ctypes.c_void_p), tri.shape[0]), "qf_bvh_refit")
+
+    #: After a frame on which some pixel collected more than K candidates (the camera-coherent pass is then wasted and
+    #: the BVH answers), go straight to the BVH for this many frames before trying the camera-coherent pass again.
+    RASTER_BACKOFF = 16
+
+    def want_raster(self, camera) -> bool:
+        if camera is None:
+            return False
+        if self._raster_backoff > 0:
+            self._raster_backoff -= 1
+            return False
+        return True
+
+    def raster_overflowed(self) -> None:
+        self._raster_backoff = self.RASTER_BACKOFF
 
     def _alloc_hits(self, n, k):
         return (torch.empty((n, k), dtype=torch.int32, device=self.device),
@@ -110,10 +126,12 @@ class RayIntersector:
         if o.shape != d.shape:
             raise ValueError("origins and vectors must have the same shape")
         if camera is not None:
+            image_width = camera.width
+        if self.want_raster(camera):
             hit_tri, hit_t, hit_count, overflow = self._hits_raster(o, d, k, camera)
             if int(overflow.item()) == 0:
                 return hit_tri, hit_t, hit_count, o, d
-            image_width = camera.width          # some ray has more than K candidates: exact K-nearest via the BVH
+            self.raster_overflowed()            # some ray has more than K candidates: exact K-nearest via the BVH
         hit_tri, hit_t, hit_count = self._hits_bvh(o, d, k, image_width)
         return hit_tri, hit_t, hit_count, o, d
 
@@ -134,6 +152,8 @@ class RayIntersector:
         if n == 0:
             return None
         if camera is not None:
+            image_width = camera.width
+        if self.want_raster(camera):
             hit_tri, hit_t, hit_count, overflow = self._hits_raster(o, d, k, camera, sort_lists=False)
         else:
             hit_tri, hit_t, hit_count = self._hits_bvh(o, d, k, image_width)
@@ -143,6 +163,7 @@ class RayIntersector:
         if overflow is not None:
             total, ovf = torch.stack([csum[-1], overflow[0].to(torch.int64)]).tolist()
             if ovf:
+                self.raster_overflowed()
                 hit_tri, hit_t, hit_count = self._hits_bvh(o, d, k, camera.width)
                 csum = torch.cumsum(hit_count.to(torch.int64), dim=0)
                 total = int(csum[-1].item())
@@ -162,7 +183,7 @@ class RayIntersector:
                                           _C.ptr(hit_count), _C.ptr(offset), _C.ptr(xyz), _C.ptr(dirs),
                                           _C.ptr(index_ray), _C.ptr(depth), _C.ptr(index_tri), _C.ptr(org),
                                           _C.stream()), "qf_pack_samples")
-        width = camera.width if camera is not None else int(image_width)
+        width = int(image_width)
         self.last_order = (self.coherent_order(hit_count, offset, total, width)
                            if width > 0 and n % width == 0 else None)
         return [xyz, dirs, index_ray, depth, index_tri, org]
