@@ -199,8 +199,14 @@ struct RasterCam {
     int w, h;
 };
 
-constexpr int kRasterLanes = 8;   // lanes cooperating on one triangle: 4 along x, 2 along y
+// kRasterLanes lanes cooperate on one triangle and share its screen box round-robin.
+// Guard band in pixels around the projected triangle.  A pixel-centre ray that the fp32 Moller-Trumbore test accepts
+// lies, in exact arithmetic, within c * eps * f pixels of the projected triangle (numerator rounding over |det|,
+// c ~ 10, eps = 2^-24, f = focal length in pixels: ~1e-3 px at f = 1111, ~3e-3 px at f = 2700), and the projected
+// vertices carry ~1e-4 px of rounding.  0.25 px leaves two orders of magnitude.
+constexpr float kRasterGuard = 0.25f;
 
+template <int kRasterLanes>
 __global__ __launch_bounds__(256) void raster_kernel(const float4 *__restrict__ tris, int64_t n_tri, RasterCam cam,
                                                      const float *__restrict__ rays_o, const float *__restrict__ rays_d,
                                                      int max_hits, int32_t *__restrict__ hit_tri, float *__restrict__ hit_t,
@@ -216,6 +222,7 @@ __global__ __launch_bounds__(256) void raster_kernel(const float4 *__restrict__ 
     float minx = INFINITY, maxx = -INFINITY, miny = INFINITY, maxy = -INFINITY;
     int behind = 0;
     const float4 vs[3] = {a, b, c};
+    float sxs[3], sys[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         const float dx = vs[k].x - cam.cx, dy = vs[k].y - cam.cy, dz = vs[k].z - cam.cz;
@@ -223,40 +230,71 @@ __global__ __launch_bounds__(256) void raster_kernel(const float4 *__restrict__ 
         const float yc = cam.r01 * dx + cam.r11 * dy + cam.r21 * dz;
         const float zc = cam.r02 * dx + cam.r12 * dy + cam.r22 * dz;
         const float zv = -zc;                                           // depth along the viewing direction
-        if (!(zv > 1e-6f)) { ++behind; continue; }
+        if (!(zv > 1e-6f)) { ++behind; sxs[k] = sys[k] = 0.0f; continue; }
         const float sx = cam.fx * (xc / zv) + cam.px0;
         const float sy = -cam.fy * (yc / zv) + cam.py0;
+        sxs[k] = sx; sys[k] = sy;
         minx = fminf(minx, sx); maxx = fmaxf(maxx, sx);
         miny = fminf(miny, sy); maxy = fmaxf(maxy, sy);
     }
     if (behind == 3) return;                 // entirely behind the camera: t > 0 is impossible
     int x0, x1, y0, y1;
+    // Conservative 2-D reject before any memory is touched: a pixel can only be hit if it lies inside the projected
+    // triangle grown by the guard band, i.e. on the inner side of every edge line moved outwards by the guard
+    // (|edge| is over-estimated by its L1 length).  Skipped for triangles that straddle the camera plane or project
+    // (almost) edge-on, where the orientation is not reliable; the exact test below decides in every case.
+    float ea[3], eb[3], ec[3];
+    bool use_edges = false;
     if (behind > 0) {                        // straddles the camera plane: no finite box, test every pixel
         x0 = 0; y0 = 0; x1 = cam.w - 1; y1 = cam.h - 1;
     } else {
-        // +-1.5 pixel guard band covers the rounding of the projection and of the ray directions
-        x0 = (int)fmaxf(floorf(minx - 1.5f), 0.0f);
-        y0 = (int)fmaxf(floorf(miny - 1.5f), 0.0f);
-        x1 = (int)fminf(ceilf(maxx + 1.5f), (float)(cam.w - 1));
-        y1 = (int)fminf(ceilf(maxy + 1.5f), (float)(cam.h - 1));
-        if (!(maxx + 1.5f >= 0.0f) || !(maxy + 1.5f >= 0.0f) || !(minx - 1.5f <= (float)(cam.w - 1)) ||
-            !(miny - 1.5f <= (float)(cam.h - 1)))
+        x0 = (int)fmaxf(floorf(minx - kRasterGuard), 0.0f);
+        y0 = (int)fmaxf(floorf(miny - kRasterGuard), 0.0f);
+        x1 = (int)fminf(ceilf(maxx + kRasterGuard), (float)(cam.w - 1));
+        y1 = (int)fminf(ceilf(maxy + kRasterGuard), (float)(cam.h - 1));
+        if (!(maxx + kRasterGuard >= 0.0f) || !(maxy + kRasterGuard >= 0.0f) ||
+            !(minx - kRasterGuard <= (float)(cam.w - 1)) || !(miny - kRasterGuard <= (float)(cam.h - 1)))
             return;
-    }
-    for (int py = y0 + (sub >> 2); py <= y1; py += 2) {
-        for (int px = x0 + (sub & 3); px <= x1; px += 4) {
-            const int64_t ray = (int64_t)py * cam.w + px;
-            const float ox = rays_o[ray * 3], oy = rays_o[ray * 3 + 1], oz = rays_o[ray * 3 + 2];
-            const float dx = rays_d[ray * 3], dy = rays_d[ray * 3 + 1], dz = rays_d[ray * 3 + 2];
-            float t;
-            if (!mt_hit(a, b, c, ox, oy, oz, dx, dy, dz, &t)) continue;
-            const int slot = atomicAdd(&hit_count[ray], 1);
-            if (slot < max_hits) {
-                hit_t[ray * max_hits + slot] = t;
-                hit_tri[ray * max_hits + slot] = id;
-            } else {
-                atomicAdd(overflow, 1);      // more than max_hits candidates: the caller re-runs the exact K-nearest BVH path
+        const float area2 = (sxs[1] - sxs[0]) * (sys[2] - sys[0]) - (sys[1] - sys[0]) * (sxs[2] - sxs[0]);
+        if (fabsf(area2) > 1e-2f) {
+            use_edges = true;
+            const float sgn = area2 > 0.0f ? 1.0f : -1.0f;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int k1 = (k + 1) % 3;
+                const float ex = sxs[k1] - sxs[k], ey = sys[k1] - sys[k];
+                // E(p) = sgn * ((p.y - v.y) * ex - (p.x - v.x) * ey): positive at the opposite vertex.
+                // keep p iff E(p) >= -guard * (|ex| + |ey|) - slack
+                ea[k] = -sgn * ey;
+                eb[k] = sgn * ex;
+                ec[k] = -(ea[k] * sxs[k] + eb[k] * sys[k]) + (kRasterGuard + 0.05f) * (fabsf(ex) + fabsf(ey)) + 1e-3f;
             }
+        }
+    }
+    const int bw = x1 - x0 + 1;
+    const int total = bw * (y1 - y0 + 1);
+    int px = x0 + sub % bw, py = y0 + sub / bw;
+    for (int q = sub; q < total; q += kRasterLanes) {
+        const int cx_ = px, cy_ = py;
+        px += kRasterLanes;
+        while (px > x1) { px -= bw; ++py; }
+        if (use_edges) {
+            const float fx_ = (float)cx_, fy_ = (float)cy_;
+            if (ea[0] * fx_ + eb[0] * fy_ + ec[0] < 0.0f || ea[1] * fx_ + eb[1] * fy_ + ec[1] < 0.0f ||
+                ea[2] * fx_ + eb[2] * fy_ + ec[2] < 0.0f)
+                continue;
+        }
+        const int64_t ray = (int64_t)cy_ * cam.w + cx_;
+        const float ox = rays_o[ray * 3], oy = rays_o[ray * 3 + 1], oz = rays_o[ray * 3 + 2];
+        const float dx = rays_d[ray * 3], dy = rays_d[ray * 3 + 1], dz = rays_d[ray * 3 + 2];
+        float t;
+        if (!mt_hit(a, b, c, ox, oy, oz, dx, dy, dz, &t)) continue;
+        const int slot = atomicAdd(&hit_count[ray], 1);
+        if (slot < max_hits) {
+            hit_t[ray * max_hits + slot] = t;
+            hit_tri[ray * max_hits + slot] = id;
+        } else {
+            atomicAdd(overflow, 1);      // more than max_hits candidates: the caller re-runs the exact K-nearest BVH path
         }
     }
 }
@@ -667,12 +705,23 @@ extern "C" int qf_raster_intersect(const qf_bvh *bvh, const qf_camera *cam, cons
     rc.py0 = cam->cy - 0.5f;
     rc.w = cam->width; rc.h = cam->height;
     if (bvh->n_tri > 0) {
-        const int64_t threads = bvh->n_tri * kRasterLanes;
+        // Lanes per triangle: the per-triangle set-up (projection, edge equations) is replicated in every lane, so few
+        // lanes win for pixel-sized triangles (measured on the 983 040-triangle 800x800 frame: 1/2/4/8 lanes ->
+        // 0.33/0.25/0.22/0.23 ms); meshes that are coarse relative to the image get more lanes per triangle.
+        const int64_t pixels_per_tri = n_rays / bvh->n_tri;
+        const int lanes = pixels_per_tri > 64 ? 16 : (pixels_per_tri > 8 ? 8 : 4);
+        const int64_t threads = bvh->n_tri * lanes;
         const int64_t blocks = qf_div_up(threads, 256);
         if (blocks > 0x7fffffff) return QF_ERR_UNSUPPORTED;
-        hipLaunchKernelGGL(raster_kernel, dim3((unsigned)blocks), dim3(256), 0, st,
-                           reinterpret_cast<const float4 *>(bvh->d_tris), bvh->n_tri, rc, rays_o, rays_d, (int)max_hits,
-                           hit_tri, hit_t, hit_count, overflow);
+#define QF_RASTER_LAUNCH(L)                                                                                           \
+    hipLaunchKernelGGL(raster_kernel<L>, dim3((unsigned)blocks), dim3(256), 0, st,                                   \
+                       reinterpret_cast<const float4 *>(bvh->d_tris), bvh->n_tri, rc, rays_o, rays_d, (int)max_hits, \
+                       hit_tri, hit_t, hit_count, overflow)
+        switch (lanes) {
+        case 16: QF_RASTER_LAUNCH(16); break;
+        case 8: QF_RASTER_LAUNCH(8); break;
+        default: QF_RASTER_LAUNCH(4); break;
+        }
         QF_LAUNCH_CHECK();
     }
     if (sort_lists) {

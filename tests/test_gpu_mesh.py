@@ -265,3 +265,38 @@ def test_coherent_order_is_the_tile_rank_pixel_permutation(device):
     # rays that are not an image: no order
     mi.sampling_raytrace_device(d[:100], o[:100])
     assert mi.rayintersector.last_order is None
+
+
+@pytest.mark.parametrize("shells,subdiv,w,h,focal_scale", [
+    (12, 6, 800, 800, 1.0),        # BASELINE frame: pixel-sized triangles (4 lanes per triangle)
+    (12, 6, 1920, 1080, 1.0),      # 1080p, focal 2667 px
+    (4, 4, 640, 480, 1.0),         # ~15 pixels per triangle (8 lanes)
+    (3, 1, 256, 256, 1.0),         # triangles hundreds of pixels across (16 lanes)
+    (4, 3, 200, 200, 6.0),         # telephoto close-up: huge projected triangles, many off screen
+])
+def test_raster_guard_band_is_conservative(device, shells, subdiv, w, h, focal_scale):
+    """The camera-coherent intersector only tests pixels inside the projected triangle grown by a 0.25-pixel guard
+    band; whatever it skips must be a miss of the exact test.  Full-size frames from several viewpoints (orbit,
+    grazing close-up inside the shells) against the BVH traversal (itself pinned to brute force above): identical
+    triangle ids, distances and counts for every ray."""
+    from quadraturefields_amd import synthetic
+    from quadraturefields_amd.mesh_utils import RayIntersector, make_camera
+    mesh = synthetic.shell_mesh(n_shells=shells, subdivisions=subdiv)
+    ri = RayIntersector(mesh, max_hits=25)
+    focal = synthetic.lego_focal(w) * focal_scale
+    cams = [synthetic.orbit_cameras(3, seed=11)[k] for k in range(3)]
+    close = synthetic.orbit_cameras(1, seed=5)[0].clone()
+    close[:, 3] *= 0.3                                   # inside the outer shells, grazing views of the inner ones
+    cams.append(close)
+    compared = 0
+    for c2w in cams:
+        o, d = synthetic.camera_rays(c2w, focal, w, h, device=device)
+        tri_r, t_r, cnt_r, overflow = ri._hits_raster(o, d, 25, make_camera(c2w, focal, w, h))
+        if int(overflow.item()):
+            continue                                     # > 25 candidates somewhere: the product falls back to the BVH
+        tri_b, t_b, cnt_b = ri._hits_bvh(o, d, 25, w)
+        assert torch.equal(cnt_r, cnt_b)
+        assert torch.equal(tri_r, tri_b) and torch.equal(t_r, t_b)
+        assert int(cnt_r.sum()) > 0
+        compared += 1
+    assert compared >= 2
