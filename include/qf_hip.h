@@ -277,6 +277,14 @@ int qf_generate_rays(const qf_camera *cam /* host */, int32_t opengl, float *ori
  * torch_scatter.scatter_max as used for triangle pruning (prune_mesh_after_finetuning.py:355-357).              */
 int qf_scatter_max(const float *values, const int64_t *index, int64_t n, int64_t n_out, float *out, void *stream);
 
+/* Offsets of the packed samples: ray_offset[r] = sum_{q<r} min(hit_count[q], max_hits) for r = 0..n_rays, i.e.
+ * ray_offset[n_rays] is the total sample count (left in device memory, so the caller can start qf_pack_samples before
+ * reading it back).  Replaces the index bookkeeping of mesh_utils.py:359-366 (np.argsort / boolean masks on the host).
+ * temp: caller-provided device scratch of at least qf_sample_offsets_temp_bytes(n_rays) bytes.     */
+int64_t qf_sample_offsets_temp_bytes(int64_t n_rays);
+int qf_sample_offsets(const int32_t *hit_count, int64_t n_rays, int32_t max_hits,
+                      int64_t *ray_offset /* [n_rays+1] */, void *temp, int64_t temp_bytes, void *stream);
+
 /* Packs the per-ray hit lists into the sample arrays sampling_raytrace_numpy returns
  * (mesh_utils.py:359-387), already sorted by (ray, depth): location = o + t d in float64,
  * dirs = d/(|d|+1e-7), depth = |location - o| (float64, rounded to fp32 at the end).

@@ -44,34 +44,45 @@ __global__ __launch_bounds__(DP_THREADS) void derive_properties_kernel(
     float *out_depth, float *weights)
 {
     __shared__ float s_tau[DP_STAGE];
+    __shared__ float s_alpha[DP_STAGE];              // 1 - exp(-tau), computed by all lanes before the serial part
     __shared__ float s_rgb[3 * DP_STAGE];
     __shared__ float s_dep[DP_STAGE];
     __shared__ float s_w[DP_STAGE];
     __shared__ int64_t s_ray[DP_STAGE + 1];          // [0]: the sample just before the chunk
     __shared__ uint8_t s_mine[DP_STAGE];             // weight computed by this block
+    __shared__ int s_heads[DP_CHUNK];                // first samples of the rays this block owns, compacted
+    __shared__ int s_nheads;
     const int64_t n_chunks = (n + DP_CHUNK - 1) / DP_CHUNK;
     for (int64_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
         const int64_t b0 = chunk * DP_CHUNK;
         const int staged = (int)((n - b0 < DP_STAGE) ? (n - b0) : DP_STAGE);
         const int own = (int)((n - b0 < DP_CHUNK) ? (n - b0) : DP_CHUNK);
+        if (threadIdx.x == 0) {
+            s_ray[0] = b0 > 0 ? index_ray[b0 - 1] : 0;
+            s_nheads = 0;
+        }
         for (int k = threadIdx.x; k < staged; k += DP_THREADS) {
-            s_tau[k] = sigma[b0 + k] * (deltas ? deltas[b0 + k] : delta_const);
+            const float tau = sigma[b0 + k] * (deltas ? deltas[b0 + k] : delta_const);
+            s_tau[k] = tau;
+            s_alpha[k] = 1.0f - expf(-tau);
             s_dep[k] = depth_s[b0 + k];
             s_ray[k + 1] = index_ray[b0 + k];
             s_mine[k] = 0;
         }
         for (int k = threadIdx.x; k < 3 * staged; k += DP_THREADS) s_rgb[k] = rgb_s[b0 * 3 + k];
-        if (threadIdx.x == 0) s_ray[0] = b0 > 0 ? index_ray[b0 - 1] : 0;
         __syncthreads();
-        for (int k = threadIdx.x; k < own; k += DP_THREADS) {
+        for (int k = threadIdx.x; k < own; k += DP_THREADS)
+            if (b0 + k == 0 || s_ray[k] != s_ray[k + 1]) s_heads[atomicAdd(&s_nheads, 1)] = k;
+        __syncthreads();
+        const int n_heads = s_nheads;
+        for (int h = threadIdx.x; h < n_heads; h += DP_THREADS) {      // consecutive lanes = different rays: no idle lanes
+            const int k = s_heads[h];
             const int64_t ray = s_ray[k + 1];
-            if (b0 + k != 0 && s_ray[k] == ray) continue;
             float cum = 0.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f, cd = 0.0f, ca = 0.0f;
             int j = k;
             for (; j < staged && s_ray[j + 1] == ray; ++j) {
-                const float tau = s_tau[j];
-                const float w = expf(-cum) * (1.0f - expf(-tau));
-                cum += tau;
+                const float w = expf(-cum) * s_alpha[j];
+                cum += s_tau[j];
                 s_w[j] = w;
                 s_mine[j] = 1;
                 cr += w * s_rgb[j * 3 + 0];

@@ -48,6 +48,7 @@ class RayIntersector:
         self.device = torch.device(device)
         self.last_order = None           # coherent processing order of the most recent image-shaped sample_device()
         self._raster_backoff = 0         # frames left to skip the camera-coherent intersector after an overflow
+        self._scratch = {}               # per-ray-count frame scratch, see _frame_scratch
         self._handle = ctypes.c_void_p()
         tri = np.ascontiguousarray(mesh.vertices.astype(np.float32)[mesh.faces].reshape(-1, 9))
         with torch.cuda.device(self.device):
@@ -141,6 +142,77 @@ class RayIntersector:
         hit_tri, _, _, _, _ = self.hits(r[:, :3], r[:, 3:])
         return hit_tri.reshape(-1).cpu().numpy()
 
+    def _frame_scratch(self, n):
+        """Per-ray-count scratch reused across frames: [n+2] int64 = sample offsets | total | raster overflow flag,
+        the scan's temp storage, a pinned host mirror of (total, overflow) and the event that guards it."""
+        s = self._scratch.get(n)
+        if s is None:
+            buf = torch.zeros((n + 2,), dtype=torch.int64, device=self.device)
+            nbytes = int(_C.lib().qf_sample_offsets_temp_bytes(n))
+            if nbytes < 0:
+                raise _C.QFError("qf_sample_offsets_temp_bytes failed")
+            temp = torch.empty((nbytes,), dtype=torch.uint8, device=self.device)
+            host = torch.zeros((2,), dtype=torch.int64).pin_memory()
+            s = self._scratch[n] = (buf, temp, host, torch.cuda.Event())
+            if len(self._scratch) > 4:
+                self._scratch.pop(next(iter(self._scratch)))
+        return s
+
+    def _hits_raster_frame(self, o, d, k, camera):
+        """Camera-coherent pass whose overflow counter lives next to the frame's sample total (one readback)."""
+        n = o.shape[0]
+        buf = self._frame_scratch(n)[0]
+        hit_tri, hit_t, hit_count = self._alloc_hits(n, k)
+        overflow = buf[n + 1:].view(torch.int32)[:1]           # low word of buf[n+1]; the high word stays zero
+        _C.check(_C.lib().qf_raster_intersect(self._handle, ctypes.byref(camera), _C.ptr(o), _C.ptr(d), n, k,
+                                              _C.ptr(hit_tri), _C.ptr(hit_t), _C.ptr(hit_count), _C.ptr(overflow),
+                                              0, _C.stream()), "qf_raster_intersect")
+        hit_count.clamp_(max=k)      # overflowing pixels counted past K; everything downstream indexes with <= K
+        return hit_tri, hit_t, hit_count, overflow
+
+    def pack_hits(self, o, d, k, hit_tri, hit_t, hit_count, overflow, width):
+        """Per-ray hit lists -> ([xyzs, dirs, index_ray, ts, index_tri, origins] or None, coherent order or None).
+
+        The output size is data dependent.  Instead of stalling on it, the offsets are scanned on the device, the
+        (total, raster overflow) pair starts its way to pinned host memory, and the pack and ordering kernels run
+        into buffers sized for the worst case (n_rays * K samples -- 60 B each, ~1 GB for an 800x800 frame, nothing
+        against 288 GB) while the host waits for those 16 bytes; the results are views of the first ``total`` rows.
+        ``overflow`` (from ``_hits_raster_frame``) marks lists with more than K candidates: the frame is redone with
+        the exact K-nearest BVH traversal."""
+        n = o.shape[0]
+        dev = self.device
+        buf, temp, host, ev = self._frame_scratch(n)
+        if overflow is None:
+            buf[n + 1].zero_()
+        _C.check(_C.lib().qf_sample_offsets(_C.ptr(hit_count), n, k, _C.ptr(buf), _C.ptr(temp), temp.numel(),
+                                            _C.stream()), "qf_sample_offsets")
+        host.copy_(buf[n:], non_blocking=True)
+        ev.record()
+        cap = n * k
+        xyz = torch.empty((cap, 3), dtype=torch.float32, device=dev)
+        dirs = torch.empty((cap, 3), dtype=torch.float32, device=dev)
+        org = torch.empty((cap, 3), dtype=torch.float32, device=dev)
+        index_ray = torch.empty((cap,), dtype=torch.int64, device=dev)
+        index_tri = torch.empty((cap,), dtype=torch.int64, device=dev)
+        depth = torch.empty((cap,), dtype=torch.float32, device=dev)
+        _C.check(_C.lib().qf_pack_samples(_C.ptr(o), _C.ptr(d), n, k, _C.ptr(hit_tri), _C.ptr(hit_t),
+                                          _C.ptr(hit_count), _C.ptr(buf), _C.ptr(xyz), _C.ptr(dirs),
+                                          _C.ptr(index_ray), _C.ptr(depth), _C.ptr(index_tri), _C.ptr(org),
+                                          _C.stream()), "qf_pack_samples")
+        order = None
+        if width > 0 and n % width == 0:
+            order = self.coherent_order(hit_count, buf, cap, width)
+        ev.synchronize()
+        total, ovf = int(host[0]), int(host[1])
+        if ovf:
+            self.raster_overflowed()
+            hit_tri, hit_t, hit_count = self._hits_bvh(o, d, k, width)
+            return self.pack_hits(o, d, k, hit_tri, hit_t, hit_count, None, width)
+        if total == 0:
+            return None, None
+        data = [xyz[:total], dirs[:total], index_ray[:total], depth[:total], index_tri[:total], org[:total]]
+        return data, (order[:total] if order is not None else None)
+
     def sample_device(self, origins, vectors, max_hits: Optional[int] = None, image_width: int = 0, camera=None):
         """Packed, sorted samples on the device: [xyzs, dirs, index_ray, ts, index_tri, origins] -- the six
         tensors the reference's DataLoader hands to the renderers (nerf_synthetic.py:256-257) -- or None
@@ -154,39 +226,12 @@ class RayIntersector:
         if camera is not None:
             image_width = camera.width
         if self.want_raster(camera):
-            hit_tri, hit_t, hit_count, overflow = self._hits_raster(o, d, k, camera, sort_lists=False)
+            hit_tri, hit_t, hit_count, overflow = self._hits_raster_frame(o, d, k, camera)
         else:
             hit_tri, hit_t, hit_count = self._hits_bvh(o, d, k, image_width)
             overflow = None
-        csum = torch.cumsum(hit_count.to(torch.int64), dim=0)
-        # output size is data dependent: ONE readback (total samples + raster overflow flag)
-        if overflow is not None:
-            total, ovf = torch.stack([csum[-1], overflow[0].to(torch.int64)]).tolist()
-            if ovf:
-                self.raster_overflowed()
-                hit_tri, hit_t, hit_count = self._hits_bvh(o, d, k, camera.width)
-                csum = torch.cumsum(hit_count.to(torch.int64), dim=0)
-                total = int(csum[-1].item())
-        else:
-            total = int(csum[-1].item())
-        if total == 0:
-            return None
-        offset = (csum - hit_count).contiguous()
-        dev = self.device
-        xyz = torch.empty((total, 3), dtype=torch.float32, device=dev)
-        dirs = torch.empty((total, 3), dtype=torch.float32, device=dev)
-        org = torch.empty((total, 3), dtype=torch.float32, device=dev)
-        index_ray = torch.empty((total,), dtype=torch.int64, device=dev)
-        index_tri = torch.empty((total,), dtype=torch.int64, device=dev)
-        depth = torch.empty((total,), dtype=torch.float32, device=dev)
-        _C.check(_C.lib().qf_pack_samples(_C.ptr(o), _C.ptr(d), n, k, _C.ptr(hit_tri), _C.ptr(hit_t),
-                                          _C.ptr(hit_count), _C.ptr(offset), _C.ptr(xyz), _C.ptr(dirs),
-                                          _C.ptr(index_ray), _C.ptr(depth), _C.ptr(index_tri), _C.ptr(org),
-                                          _C.stream()), "qf_pack_samples")
-        width = int(image_width)
-        self.last_order = (self.coherent_order(hit_count, offset, total, width)
-                           if width > 0 and n % width == 0 else None)
-        return [xyz, dirs, index_ray, depth, index_tri, org]
+        data, self.last_order = self.pack_hits(o, d, k, hit_tri, hit_t, hit_count, overflow, int(image_width))
+        return data
 
     def coherent_order(self, hit_count: torch.Tensor, ray_offset: torch.Tensor, total: int, width: int) -> torch.Tensor:
         """int32 permutation of the ``total`` packed samples of a row-major ``width``-wide image, ordered
