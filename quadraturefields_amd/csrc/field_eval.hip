@@ -146,11 +146,24 @@ __global__ __launch_bounds__(kBlock, 4) void field_kernel(const FieldArgs a)
     __syncthreads();
     const f32x4 *img_base = reinterpret_cast<const f32x4 *>(lds);   // img_base[(m>>2)*64 + lane]
 
+    // Workgroups are dealt round-robin to the 8 XCDs, each with its own L2.  Give every XCD one CONTIGUOUS eighth
+    // of the (spatially coherent) processing order instead of every eighth chunk of it: an L2 then only sees the
+    // table rows of its own slab of the scene, which is what lets the mid-resolution levels stay resident.
     const int64_t n_groups = (a.n + 15) >> 4;
-    const int64_t wave_global = (int64_t)blockIdx.x * (kBlock / 64) + (tid >> 6);
-    const int64_t wave_stride = (int64_t)gridDim.x * (kBlock / 64);
+    int64_t grp_begin, grp_end, wave_stride;
+    if ((gridDim.x & 7) == 0) {
+        const int64_t per_xcd = (n_groups + 7) >> 3;
+        grp_begin = (int64_t)(blockIdx.x & 7) * per_xcd;
+        grp_end = grp_begin + per_xcd < n_groups ? grp_begin + per_xcd : n_groups;
+        grp_begin += (int64_t)(blockIdx.x >> 3) * (kBlock / 64) + (tid >> 6);
+        wave_stride = (int64_t)(gridDim.x >> 3) * (kBlock / 64);
+    } else {
+        grp_begin = (int64_t)blockIdx.x * (kBlock / 64) + (tid >> 6);
+        grp_end = n_groups;
+        wave_stride = (int64_t)gridDim.x * (kBlock / 64);
+    }
 
-    for (int64_t grp = wave_global; grp < n_groups; grp += wave_stride) {
+    for (int64_t grp = grp_begin; grp < grp_end; grp += wave_stride) {
         const int64_t pt_raw = grp * 16 + p;
         const bool valid = pt_raw < a.n;
         int64_t pt = valid ? pt_raw : a.n - 1;
@@ -546,6 +559,7 @@ int launch_field(const FieldArgs &a, hipStream_t st)
     int64_t blocks = qf_div_up(n_groups, kBlock / 64);
     const int64_t cap = (int64_t)qf_cu_count_cached() * 2;
     if (blocks > cap) blocks = cap;
+    if (blocks >= 64) blocks &= ~(int64_t)7;          // a multiple of 8: the XCD-contiguous mapping of field_kernel
     hipLaunchKernelGGL(field_kernel<HEAD>, dim3((unsigned)blocks), dim3(kBlock), lds_bytes, st, a);
     QF_LAUNCH_CHECK();
     return QF_OK;

@@ -131,10 +131,21 @@ __global__ __launch_bounds__(kBlockB, 4) void field_kernel_bf16(const FieldArgsB
     __syncthreads();
     const uint4 *img_base = reinterpret_cast<const uint4 *>(ldsb);
 
+    // one contiguous eighth of the processing order per XCD (see field_kernel in field_eval.hip)
     const int64_t n_groups = (a.n + 15) >> 4;
-    const int64_t wave_global = (int64_t)blockIdx.x * (kBlockB / 64) + (tid >> 6);
-    const int64_t wave_stride = (int64_t)gridDim.x * (kBlockB / 64);
-    for (int64_t grp = wave_global; grp < n_groups; grp += wave_stride) {
+    int64_t grp_begin, grp_end, wave_stride;
+    if ((gridDim.x & 7) == 0) {
+        const int64_t per_xcd = (n_groups + 7) >> 3;
+        grp_begin = (int64_t)(blockIdx.x & 7) * per_xcd;
+        grp_end = grp_begin + per_xcd < n_groups ? grp_begin + per_xcd : n_groups;
+        grp_begin += (int64_t)(blockIdx.x >> 3) * (kBlockB / 64) + (tid >> 6);
+        wave_stride = (int64_t)(gridDim.x >> 3) * (kBlockB / 64);
+    } else {
+        grp_begin = (int64_t)blockIdx.x * (kBlockB / 64) + (tid >> 6);
+        grp_end = n_groups;
+        wave_stride = (int64_t)gridDim.x * (kBlockB / 64);
+    }
+    for (int64_t grp = grp_begin; grp < grp_end; grp += wave_stride) {
         const int64_t pt_raw = grp * 16 + p;
         const bool valid = pt_raw < a.n;
         int64_t pt = valid ? pt_raw : a.n - 1;
@@ -305,6 +316,7 @@ int launch_field_b(const FieldArgsB &a, hipStream_t st)
     int64_t blocks = qf_div_up((a.n + 15) / 16, kBlockB / 64);
     const int64_t cap = (int64_t)qf_cu_count_cached() * 2;
     if (blocks > cap) blocks = cap;
+    if (blocks >= 64) blocks &= ~(int64_t)7;
     hipLaunchKernelGGL(field_kernel_bf16<HEAD>, dim3((unsigned)blocks), dim3(kBlockB), lds_bytes, st, a);
     QF_LAUNCH_CHECK();
     return QF_OK;
