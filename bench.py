@@ -101,7 +101,7 @@ class Stages:
         return {k: (float(np.mean([a.elapsed_time(b) for a, b in v])) if v else None) for k, v in self.ev.items()}
 
 
-def cpu_baseline(mesh, field, cam_o, cam_d, crop=40):
+def cpu_baseline(mesh, field, cam_o, cam_d, crop=200):
     """The oracle (CPU restatement of the reference path) timed on this box's host cores on a bounded sample:
     the centre crop x crop pixels of frame 0 through brute-force multi-hit intersection (OpenMP C), torch-CPU
     field evaluation and compositing."""
