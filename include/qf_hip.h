@@ -338,6 +338,17 @@ int qf_texture_fetch(const qf_texture_set *tex /* host */, const int64_t *texel,
 int qf_texture_shade(const qf_texture_set *tex /* host */, const int64_t *texel,
                      const float *dirs, int64_t n, float *rgb, float *sigma, void *stream);
 
+/* Device-resident form of the same texture set: one 64-byte record per texel,
+ * [alpha | diffuse rgb | (lambda, azimuth, elevation, colour rgb) * n_lobes | zero pad], so a sample reads ONE
+ * 64-byte sector instead of 2 + 2L scattered ones from the reference's planes (texture_utils.py:149-175 indexes
+ * each plane separately).  qf_texture_pack builds records [T*T, QF_TEXEL_RECORD_BYTES] from the planes;
+ * qf_texture_shade_packed == qf_texture_shade on them, bit for bit.                             */
+#define QF_TEXEL_RECORD_BYTES 64
+int qf_texture_pack(const qf_texture_set *tex /* host */, uint8_t *records, void *stream);
+int qf_texture_shade_packed(const uint8_t *records, int32_t texture_size, int32_t n_lobes,
+                            int32_t sigmoid_codec, float lambda_thres, const int64_t *texel,
+                            const float *dirs, int64_t n, float *rgb, float *sigma, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

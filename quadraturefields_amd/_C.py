@@ -15,6 +15,7 @@ LIB_PATH = os.path.join(_PKG, "libqf_hip.so")
 QF_MAX_LEVELS = 16
 QF_MAX_LOBES = 8
 QF_BVH_MAX_HITS = 64
+QF_TEXEL_RECORD_BYTES = 64
 HEAD_NONE, HEAD_NGP, HEAD_SG, HEAD_SG_FEATURES = 0, 1, 2, 3
 BG_WHITE, BG_BLACK, BG_CUSTOM = 0, 1, 2
 
@@ -95,6 +96,8 @@ _SIGNATURES = {
     "qf_texel_indices": (c_int, [_P, _P, _P, _P, _P, c_int64, c_int32, _P, _P]),
     "qf_texture_fetch": (c_int, [POINTER(TextureSet), _P, c_int64, _P, _P]),
     "qf_texture_shade": (c_int, [POINTER(TextureSet), _P, _P, c_int64, _P, _P, _P]),
+    "qf_texture_pack": (c_int, [POINTER(TextureSet), _P, _P]),
+    "qf_texture_shade_packed": (c_int, [_P, c_int32, c_int32, c_int32, c_float, _P, _P, c_int64, _P, _P, _P]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 

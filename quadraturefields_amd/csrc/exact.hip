@@ -511,18 +511,24 @@ __device__ __forceinline__ float decode_color(uint8_t c, int sigmoid_codec)
     return v * 2.0f * 12.0f - 12.0f;                                              // ngp.py:280 (B-7)
 }
 
-// Decodes one texel into out[0 .. 3+7L] = [diffuse3 | (axis3, lambda, colour3) * L | sigma].
-__device__ __forceinline__ void decode_texel(const TexArgs &t, int64_t row, int64_t col, float *out)
+// Device-resident texel record: the 4 + 6L quantised bytes of one texel, contiguous and padded to one 64-byte
+// sector -- [alpha | diffuse rgb | (lambda, azimuth, elevation, colour rgb) * L].  The reference keeps 2 + 2L separate
+// planes (the PNG set of texture_utils.py:67-124), i.e. 2 + 2L scattered sector reads per sample; a record is ONE.
+constexpr int kTexelRecord = QF_TEXEL_RECORD_BYTES;
+
+// Decodes one record into out[0 .. 3+7L] = [diffuse3 | (axis3, lambda, colour3) * L | sigma].
+__device__ __forceinline__ void decode_record(const uint8_t *rec, int n_lobes, int sigmoid_codec, float lambda_thres,
+                                              float *out)
 {
-    const int64_t px = row * t.size + col;
-    const float a = (float)t.alpha[px] / 255.0f;
+    const float a = (float)rec[0] / 255.0f;
     const float sigma = -logf(fmaxf(1.0f - a, 1e-6f)) / 0.005f;                   // texture_utils.py:61-65 (B-9)
-    out[0] = decode_color(t.diffuse[px * 3 + 0], t.sigmoid_codec);
-    out[1] = decode_color(t.diffuse[px * 3 + 1], t.sigmoid_codec);
-    out[2] = decode_color(t.diffuse[px * 3 + 2], t.sigmoid_codec);
+    out[0] = decode_color(rec[1], sigmoid_codec);
+    out[1] = decode_color(rec[2], sigmoid_codec);
+    out[2] = decode_color(rec[3], sigmoid_codec);
     const float pi = 3.14159274101257324f;   // float32(np.pi)
-    for (int l = 0; l < t.n_lobes; ++l) {
-        const uint8_t lc = t.lam[l][px * 3 + 0], az8 = t.lam[l][px * 3 + 1], el8 = t.lam[l][px * 3 + 2];
+    for (int l = 0; l < n_lobes; ++l) {
+        const uint8_t *r = rec + 4 + 6 * l;
+        const uint8_t lc = r[0], az8 = r[1], el8 = r[2];
         const float az = (float)(uint8_t)(az8 - 128) / 128.0f * pi;               // uint8 wrap (B-8), ngp.py:246
         const float el = (float)el8 / 256.0f * pi;                                // ngp.py:248
         const float se = sinf(el);
@@ -530,12 +536,88 @@ __device__ __forceinline__ void decode_texel(const TexArgs &t, int64_t row, int6
         o[0] = cosf(az) * se;
         o[1] = sinf(az) * se;
         o[2] = cosf(el);
-        o[3] = expf((float)lc * t.lambda_thres / 255.0f - 2.5f);                  // ngp.py:261-262
-        o[4] = decode_color(t.colors[l][px * 3 + 0], t.sigmoid_codec);
-        o[5] = decode_color(t.colors[l][px * 3 + 1], t.sigmoid_codec);
-        o[6] = decode_color(t.colors[l][px * 3 + 2], t.sigmoid_codec);
+        o[3] = expf((float)lc * lambda_thres / 255.0f - 2.5f);                    // ngp.py:261-262
+        o[4] = decode_color(r[3], sigmoid_codec);
+        o[5] = decode_color(r[4], sigmoid_codec);
+        o[6] = decode_color(r[5], sigmoid_codec);
     }
-    out[3 + 7 * t.n_lobes] = sigma;
+    out[3 + 7 * n_lobes] = sigma;
+}
+
+// Gathers a texel's bytes from the reference's planes into record order.
+__device__ __forceinline__ void gather_record(const TexArgs &t, int64_t px, uint8_t *rec)
+{
+    rec[0] = t.alpha[px];
+    rec[1] = t.diffuse[px * 3 + 0];
+    rec[2] = t.diffuse[px * 3 + 1];
+    rec[3] = t.diffuse[px * 3 + 2];
+    for (int l = 0; l < t.n_lobes; ++l) {
+        uint8_t *r = rec + 4 + 6 * l;
+        r[0] = t.lam[l][px * 3 + 0];
+        r[1] = t.lam[l][px * 3 + 1];
+        r[2] = t.lam[l][px * 3 + 2];
+        r[3] = t.colors[l][px * 3 + 0];
+        r[4] = t.colors[l][px * 3 + 1];
+        r[5] = t.colors[l][px * 3 + 2];
+    }
+}
+
+__device__ __forceinline__ void decode_texel(const TexArgs &t, int64_t row, int64_t col, float *out)
+{
+    uint8_t rec[kTexelRecord];
+    gather_record(t, row * t.size + col, rec);
+    decode_record(rec, t.n_lobes, t.sigmoid_codec, t.lambda_thres, out);
+}
+
+// SG shading of one decoded texel (ngp.py:371-393,456-461).
+__device__ __forceinline__ void shade_decoded(const float *f, int n_lobes, float dx, float dy, float dz, float *rgb3)
+{
+    float r = 0.0f, g = 0.0f, b = 0.0f;
+    for (int l = 0; l < n_lobes; ++l) {
+        const float *x = f + 3 + 7 * l;
+        const float nrm = sqrtf((x[0] * x[0] + x[1] * x[1]) + x[2] * x[2]);
+        const float dotp = ((x[0] / nrm) * dx + (x[1] / nrm) * dy) + (x[2] / nrm) * dz;
+        const float e = expf(fabsf(x[3]) * (dotp - 1.0f));
+        r += x[4] * e;
+        g += x[5] * e;
+        b += x[6] * e;
+    }
+    rgb3[0] = 1.0f / (1.0f + expf(-(f[0] + r)));
+    rgb3[1] = 1.0f / (1.0f + expf(-(f[1] + g)));
+    rgb3[2] = 1.0f / (1.0f + expf(-(f[2] + b)));
+}
+
+__global__ void texture_pack_kernel(TexArgs t, uint8_t *records)
+{
+    const int64_t n = (int64_t)t.size * t.size;
+    for (int64_t px = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; px < n; px += (int64_t)gridDim.x * blockDim.x) {
+        union { uint8_t b[kTexelRecord]; uint4 q[kTexelRecord / 16]; } rec;
+#pragma unroll
+        for (int k = 0; k < kTexelRecord / 16; ++k) rec.q[k] = make_uint4(0u, 0u, 0u, 0u);
+        gather_record(t, px, rec.b);
+        uint4 *dst = reinterpret_cast<uint4 *>(records + px * kTexelRecord);
+#pragma unroll
+        for (int k = 0; k < kTexelRecord / 16; ++k) dst[k] = rec.q[k];
+    }
+}
+
+__global__ void texture_shade_packed_kernel(const uint8_t *records, int size, int n_lobes, int sigmoid_codec,
+                                            float lambda_thres, const int64_t *texel, const float *dirs, int64_t n,
+                                            float *rgb, float *sigma)
+{
+    const int n16 = (4 + 6 * n_lobes + 15) / 16;       // 16-byte pieces of the record that carry data
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t px = texel[i * 2] * size + texel[i * 2 + 1];
+        union { uint8_t b[kTexelRecord]; uint4 q[kTexelRecord / 16]; } rec;
+        const uint4 *src = reinterpret_cast<const uint4 *>(records + px * kTexelRecord);
+#pragma unroll
+        for (int k = 0; k < kTexelRecord / 16; ++k)
+            if (k < n16) rec.q[k] = src[k];
+        float f[3 + 7 * QF_MAX_LOBES + 1];
+        decode_record(rec.b, n_lobes, sigmoid_codec, lambda_thres, f);
+        shade_decoded(f, n_lobes, dirs[i * 3], dirs[i * 3 + 1], dirs[i * 3 + 2], rgb + i * 3);
+        sigma[i] = f[3 + 7 * n_lobes];
+    }
 }
 
 __global__ void texture_fetch_kernel(TexArgs t, const int64_t *texel, int64_t n, float *features)
@@ -554,20 +636,7 @@ __global__ void texture_shade_kernel(TexArgs t, const int64_t *texel, const floa
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         float f[3 + 7 * QF_MAX_LOBES + 1];
         decode_texel(t, texel[i * 2], texel[i * 2 + 1], f);
-        const float dx = dirs[i * 3], dy = dirs[i * 3 + 1], dz = dirs[i * 3 + 2];
-        float r = 0.0f, g = 0.0f, b = 0.0f;
-        for (int l = 0; l < t.n_lobes; ++l) {
-            const float *x = f + 3 + 7 * l;
-            const float nrm = sqrtf((x[0] * x[0] + x[1] * x[1]) + x[2] * x[2]);
-            const float dotp = ((x[0] / nrm) * dx + (x[1] / nrm) * dy) + (x[2] / nrm) * dz;
-            const float e = expf(fabsf(x[3]) * (dotp - 1.0f));
-            r += x[4] * e;
-            g += x[5] * e;
-            b += x[6] * e;
-        }
-        rgb[i * 3 + 0] = 1.0f / (1.0f + expf(-(f[0] + r)));
-        rgb[i * 3 + 1] = 1.0f / (1.0f + expf(-(f[1] + g)));
-        rgb[i * 3 + 2] = 1.0f / (1.0f + expf(-(f[2] + b)));
+        shade_decoded(f, t.n_lobes, dirs[i * 3], dirs[i * 3 + 1], dirs[i * 3 + 2], rgb + i * 3);
         sigma[i] = f[3 + 7 * t.n_lobes];
     }
 }
@@ -681,6 +750,29 @@ extern "C" int qf_texture_shade(const qf_texture_set *tex, const int64_t *texel,
     if (n == 0) return QF_OK;
     if (!texel || !dirs || !rgb || !sigma) return QF_ERR_INVALID_ARGUMENT;
     QF_SIMPLE_LAUNCH(texture_shade_kernel, n, t, texel, dirs, n, rgb, sigma);
+    return QF_OK;
+}
+
+extern "C" int qf_texture_pack(const qf_texture_set *tex, uint8_t *records, void *stream)
+{
+    TexArgs t;
+    int rc = fill_tex_args(tex, &t);
+    if (rc != QF_OK) return rc;
+    if (!records || 4 + 6 * t.n_lobes > kTexelRecord) return QF_ERR_INVALID_ARGUMENT;
+    QF_SIMPLE_LAUNCH(texture_pack_kernel, (int64_t)t.size * t.size, t, records);
+    return QF_OK;
+}
+
+extern "C" int qf_texture_shade_packed(const uint8_t *records, int32_t texture_size, int32_t n_lobes,
+                                       int32_t sigmoid_codec, float lambda_thres, const int64_t *texel,
+                                       const float *dirs, int64_t n, float *rgb, float *sigma, void *stream)
+{
+    if (!records || texture_size < 1 || n < 0) return QF_ERR_INVALID_ARGUMENT;
+    if (n_lobes < 1 || n_lobes > QF_MAX_LOBES) return QF_ERR_UNSUPPORTED;
+    if (n == 0) return QF_OK;
+    if (!texel || !dirs || !rgb || !sigma) return QF_ERR_INVALID_ARGUMENT;
+    QF_SIMPLE_LAUNCH(texture_shade_packed_kernel, n, records, (int)texture_size, (int)n_lobes, (int)sigmoid_codec,
+                     lambda_thres, texel, dirs, n, rgb, sigma);
     return QF_OK;
 }
 

@@ -131,13 +131,38 @@ class FeatureCompression:
                  "qf_texture_fetch")
         return out
 
-    def shade(self, indices, dirs):
-        """Fused fetch + dequantise + spherical-Gaussian shading: (rgb [S,3], sigma [S])."""
+    def records(self) -> torch.Tensor:
+        """The device-resident form of the texture set: one 64-byte record per texel (all of a texel's quantised
+        bytes in one sector), built from the planes on first use and rebuilt when a plane is modified in place or
+        replaced.  [T*T, 64] uint8."""
+        planes = [self.alpha, self.diffuse] + [self.sg_colors[i] for i in range(self.num_lobes)] + \
+                 [self.lambdas[i] for i in range(self.num_lobes)]
+        key = tuple((p.data_ptr(), p._version) for p in planes)
+        cache = getattr(self, "_records", None)
+        if cache is None or cache[0] != key:
+            t = self.texture_set()
+            size = int(self.alpha.shape[0])
+            rec = torch.empty((size * size, _C.QF_TEXEL_RECORD_BYTES), dtype=torch.uint8, device=self.alpha.device)
+            _C.check(_C.lib().qf_texture_pack(ctypes.byref(t), _C.ptr(rec), _C.stream()), "qf_texture_pack")
+            planes = [self.alpha, self.diffuse] + [self.sg_colors[i] for i in range(self.num_lobes)] + \
+                     [self.lambdas[i] for i in range(self.num_lobes)]      # texture_set() may have made them contiguous
+            cache = self._records = (tuple((p.data_ptr(), p._version) for p in planes), rec)
+        return cache[1]
+
+    def shade(self, indices, dirs, packed: bool = True):
+        """Fused fetch + dequantise + spherical-Gaussian shading: (rgb [S,3], sigma [S]).  ``packed`` reads the
+        interleaved texel records (one sector per sample); ``packed=False`` reads the reference's planes.  Same bits."""
         indices = _C.i64c(indices)
         dirs = _C.f32c(dirs)
         n = indices.shape[0]
         rgb = torch.empty((n, 3), dtype=torch.float32, device=indices.device)
         sigma = torch.empty((n,), dtype=torch.float32, device=indices.device)
+        if packed:
+            _C.check(_C.lib().qf_texture_shade_packed(
+                _C.ptr(self.records()), int(self.alpha.shape[0]), self.num_lobes,
+                1 if self.compression_type == "sigma" else 0, float(self.lambda_thres), _C.ptr(indices), _C.ptr(dirs), n,
+                _C.ptr(rgb), _C.ptr(sigma), _C.stream()), "qf_texture_shade_packed")
+            return rgb, sigma
         t = self.texture_set()
         _C.check(_C.lib().qf_texture_shade(ctypes.byref(t), _C.ptr(indices), _C.ptr(dirs), n, _C.ptr(rgb),
                                            _C.ptr(sigma), _C.stream()), "qf_texture_shade")

@@ -94,3 +94,35 @@ def test_compress_roundtrip_through_textures(device):
     data = oq.compress_features(feats, lobes, "linear", 7.5)
     assert torch.equal(comp.alpha.cpu().reshape(-1), data["alpha"])
     assert torch.equal(comp.diffuse.cpu().reshape(-1, 3), data["diffuse"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lobes", [1, 3, 6, 8])
+def test_packed_texel_records_equal_planes(device, lobes):
+    """The interleaved 64-byte texel records (one sector per sample) shade to the same bits as the reference's planes,
+    and are rebuilt when a plane changes."""
+    from quadraturefields_amd import synthetic
+    from quadraturefields_amd.texture_utils import FeatureCompression
+    size = 96
+    tex = synthetic.random_textures(size, lobes, seed=lobes)
+    comp = FeatureCompression.from_arrays(tex["alpha"], tex["diffuse"], tex["colors"], tex["lambdas"],
+                                          compression_type="linear", lambda_thres=5.0, device=device)
+    g = torch.Generator().manual_seed(0)
+    n = 5000
+    idx = torch.randint(0, size, (n, 2), generator=g).to(device)
+    idx[0] = torch.tensor([0, 0])
+    idx[1] = torch.tensor([size - 1, size - 1])
+    d = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1).to(device)
+    rgb_p, sig_p = comp.shade(idx, d, packed=True)
+    rgb_r, sig_r = comp.shade(idx, d, packed=False)
+    assert torch.equal(rgb_p, rgb_r) and torch.equal(sig_p, sig_r)
+    rec = comp.records()
+    assert rec.shape == (size * size, 64) and rec.dtype == torch.uint8
+    assert torch.equal(rec[:, 0].reshape(size, size), comp.alpha)
+    assert torch.equal(rec[:, 1:4].reshape(size, size, 3), comp.diffuse)
+    assert torch.equal(rec[:, 4:7].reshape(size, size, 3), comp.lambdas[0])
+    assert torch.equal(rec[:, 7:10].reshape(size, size, 3), comp.sg_colors[0])
+    assert int(rec[:, 4 + 6 * lobes:].max()) == 0
+    comp.alpha[idx[:, 0], idx[:, 1]] = 77                 # in-place edit: the records follow
+    rgb2, sig2 = comp.shade(idx, d)
+    assert torch.equal(sig2, comp.shade(idx, d, packed=False)[1]) and not torch.equal(sig2, sig_p)

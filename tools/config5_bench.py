@@ -1,0 +1,85 @@
+"""BASELINE config 5: render from the baked spherical-Gaussian textures -- 4096 x 4096 uint8
+texture set, L = 6 lobes, the bench mesh and cameras -- through the reference-named entry point
+``render_image_bake_texture_images_with_occgrid``.  A scale exercise beside bench.py (whose line stays config 2):
+prints one JSON object.
+
+    python tools/config5_bench.py --steps 10 --warmup 2 [--texture-size 4096] [--lobes 6]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch
+
+import bench
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--texture-size", type=int, default=4096)
+    ap.add_argument("--lobes", type=int, default=6)
+    args = ap.parse_args()
+    torch.set_grad_enabled(False)
+    from quadraturefields_amd import synthetic, utils
+    from quadraturefields_amd.datasets.utils import Rays
+    from quadraturefields_amd.mesh_utils import make_camera
+    from quadraturefields_amd.texture_utils import FeatureCompression
+    device = torch.device("cuda:0")
+    mesh, mi, field = bench.build_scene(device)
+    tex = synthetic.random_textures(args.texture_size, args.lobes, seed=42)
+    comp = FeatureCompression.from_arrays(tex["alpha"], tex["diffuse"], tex["colors"], tex["lambdas"],
+                                          compression_type="sigmoid", lambda_thres=7.5, device=device)
+    uv = torch.from_numpy(synthetic.scaled_uv(mesh, args.texture_size)).to(device)
+    n_frames = args.steps + args.warmup
+    cams = synthetic.orbit_cameras(n_frames, seed=42)
+    focal = synthetic.lego_focal(bench.W)
+    rays = [synthetic.camera_rays(cams[i], focal, bench.W, bench.H, device=device) for i in range(n_frames)]
+    cameras = [make_camera(cams[i], focal, bench.W, bench.H) for i in range(n_frames)]
+    ev = {k: [] for k in ("sample", "render")}
+
+    def frame(i, record):
+        o, d = rays[i]
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(3)] if record else None
+        if record:
+            marks[0].record()
+        data = mi.sampling_raytrace_device(d, o, camera=cameras[i])
+        if record:
+            marks[1].record()
+        out = utils.render_image_bake_texture_images_with_occgrid(
+            field, Rays(origins=o, viewdirs=d), data, uv=uv, render_step_size=bench.STEP, mesh_intersect=mi,
+            compressor=comp, discretize=False)
+        if record:
+            marks[2].record()
+            ev["sample"].append((marks[0], marks[1]))
+            ev["render"].append((marks[1], marks[2]))
+        return out[0], out[3]
+
+    for i in range(args.warmup):
+        frame(i, False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    pts = 0
+    for i in range(args.warmup, n_frames):
+        pts += frame(i, True)[1]
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    ms = {k: sum(a.elapsed_time(b) for a, b in v) / len(v) for k, v in ev.items()}
+    n_rays = bench.W * bench.H
+    bytes_per_sample = 1 + 3 + 6 * args.lobes
+    print(json.dumps({
+        "workload": f"config 5: baked SG textures {args.texture_size}^2, L={args.lobes}, 800x800, bench mesh",
+        "rays_per_s": n_rays * args.steps / el, "ms_per_frame": el / args.steps * 1e3,
+        "points_per_frame": pts / args.steps, "stage_ms": ms,
+        "texture_bytes_per_sample": bytes_per_sample,
+        "texture_set_mb": (args.texture_size ** 2) * bytes_per_sample / 1e6}))
+
+
+if __name__ == "__main__":
+    main()
