@@ -310,6 +310,14 @@ int qf_coherent_order(const int32_t *hit_count, const int64_t *ray_offset, const
 int qf_resort_by_depth(const int64_t *index_ray, const float *depth, int64_t n, int64_t *perm,
                        void *stream);
 
+/* The whole of sampling_indexing (mesh_utils.py:389-412) in one launch: the re-sort above, the gathers of
+ * points / depth / origins / vectors / index_tri through the permutation (index_ray is unchanged by a within-ray
+ * sort) and kaolin's mark_pack_boundaries (:407).  perm and boundary may be NULL.               */
+int qf_resort_samples(const int64_t *index_ray, const float *depth, int64_t n, const float *points,
+                      const float *origins, const float *vectors, const int64_t *index_tri,
+                      int64_t *perm, float *out_points, float *out_depth, float *out_origins,
+                      float *out_vectors, int64_t *out_index_tri, uint8_t *boundary, void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * Baked spherical-Gaussian textures.
  * Replaces trimesh.triangles.points_to_barycentric + the UV lookup (utils.py:1055-1063) and

@@ -93,6 +93,7 @@ _SIGNATURES = {
     "qf_tile_totals": (c_int, [_P, c_int32, c_int32, _P, _P]),
     "qf_coherent_order": (c_int, [_P, _P, _P, c_int32, c_int32, _P, _P]),
     "qf_resort_by_depth": (c_int, [_P, _P, c_int64, _P, _P]),
+    "qf_resort_samples": (c_int, [_P, _P, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "qf_texel_indices": (c_int, [_P, _P, _P, _P, _P, c_int64, c_int32, _P, _P]),
     "qf_texture_fetch": (c_int, [POINTER(TextureSet), _P, c_int64, _P, _P]),
     "qf_texture_shade": (c_int, [POINTER(TextureSet), _P, _P, c_int64, _P, _P, _P]),

@@ -456,6 +456,111 @@ __global__ void resort_kernel(const int64_t *index_ray, const float *depth, int6
     }
 }
 
+// sampling_indexing (mesh_utils.py:389-412) in one pass: the stable per-ray re-sort by depth AND the gathers of the
+// sample arrays through the resulting permutation AND the pack boundaries.  A workgroup owns RS_CHUNK consecutive
+// samples (+ halo: a ray of the mesh path has at most QF_BVH_MAX_HITS = 64 samples, so rays starting in the chunk end
+// inside the staged window); depths and ray ids are staged in LDS, the first samples of the rays are compacted so that
+// consecutive lanes sort different rays (insertion sort of local indices, = np.lexsort((depth, ray)) on grouped
+// rays), and the arrays are then written coalesced, reading from (almost always nearly the same) source positions.
+// Rays that run past the window take the slow path through global memory.
+constexpr int RS_THREADS = 256;
+constexpr int RS_CHUNK = 1024;
+constexpr int RS_HALO = 64;
+constexpr int RS_STAGE = RS_CHUNK + RS_HALO;
+
+__global__ __launch_bounds__(RS_THREADS) void resort_samples_kernel(
+    const int64_t *index_ray, const float *depth, int64_t n, const float *points, const float *origins,
+    const float *vectors, const int64_t *index_tri, int64_t *perm, float *out_points, float *out_depth,
+    float *out_origins, float *out_vectors, int64_t *out_index_tri, uint8_t *boundary)
+{
+    __shared__ float s_depth[RS_STAGE];
+    __shared__ int64_t s_ray[RS_STAGE + 1];
+    __shared__ int s_src[RS_STAGE];                  // local source index of the sample that lands at each position
+    __shared__ uint8_t s_mine[RS_STAGE];
+    __shared__ int s_heads[RS_CHUNK];
+    __shared__ int s_nheads;
+    const int64_t n_chunks = (n + RS_CHUNK - 1) / RS_CHUNK;
+    for (int64_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+        const int64_t b0 = chunk * RS_CHUNK;
+        const int staged = (int)((n - b0 < RS_STAGE) ? (n - b0) : RS_STAGE);
+        const int own = (int)((n - b0 < RS_CHUNK) ? (n - b0) : RS_CHUNK);
+        if (threadIdx.x == 0) {
+            s_ray[0] = b0 > 0 ? index_ray[b0 - 1] : 0;
+            s_nheads = 0;
+        }
+        for (int k = threadIdx.x; k < staged; k += RS_THREADS) {
+            s_depth[k] = depth[b0 + k];
+            s_ray[k + 1] = index_ray[b0 + k];
+            s_mine[k] = 0;
+        }
+        __syncthreads();
+        for (int k = threadIdx.x; k < own; k += RS_THREADS) {
+            const bool head = (b0 + k == 0) || s_ray[k] != s_ray[k + 1];
+            if (boundary) boundary[b0 + k] = head ? 1 : 0;
+            if (head) s_heads[atomicAdd(&s_nheads, 1)] = k;
+        }
+        __syncthreads();
+        const int n_heads = s_nheads;
+        for (int h = threadIdx.x; h < n_heads; h += RS_THREADS) {
+            const int k = s_heads[h];
+            const int64_t ray = s_ray[k + 1];
+            int end = k + 1;
+            while (end < staged && s_ray[end + 1] == ray) ++end;
+            const bool spills = end == staged && b0 + staged < n && index_ray[b0 + staged] == ray;
+            if (!spills) {
+                s_src[k] = k;
+                s_mine[k] = 1;
+                for (int q = k + 1; q < end; ++q) {
+                    const float dq = s_depth[q];
+                    int j = q - 1;
+                    while (j >= k && s_depth[s_src[j]] > dq) { s_src[j + 1] = s_src[j]; --j; }
+                    s_src[j + 1] = q;
+                    s_mine[q] = 1;
+                }
+            } else {                                  // longer than the window: sort and gather through global memory
+                const int64_t i = b0 + k;
+                int64_t e = i + 1;
+                while (e < n && index_ray[e] == ray) ++e;
+                // perm doubles as the work array; without one, fall back to a selection by rank
+                for (int64_t q = i; q < e; ++q) {
+                    const float dq = depth[q];
+                    int64_t rank = 0;
+                    for (int64_t r = i; r < e; ++r) {
+                        const float dr = depth[r];
+                        rank += (dr < dq) || (dr == dq && r < q);
+                    }
+                    const int64_t dst = i + rank;
+                    if (perm) perm[dst] = q;
+                    out_depth[dst] = dq;
+                    out_index_tri[dst] = index_tri[q];
+                    for (int c = 0; c < 3; ++c) {
+                        out_points[dst * 3 + c] = points[q * 3 + c];
+                        out_origins[dst * 3 + c] = origins[q * 3 + c];
+                        out_vectors[dst * 3 + c] = vectors[q * 3 + c];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        for (int k = threadIdx.x; k < staged; k += RS_THREADS) {
+            if (!s_mine[k]) continue;
+            const int64_t src = b0 + s_src[k], dst = b0 + k;
+            if (perm) perm[dst] = src;
+            out_depth[dst] = s_depth[s_src[k]];
+            out_index_tri[dst] = index_tri[src];
+        }
+        for (int e = threadIdx.x; e < 3 * staged; e += RS_THREADS) {
+            const int k = e / 3, c = e - 3 * k;
+            if (!s_mine[k]) continue;
+            const int64_t src = (b0 + s_src[k]) * 3 + c, dst = b0 * 3 + e;
+            out_points[dst] = points[src];
+            out_origins[dst] = origins[src];
+            out_vectors[dst] = vectors[src];
+        }
+        __syncthreads();
+    }
+}
+
 // utils.py:1055-1063: float64 Cramer barycentrics -> fp32 clamp / renormalise -> uv -> floor -> clip.
 __global__ void texel_indices_kernel(const double *vertices, const int64_t *faces, const float *uv, const float *points,
                                      const int64_t *index_tri, int64_t n, int texture_size, int64_t *texel)
@@ -601,10 +706,30 @@ __global__ void texture_pack_kernel(TexArgs t, uint8_t *records)
     }
 }
 
-__global__ void texture_shade_packed_kernel(const uint8_t *records, int size, int n_lobes, int sigmoid_codec,
-                                            float lambda_thres, const int64_t *texel, const float *dirs, int64_t n,
-                                            float *rgb, float *sigma)
+// Every quantity a record decodes to is a function of ONE uint8 code, so a workgroup first evaluates the reference's
+// dequantisers (the same expressions as decode_record, hence the same bits) for all 256 codes into LDS and then
+// decodes by lookup: the 4L sin/cos, L exp and 3+3L colour decodes per sample become LDS reads.
+__global__ __launch_bounds__(256) void texture_shade_packed_kernel(const uint8_t *records, int size, int n_lobes,
+                                                                   int sigmoid_codec, float lambda_thres,
+                                                                   const int64_t *texel, const float *dirs, int64_t n,
+                                                                   float *rgb, float *sigma)
 {
+    __shared__ float s_sigma[256], s_col[256], s_caz[256], s_saz[256], s_sel[256], s_cel[256], s_lam[256];
+    {
+        const int c = threadIdx.x;
+        const float pi = 3.14159274101257324f;   // float32(np.pi)
+        const float a = (float)c / 255.0f;
+        s_sigma[c] = -logf(fmaxf(1.0f - a, 1e-6f)) / 0.005f;
+        s_col[c] = decode_color((uint8_t)c, sigmoid_codec);
+        const float az = (float)(uint8_t)(c - 128) / 128.0f * pi;
+        const float el = (float)c / 256.0f * pi;
+        s_caz[c] = cosf(az);
+        s_saz[c] = sinf(az);
+        s_sel[c] = sinf(el);
+        s_cel[c] = cosf(el);
+        s_lam[c] = expf((float)c * lambda_thres / 255.0f - 2.5f);
+    }
+    __syncthreads();
     const int n16 = (4 + 6 * n_lobes + 15) / 16;       // 16-byte pieces of the record that carry data
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t px = texel[i * 2] * size + texel[i * 2 + 1];
@@ -613,10 +738,23 @@ __global__ void texture_shade_packed_kernel(const uint8_t *records, int size, in
 #pragma unroll
         for (int k = 0; k < kTexelRecord / 16; ++k)
             if (k < n16) rec.q[k] = src[k];
-        float f[3 + 7 * QF_MAX_LOBES + 1];
-        decode_record(rec.b, n_lobes, sigmoid_codec, lambda_thres, f);
-        shade_decoded(f, n_lobes, dirs[i * 3], dirs[i * 3 + 1], dirs[i * 3 + 2], rgb + i * 3);
-        sigma[i] = f[3 + 7 * n_lobes];
+        const float dx = dirs[i * 3], dy = dirs[i * 3 + 1], dz = dirs[i * 3 + 2];
+        float r = 0.0f, g = 0.0f, b = 0.0f;
+        for (int l = 0; l < n_lobes; ++l) {
+            const uint8_t *q = rec.b + 4 + 6 * l;
+            const float se = s_sel[q[2]];
+            const float x0 = s_caz[q[1]] * se, x1 = s_saz[q[1]] * se, x2 = s_cel[q[2]];
+            const float nrm = sqrtf((x0 * x0 + x1 * x1) + x2 * x2);
+            const float dotp = ((x0 / nrm) * dx + (x1 / nrm) * dy) + (x2 / nrm) * dz;
+            const float e = expf(fabsf(s_lam[q[0]]) * (dotp - 1.0f));
+            r += s_col[q[3]] * e;
+            g += s_col[q[4]] * e;
+            b += s_col[q[5]] * e;
+        }
+        rgb[i * 3 + 0] = 1.0f / (1.0f + expf(-(s_col[rec.b[1]] + r)));
+        rgb[i * 3 + 1] = 1.0f / (1.0f + expf(-(s_col[rec.b[2]] + g)));
+        rgb[i * 3 + 2] = 1.0f / (1.0f + expf(-(s_col[rec.b[3]] + b)));
+        sigma[i] = s_sigma[rec.b[0]];
     }
 }
 
@@ -715,6 +853,24 @@ extern "C" int qf_resort_by_depth(const int64_t *index_ray, const float *depth, 
     if (n == 0) return QF_OK;
     if (!index_ray || !depth || !perm) return QF_ERR_INVALID_ARGUMENT;
     QF_SIMPLE_LAUNCH(resort_kernel, n, index_ray, depth, n, perm);
+    return QF_OK;
+}
+
+extern "C" int qf_resort_samples(const int64_t *index_ray, const float *depth, int64_t n, const float *points,
+                                 const float *origins, const float *vectors, const int64_t *index_tri, int64_t *perm,
+                                 float *out_points, float *out_depth, float *out_origins, float *out_vectors,
+                                 int64_t *out_index_tri, uint8_t *boundary, void *stream)
+{
+    if (n < 0) return QF_ERR_INVALID_ARGUMENT;
+    if (n == 0) return QF_OK;
+    if (!index_ray || !depth || !points || !origins || !vectors || !index_tri || !out_points || !out_depth ||
+        !out_origins || !out_vectors || !out_index_tri)
+        return QF_ERR_INVALID_ARGUMENT;
+    const int64_t n_chunks = (n + RS_CHUNK - 1) / RS_CHUNK;
+    hipLaunchKernelGGL(resort_samples_kernel, dim3((unsigned)(n_chunks < 65536 ? n_chunks : 65536)), dim3(RS_THREADS), 0,
+                       qf_stream(stream), index_ray, depth, n, points, origins, vectors, index_tri, perm, out_points,
+                       out_depth, out_origins, out_vectors, out_index_tri, boundary);
+    QF_LAUNCH_CHECK();
     return QF_OK;
 }
 

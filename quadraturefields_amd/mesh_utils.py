@@ -334,15 +334,28 @@ class MeshIntersection:
 
     def sampling_indexing(self, points, origins, vectors, index_ray, depth, index_tri, random=0):
         """Re-sort by (ray, depth) after deformation, boundaries, deltas -- mesh_utils.py:389-412, without
-        leaving the device."""
+        leaving the device.  Inference: ONE launch (``qf_resort_samples``: sort, gathers and boundaries fused).
+        When autograd is recording on the inputs (training) the permutation is applied with differentiable
+        indexing instead."""
         index_ray = _C.i64c(index_ray)
-        depth = _C.f32c(depth)
         n = depth.shape[0]
-        perm = torch.empty((n,), dtype=torch.int64, device=depth.device)
-        _C.check(_C.lib().qf_resort_by_depth(_C.ptr(index_ray), _C.ptr(depth), n, _C.ptr(perm), _C.stream()),
-                 "qf_resort_by_depth")
-        index_tri, index_ray = index_tri[perm], index_ray[perm]
-        points, depth, origins, vectors = points[perm], depth[perm], origins[perm], vectors[perm]
-        boundary = spc_render.mark_pack_boundaries(index_ray)
-        deltas = self.find_deltas(boundary, depth)
-        return points, deltas, boundary, vectors, index_ray, depth, index_tri, origins
+        dev = depth.device
+        if torch.is_grad_enabled() and any(t.requires_grad for t in (points, depth, origins, vectors)):
+            depth_c = _C.f32c(depth.detach())
+            perm = torch.empty((n,), dtype=torch.int64, device=dev)
+            _C.check(_C.lib().qf_resort_by_depth(_C.ptr(index_ray), _C.ptr(depth_c), n, _C.ptr(perm), _C.stream()),
+                     "qf_resort_by_depth")
+            index_tri, index_ray = index_tri[perm], index_ray[perm]
+            points, depth, origins, vectors = points[perm], depth[perm], origins[perm], vectors[perm]
+            boundary = spc_render.mark_pack_boundaries(index_ray)
+            return points, self.find_deltas(boundary, depth), boundary, vectors, index_ray, depth, index_tri, origins
+        points, depth, origins, vectors = (_C.f32c(t.detach()) for t in (points, depth, origins, vectors))
+        index_tri = _C.i64c(index_tri)
+        o_points, o_origins, o_vectors = torch.empty_like(points), torch.empty_like(origins), torch.empty_like(vectors)
+        o_depth, o_tri = torch.empty_like(depth), torch.empty_like(index_tri)
+        boundary = torch.empty((n,), dtype=torch.bool, device=dev)
+        _C.check(_C.lib().qf_resort_samples(
+            _C.ptr(index_ray), _C.ptr(depth), n, _C.ptr(points), _C.ptr(origins), _C.ptr(vectors), _C.ptr(index_tri),
+            None, _C.ptr(o_points), _C.ptr(o_depth), _C.ptr(o_origins), _C.ptr(o_vectors), _C.ptr(o_tri),
+            _C.ptr(boundary), _C.stream()), "qf_resort_samples")
+        return o_points, self.find_deltas(boundary, o_depth), boundary, o_vectors, index_ray, o_depth, o_tri, o_origins

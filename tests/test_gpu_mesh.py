@@ -300,3 +300,42 @@ def test_raster_guard_band_is_conservative(device, shells, subdiv, w, h, focal_s
         assert int(cnt_r.sum()) > 0
         compared += 1
     assert compared >= 2
+
+
+def test_resort_samples_fused_equals_lexsort(device):
+    """qf_resort_samples == np.lexsort((depth, ray)) + gathers + mark_pack_boundaries, bit for bit: rays of 1..64
+    samples with ties, chunk-boundary straddlers, one ray longer than the staged window (slow path), empty input."""
+    from quadraturefields_amd import synthetic
+    from quadraturefields_amd.mesh_utils import MeshIntersection
+    mi = MeshIntersection(synthetic.shell_mesh(n_shells=1, subdivisions=1), simplify_mesh=False, num_intersections=25)
+    rng = np.random.default_rng(5)
+    counts = rng.integers(1, 65, size=400)
+    counts[37] = 1500                                        # longer than chunk + halo
+    counts[rng.random(400) < 0.2] = 1
+    ray = np.repeat(np.arange(400) * 3, counts)              # grouped, non-contiguous ray ids
+    n = ray.shape[0]
+    depth = rng.random(n).astype(np.float32)
+    depth[rng.random(n) < 0.1] = 0.5                         # ties: stable order
+    depth[:5] = np.sort(depth[:5])
+    pts, org, vec = (rng.normal(size=(n, 3)).astype(np.float32) for _ in range(3))
+    tri = rng.integers(0, 1000, size=n)
+    order = np.lexsort((depth, ray))
+    t = lambda a: torch.from_numpy(a).to(device)
+    out = mi.sampling_indexing(t(pts), t(org), t(vec), t(ray), t(depth), t(tri))
+    points, deltas, boundary, vectors, index_ray, d_sorted, index_tri, origins = out
+    assert np.array_equal(points.cpu().numpy(), pts[order]) and np.array_equal(vectors.cpu().numpy(), vec[order])
+    assert np.array_equal(origins.cpu().numpy(), org[order]) and np.array_equal(d_sorted.cpu().numpy(), depth[order])
+    assert np.array_equal(index_tri.cpu().numpy(), tri[order]) and np.array_equal(index_ray.cpu().numpy(), ray[order])
+    assert boundary.dtype == torch.bool
+    assert np.array_equal(boundary.cpu().numpy(), np.r_[True, ray[1:] != ray[:-1]])
+    assert deltas.shape == (n,) and float(deltas[0]) == np.float32(0.005)
+    with torch.enable_grad():                                # the differentiable route gives the same arrays
+        p2 = t(pts).requires_grad_(True)
+        out2 = mi.sampling_indexing(p2, t(org), t(vec), t(ray), t(depth), t(tri))
+        assert out2[0].requires_grad and torch.equal(out2[0].detach(), points) and torch.equal(out2[5], d_sorted)
+        assert torch.equal(out2[2], boundary) and torch.equal(out2[6], index_tri)
+    e = torch.empty
+    out0 = mi.sampling_indexing(e((0, 3), device=device), e((0, 3), device=device), e((0, 3), device=device),
+                                e((0,), dtype=torch.int64, device=device), e((0,), device=device),
+                                e((0,), dtype=torch.int64, device=device))
+    assert out0[0].shape == (0, 3) and out0[2].shape == (0,)
