@@ -16,7 +16,7 @@
 //     four neurons of ITS OWN point -- exactly the B operand of the next layer's k-step, so
 //     activations never leave registers between layers (no LDS, no shuffles).  The k order of each
 //     layer is permuted to match; the permutation is folded into the LDS weight image.
-//   * workgroup = 8 waves, persistent: grid = CUs x 2, waves stride over the 16-point groups.
+//   * workgroup = 8 waves, persistent: grid = CUs, waves stride over the 16-point groups of their XCD's share.
 #include "field_common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -557,7 +557,10 @@ int launch_field(const FieldArgs &a, hipStream_t st)
     const size_t lds_bytes = (size_t)(n_m * 64 + 128 + 8 * QF_MAX_LEVELS) * sizeof(float);
     const int64_t n_groups = (a.n + 15) / 16;
     int64_t blocks = qf_div_up(n_groups, kBlock / 64);
-    const int64_t cap = (int64_t)qf_cu_count_cached() * 2;
+    // ONE 8-wave workgroup per CU.  The kernel is bound by the fabric's sector-request rate, not by latency hiding:
+    // measured on the bench frame, 4 / 6 / 8 / 10 / 12 / 16 waves per CU -> 2.17 / 1.54 / 1.39 / 1.60 / 1.52 / 1.53 ms
+    // (fewer points in flight per XCD = a smaller L2 working set; below 8 waves the gathers no longer cover the latency).
+    const int64_t cap = (int64_t)qf_cu_count_cached();
     if (blocks > cap) blocks = cap;
     if (blocks >= 64) blocks &= ~(int64_t)7;          // a multiple of 8: the XCD-contiguous mapping of field_kernel
     hipLaunchKernelGGL(field_kernel<HEAD>, dim3((unsigned)blocks), dim3(kBlock), lds_bytes, st, a);

@@ -314,7 +314,7 @@ int launch_field_b(const FieldArgsB &a, hipStream_t st)
     if (HEAD == QF_HEAD_SG) n_m = 18 + 2 * a.nt_out;
     const size_t lds_bytes = (size_t)n_m * 1024 + (128 + 8 * QF_MAX_LEVELS) * sizeof(float);
     int64_t blocks = qf_div_up((a.n + 15) / 16, kBlockB / 64);
-    const int64_t cap = (int64_t)qf_cu_count_cached() * 2;
+    const int64_t cap = (int64_t)qf_cu_count_cached();   // one workgroup per CU, see launch_field in field_eval.hip
     if (blocks > cap) blocks = cap;
     if (blocks >= 64) blocks &= ~(int64_t)7;
     hipLaunchKernelGGL(field_kernel_bf16<HEAD>, dim3((unsigned)blocks), dim3(kBlockB), lds_bytes, st, a);
