@@ -71,28 +71,42 @@ class Stages:
     def frame(self, o, d, cam=None, record=False):
         """cam (mesh_utils.make_camera): the rays are that camera's pixel grid -> camera-coherent intersector,
         with the exact K-nearest BVH traversal as fallback when a pixel collects more than MAX_HITS candidates."""
-        from quadraturefields_amd import utils
-        n_rays = o.shape[0]
+        return self.finish(self.begin(o, d, cam, record))
+
+    def begin(self, o, d, cam=None, record=False):
+        """First half of a frame on the current stream, no host wait: intersection, offsets scan, the 16-byte
+        readback, pack and ordering kernels."""
         ri = self.mi.rayintersector
         if ri.want_raster(cam):
-            hits = self._timed("traverse", lambda: ri._hits_raster_frame(o, d, MAX_HITS, cam) + (o, d), record)
+            hits = self._timed("traverse", lambda: ri._hits_raster_frame(o, d, MAX_HITS, cam), record)
         else:
-            hits = self._timed("traverse", lambda: ri._hits_bvh(o, d, MAX_HITS, W) + (None, o, d), record)
-        data = self._timed("pack", lambda: self._pack(hits), record)
+            hits = self._timed("traverse", lambda: ri._hits_bvh(o, d, MAX_HITS, W) + (None,), record)
+        hit_tri, hit_t, hit_count, overflow = hits
+        pending = self._timed("pack", lambda: ri.pack_hits_begin(o, d, MAX_HITS, hit_tri, hit_t, hit_count, overflow, W),
+                              record)
+        return pending, overflow is not None, record, o.shape[0]
+
+    def finish(self, begun):
+        """Second half, on the stream ``begin`` ran on: wait for the sample count, field, compositing."""
+        from quadraturefields_amd import utils
+        pending, rastered, record, n_rays = begun
+        ri = self.mi.rayintersector
+        before = ri._raster_backoff
+        data, order = ri.pack_hits_end(pending)
+        if rastered and ri._raster_backoff > before:
+            self.fallbacks = getattr(self, "fallbacks", 0) + 1
         xyz, dirs, index_ray, ts, index_tri, org = data
-        rgbs, sigmas = self._timed("field", lambda: self.field(xyz, dirs, order=self.order), record)
+        order = order if self.coherent else None
+        rgbs, sigmas = self._timed("field", lambda: self.field(xyz, dirs, order=order), record)
         out = self._timed("composite", lambda: utils.derive_properties(
             rgbs, sigmas.reshape(-1), ts, STEP, None, index_ray, bg_color="white", N=n_rays), record)
         rgb, alpha, _, depth, _ = out
         return rgb, alpha, depth, xyz.shape[0]
 
     def _pack(self, hits):
+        """(tools/field_bench.py) hits = (hit_tri, hit_t, hit_count, overflow, o, d) -> packed samples; sets .order."""
         hit_tri, hit_t, hit_count, overflow, o, d = hits
-        ri = self.mi.rayintersector
-        before = ri._raster_backoff
-        data, order = ri.pack_hits(o, d, MAX_HITS, hit_tri, hit_t, hit_count, overflow, W)
-        if overflow is not None and ri._raster_backoff > before:
-            self.fallbacks = getattr(self, "fallbacks", 0) + 1
+        data, order = self.mi.rayintersector.pack_hits(o, d, MAX_HITS, hit_tri, hit_t, hit_count, overflow, W)
         self.order = order if self.coherent else None
         return data
 
@@ -136,6 +150,10 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pipeline", type=int, default=1, choices=[1, 2, 3],
+                    help="frames in flight (one HIP stream each); 1 = strictly one frame after the other.  Measured: "
+                         "2 or 3 frames in flight are 4-5 %% SLOWER (the fabric-bound field kernels of two frames "
+                         "overlap each other and the small kernels gain nothing), so the default stays 1")
     ap.add_argument("--intersector", default="raster", choices=["raster", "bvh"],
                     help="raster: camera-coherent intersector (BVH fallback on overflow); bvh: BVH traversal only")
     args = ap.parse_args()
@@ -158,27 +176,43 @@ def main():
     rays = [synthetic.camera_rays(cams[i * world + rank], focal, W, H, device=device) for i in range(n_frames)]
     cameras = [None if args.intersector == "bvh" else make_camera(cams[i * world + rank], focal, W, H) for i in range(n_frames)]
     stages = Stages(mi, field)
-    gather_buf = torch.empty((world * W * H, 5), dtype=torch.float32, device=device) if world > 1 else None
 
-    def step(i, record):
-        o, d = rays[i]
-        rgb, alpha, depth, n_pts = stages.frame(o, d, cameras[i], record)
-        if world > 1:
-            torch.distributed.all_gather_into_tensor(gather_buf, torch.cat([rgb, alpha, depth], dim=1))
+    # --pipeline N keeps N frames in flight: frame i's intersection / pack kernels are enqueued on one stream before
+    # the host waits for frame i-1's sample count and launches its field + compositing kernels on another.
+    streams = [torch.cuda.Stream(device=device) for _ in range(max(1, args.pipeline))]
+    gather_bufs = {s: torch.empty((world * W * H, 5), dtype=torch.float32, device=device) for s in streams} if world > 1 else {}
+
+    def complete(begun, s):
+        with torch.cuda.stream(s):
+            rgb, alpha, depth, n_pts = stages.finish(begun)
+            if world > 1:
+                torch.distributed.all_gather_into_tensor(gather_bufs[s], torch.cat([rgb, alpha, depth], dim=1))
         return rgb, n_pts
 
-    for i in range(args.warmup):
-        step(i, False)
-        torch.cuda.synchronize()
-        log(f"warmup {i} done")
+    def run(first, last, record):
+        """Frames [first, last) with len(streams) of them in flight; returns (last rgb, total points)."""
+        inflight, pts, rgb = [], 0, None
+        for i in range(first, last):
+            s = streams[i % len(streams)]
+            with torch.cuda.stream(s):
+                begun = stages.begin(rays[i][0], rays[i][1], cameras[i], record)
+            inflight.append((begun, s))
+            if len(inflight) == len(streams):
+                rgb, n_pts = complete(*inflight.pop(0))
+                pts += n_pts
+        while inflight:
+            rgb, n_pts = complete(*inflight.pop(0))
+            pts += n_pts
+        return rgb, pts
+
+    run(0, args.warmup, False)
+    torch.cuda.synchronize()
+    log(f"{args.warmup} warmup frames done")
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    pts = 0
-    for i in range(args.warmup, n_frames):
-        rgb, n_pts = step(i, "field")
-        pts += n_pts
+    rgb, pts = run(args.warmup, n_frames, "field")
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
@@ -234,6 +268,7 @@ def main():
             "rays_per_frame": W * H, "max_hits": MAX_HITS, "triangles": int(mesh.faces.shape[0]),
             "log2_hashmap_size": LOG2_T, "render_step_size": STEP, "up_sample": 1,
             "intersector": args.intersector, "bvh_fallback_frames": getattr(stages, "fallbacks", 0),
+            "frames_in_flight": len(streams),
             "parallelism": f"{world} rank(s), one frame per rank per step" + (", all_gather of tiles" if world > 1 else ""),
         },
         "quadrature_points_per_frame": pts_per_launch,

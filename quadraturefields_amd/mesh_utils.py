@@ -145,7 +145,8 @@ class RayIntersector:
     def _frame_scratch(self, n):
         """Per-ray-count scratch reused across frames: [n+2] int64 = sample offsets | total | raster overflow flag,
         the scan's temp storage, a pinned host mirror of (total, overflow) and the event that guards it."""
-        s = self._scratch.get(n)
+        key = (n, torch.cuda.current_stream().cuda_stream)      # frames in flight on different streams do not share it
+        s = self._scratch.get(key)
         if s is None:
             buf = torch.zeros((n + 2,), dtype=torch.int64, device=self.device)
             nbytes = int(_C.lib().qf_sample_offsets_temp_bytes(n))
@@ -153,8 +154,8 @@ class RayIntersector:
                 raise _C.QFError("qf_sample_offsets_temp_bytes failed")
             temp = torch.empty((nbytes,), dtype=torch.uint8, device=self.device)
             host = torch.zeros((2,), dtype=torch.int64).pin_memory()
-            s = self._scratch[n] = (buf, temp, host, torch.cuda.Event())
-            if len(self._scratch) > 4:
+            s = self._scratch[key] = (buf, temp, host, torch.cuda.Event())
+            if len(self._scratch) > 8:
                 self._scratch.pop(next(iter(self._scratch)))
         return s
 
@@ -178,7 +179,12 @@ class RayIntersector:
         into buffers sized for the worst case (n_rays * K samples -- 60 B each, ~1 GB for an 800x800 frame, nothing
         against 288 GB) while the host waits for those 16 bytes; the results are views of the first ``total`` rows.
         ``overflow`` (from ``_hits_raster_frame``) marks lists with more than K candidates: the frame is redone with
-        the exact K-nearest BVH traversal."""
+        the exact K-nearest BVH traversal.  ``pack_hits_begin`` / ``pack_hits_end`` are the two halves, for callers
+        that keep several frames in flight on different streams."""
+        return self.pack_hits_end(self.pack_hits_begin(o, d, k, hit_tri, hit_t, hit_count, overflow, width))
+
+    def pack_hits_begin(self, o, d, k, hit_tri, hit_t, hit_count, overflow, width):
+        """Enqueue scan, readback, pack and ordering on the current stream; no host wait."""
         n = o.shape[0]
         dev = self.device
         buf, temp, host, ev = self._frame_scratch(n)
@@ -202,6 +208,12 @@ class RayIntersector:
         order = None
         if width > 0 and n % width == 0:
             order = self.coherent_order(hit_count, buf, cap, width)
+        return (o, d, k, width, host, ev, [xyz, dirs, index_ray, depth, index_tri, org], order,
+                (hit_tri, hit_t, hit_count))          # the lists stay referenced until the kernels reading them ran
+
+    def pack_hits_end(self, pending):
+        """Wait for the 16-byte readback of ``pack_hits_begin`` and slice the results (same stream as ``begin``)."""
+        o, d, k, width, host, ev, arrays, order, _lists = pending
         ev.synchronize()
         total, ovf = int(host[0]), int(host[1])
         if ovf:
@@ -210,8 +222,7 @@ class RayIntersector:
             return self.pack_hits(o, d, k, hit_tri, hit_t, hit_count, None, width)
         if total == 0:
             return None, None
-        data = [xyz[:total], dirs[:total], index_ray[:total], depth[:total], index_tri[:total], org[:total]]
-        return data, (order[:total] if order is not None else None)
+        return [t[:total] for t in arrays], (order[:total] if order is not None else None)
 
     def sample_device(self, origins, vectors, max_hits: Optional[int] = None, image_width: int = 0, camera=None):
         """Packed, sorted samples on the device: [xyzs, dirs, index_ray, ts, index_tri, origins] -- the six
