@@ -135,11 +135,13 @@ int qf_sg_features_to_rgb(const float *features, int64_t feat_stride, const floa
 
 /* Deformation field: examples/field.py Field.density (:186-203) as used at utils.py:555-566:
  * x01 = (x+scale)/(2 scale); cat[x01, grid(x01)] (35) -> hidden -> hidden -> 1, ReLU, biases.
- * w1 [hidden,35], b1, w2 [hidden,hidden], b2, wout [1,hidden], bout [1]; hidden must be 32.   */
+ * w1 [hidden,35], b1, w2 [hidden,hidden], b2, wout [1,hidden], bout [1]; hidden must be 32.
+ * order: NULL or a processing permutation as in qf_field_forward (results unchanged).          */
 int qf_deform_field_forward(const qf_grid_desc *grid /* host */, const float *table, float scale,
                             int32_t hidden, const float *w1, const float *b1, const float *w2,
                             const float *b2, const float *wout, const float *bout,
-                            const float *xyz, int64_t n, float *out /* [n] */, void *stream);
+                            const float *xyz, int64_t n, const int32_t *order, float *out /* [n] */,
+                            void *stream);
 
 /* xyz += (tanh(f)*scaling*(1,1,1) . dir) dir ; ts += same scalar.  utils.py:566-571.          */
 int qf_apply_deformation(const float *f /* [n] */, float scaling, const float *dirs,

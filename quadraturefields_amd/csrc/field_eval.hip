@@ -449,6 +449,7 @@ struct DeformArgs {
     float scale;
     const float *w1, *b1, *w2, *b2, *wout, *bout;
     const float *xyz;
+    const int32_t *order;
     int64_t n;
     float *out;
 };
@@ -492,13 +493,25 @@ __global__ __launch_bounds__(kBlock, 4) void deform_kernel(const DeformArgs a)
         lc[j].scale = a.grid.scale[level];
         lc[j].hashed = (a.grid.hashed_mask >> level) & 1u;
     }
+    // one contiguous eighth of the processing order per XCD (see field_kernel)
     const int64_t n_groups = (a.n + 15) >> 4;
-    const int64_t wave_global = (int64_t)blockIdx.x * (kBlock / 64) + (tid >> 6);
-    const int64_t wave_stride = (int64_t)gridDim.x * (kBlock / 64);
-    for (int64_t grp = wave_global; grp < n_groups; grp += wave_stride) {
+    int64_t grp_begin, grp_end, wave_stride;
+    if ((gridDim.x & 7) == 0) {
+        const int64_t per_xcd = (n_groups + 7) >> 3;
+        grp_begin = (int64_t)(blockIdx.x & 7) * per_xcd;
+        grp_end = grp_begin + per_xcd < n_groups ? grp_begin + per_xcd : n_groups;
+        grp_begin += (int64_t)(blockIdx.x >> 3) * (kBlock / 64) + (tid >> 6);
+        wave_stride = (int64_t)(gridDim.x >> 3) * (kBlock / 64);
+    } else {
+        grp_begin = (int64_t)blockIdx.x * (kBlock / 64) + (tid >> 6);
+        grp_end = n_groups;
+        wave_stride = (int64_t)gridDim.x * (kBlock / 64);
+    }
+    for (int64_t grp = grp_begin; grp < grp_end; grp += wave_stride) {
         const int64_t pt_raw = grp * 16 + p;
         const bool valid = pt_raw < a.n;
-        const int64_t pt = valid ? pt_raw : a.n - 1;
+        int64_t pt = valid ? pt_raw : a.n - 1;
+        if (a.order) pt = a.order[pt];
         // (x - (-s)) / (s - (-s)), field.py:195
         const float x01 = (a.xyz[pt * 3 + 0] + a.scale) / (a.scale + a.scale);
         const float y01 = (a.xyz[pt * 3 + 1] + a.scale) / (a.scale + a.scale);
@@ -654,8 +667,8 @@ extern "C" int qf_sg_features_to_rgb(const float *features, int64_t feat_stride,
 
 extern "C" int qf_deform_field_forward(const qf_grid_desc *grid, const float *table, float scale, int32_t hidden,
                                        const float *w1, const float *b1, const float *w2, const float *b2,
-                                       const float *wout, const float *bout, const float *xyz, int64_t n, float *out,
-                                       void *stream)
+                                       const float *wout, const float *bout, const float *xyz, int64_t n,
+                                       const int32_t *order, float *out, void *stream)
 {
     if (!grid || !table || n < 0 || !(scale > 0.0f)) return QF_ERR_INVALID_ARGUMENT;
     if (hidden != 32) return QF_ERR_UNSUPPORTED;
@@ -669,12 +682,14 @@ extern "C" int qf_deform_field_forward(const qf_grid_desc *grid, const float *ta
     a.scale = scale;
     a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2; a.wout = wout; a.bout = bout;
     a.xyz = xyz;
+    a.order = order;
     a.n = n;
     a.out = out;
     const size_t lds_bytes = (size_t)(kDeformMfma * 64 + 64) * sizeof(float);
     int64_t blocks = qf_div_up((n + 15) / 16, kBlock / 64);
-    const int64_t cap = (int64_t)qf_cu_count_cached() * 2;
+    const int64_t cap = (int64_t)qf_cu_count_cached();     // one workgroup per CU, see launch_field
     if (blocks > cap) blocks = cap;
+    if (blocks >= 64) blocks &= ~(int64_t)7;
     hipLaunchKernelGGL(deform_kernel, dim3((unsigned)blocks), dim3(kBlock), lds_bytes, qf_stream(stream), a);
     QF_LAUNCH_CHECK();
     return QF_OK;

@@ -16,6 +16,7 @@ import torch
 
 from . import _C
 from .datasets.utils import Rays, namedtuple_map
+from .field import Field as _Field
 
 NERF_SYNTHETIC_SCENES = ["chair", "drums", "ficus", "hotdog", "lego", "materials", "mic", "ship"]
 
@@ -182,7 +183,9 @@ def render_image_finetune_with_occgrid(
         loss = ((del_vector ** 2).mean() + ((del_vector_v - del_vector.detach()) ** 2).mean()).reshape(1)
     elif field_net is not None and scaling != 0:
         xyzs, ts = xyzs.clone(), ts.clone()
-        f = field_net(xyzs, return_grad=False)[0].detach().reshape(-1).contiguous()
+        # the samples arrive sorted by (ray, depth), which is the layout ``order`` was built for
+        f = (field_net(xyzs, return_grad=False, order=order) if isinstance(field_net, _Field)
+             else field_net(xyzs, return_grad=False))[0].detach().reshape(-1).contiguous()
         before = xyzs.clone() if mesh_finetune is not None else None
         _C.check(_C.lib().qf_apply_deformation(_C.ptr(f), float(scaling), _C.ptr(_C.f32c(dirs)), _C.ptr(xyzs),
                                                _C.ptr(ts), xyzs.shape[0], _C.stream()), "qf_apply_deformation")

@@ -120,6 +120,12 @@ def test_deform_field_matches_oracle(device):
     got, grad = f(x.to(device), return_grad=False)
     assert grad is None and got.shape == (3001, 1)
     _close(got, want, 2e-5, 2e-5)
+    # a processing permutation only changes the order in which points are visited
+    order = torch.randperm(3001, generator=torch.Generator().manual_seed(1)).to(torch.int32).to(device)
+    assert torch.equal(f(x.to(device), return_grad=False, order=order)[0], got)
+    big, _ = helpers.random_points(70001, seed=10, outside_frac=0.0)     # enough groups for the XCD-contiguous mapping
+    want_big = ofields.deform_field(big, helpers.oracle_deform_weights(f))
+    _close(f(big.to(device), return_grad=False)[0], want_big, 2e-5, 2e-5)
 
 
 def test_linearity_of_grid_in_table(device):

@@ -17,7 +17,8 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"])
     ap.add_argument("--order", default="coherent", choices=["ray", "tile", "tile4", "random", "coherent"])
-    ap.add_argument("--stage", default="field", choices=["field", "traverse", "raster", "pack", "composite", "frame"])
+    ap.add_argument("--deform-log2-t", type=int, default=24)
+    ap.add_argument("--stage", default="field", choices=["field", "traverse", "raster", "pack", "composite", "frame", "deform"])
     args = ap.parse_args()
     torch.set_grad_enabled(False)
     dev = torch.device("cuda:0")
@@ -52,7 +53,17 @@ def main():
             key = torch.randperm(n, device=dev)
         order = torch.argsort(key).to(torch.int32).contiguous()
 
+    net = None
+    if args.stage == "deform":      # the deformation field of train_finetune.py:387-399 (T = 2^24: a 1 GB fp32 table)
+        from quadraturefields_amd.field import Field
+        net = Field(scale=1.5, precision=16, log2_T=args.deform_log2_t, L=16, max_res=512, min_res=16, output_dim=1,
+                    hidden_size=32, num_features=2, back_prop=False, nl="relu")
+        net.load_state_dict(synthetic.seeded_deform_state(net.xyz_encoder.grid.n_params), strict=False)
+        net = net.to(dev)
+
     def run():
+        if args.stage == "deform":
+            return net(xyz, return_grad=False, order=order)[0]
         if args.stage == "field":
             return field(xyz, dirs, order=order)
         if args.stage == "traverse":
