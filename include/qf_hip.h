@@ -219,11 +219,18 @@ typedef struct qf_bvh qf_bvh; /* opaque; owns device memory */
 /* tri_verts: HOST pointer, [n_tri][3][3] fp32 (the layout of mesh.vertices[mesh.faces]).
  * Builds a SAH BVH on the host and uploads it.                                                */
 int qf_bvh_create(const float *tri_verts /* host */, int64_t n_tri, qf_bvh **out);
+/* Same, with the level (1..32) below which the builder stops taking SAH splits and halves the index range
+ * (qf_bvh_create uses 32).  Any value gives a valid tree and identical hits; small values trade traversal speed for
+ * a shallower tree -- used by the tests to exercise the depth bound.                            */
+int qf_bvh_create_ex(const float *tri_verts /* host */, int64_t n_tri, int32_t sah_depth, qf_bvh **out);
 /* Same topology, new vertex positions (Intersector.update_vertices / train_finetune.py:716-718). */
 int qf_bvh_refit(qf_bvh *bvh, const float *tri_verts /* host */, int64_t n_tri);
 void qf_bvh_destroy(qf_bvh *bvh);
 int64_t qf_bvh_num_triangles(const qf_bvh *bvh);
 int64_t qf_bvh_num_nodes(const qf_bvh *bvh);
+/* Depth of the deepest inner node (root = 1).  The builder guarantees <= 64, the size of the traversal stack, for
+ * any input: below level 32 it halves the index range instead of taking the SAH split.          */
+int32_t qf_bvh_max_depth(const qf_bvh *bvh);
 /* Host copies for inspection/tests: nodes as 16 floats each, leaf triangle ids. */
 int qf_bvh_copy_nodes(const qf_bvh *bvh, float *nodes_host, int64_t capacity_nodes);
 int qf_bvh_copy_tri_ids(const qf_bvh *bvh, int32_t *ids_host, int64_t capacity);

@@ -73,10 +73,12 @@ _SIGNATURES = {
     "qf_accumulate_along_rays": (c_int, [_P, _P, c_int32, _P, c_int64, c_int64, _P, _P]),
     "qf_render_from_density": (c_int, [_P, _P, _P, _P, _P, c_int64, c_int64, _P, _P, _P, _P, _P, _P, _P, _P]),
     "qf_bvh_create": (c_int, [_P, c_int64, POINTER(c_void_p)]),
+    "qf_bvh_create_ex": (c_int, [_P, c_int64, c_int32, POINTER(c_void_p)]),
     "qf_bvh_refit": (c_int, [_P, _P, c_int64]),
     "qf_bvh_destroy": (None, [_P]),
     "qf_bvh_num_triangles": (c_int64, [_P]),
     "qf_bvh_num_nodes": (c_int64, [_P]),
+    "qf_bvh_max_depth": (c_int32, [_P]),
     "qf_bvh_copy_nodes": (c_int, [_P, _P, c_int64]),
     "qf_bvh_copy_tri_ids": (c_int, [_P, _P, c_int64]),
     "qf_bvh_intersect": (c_int, [_P, _P, _P, c_int64, c_int32, c_int32, _P, _P, _P, _P]),

@@ -63,7 +63,7 @@ void store_child(float *node, int side, const Box &b, float eps, int32_t child, 
     node[14 + side] = as_float(count);
 }
 
-struct Task { int32_t node, begin, end; };
+struct Task { int32_t node, begin, end, depth; };
 
 // Chooses a partition of ids[begin,end) and returns mid.
 int32_t partition(std::vector<int32_t> &ids, const std::vector<Box> &boxes, const std::vector<float> &cent,
@@ -161,7 +161,7 @@ int upload(qf_bvh *bvh, const float *tri_verts)
     return QF_OK;
 }
 
-void build_host(qf_bvh *bvh, const float *tri_verts, int64_t n_tri)
+void build_host(qf_bvh *bvh, const float *tri_verts, int64_t n_tri, int sah_depth = QF_BVH_SAH_DEPTH)
 {
     bvh->n_tri = n_tri;
     bvh->h_tri_ids.resize((size_t)n_tri);
@@ -189,12 +189,16 @@ void build_host(qf_bvh *bvh, const float *tri_verts, int64_t n_tri)
         empty.reset();
         store_child(nodes.data(), 1, empty, 0.f, ~0, 0);
     } else {
-        stack.push_back({0, 0, (int32_t)n_tri});
+        stack.push_back({0, 0, (int32_t)n_tri, 1});
     }
+    bvh->max_depth = n_tri > 0 ? 1 : 0;
     while (!stack.empty()) {
         const Task t = stack.back();
         stack.pop_back();
-        const int32_t mid = partition(ids, boxes, cent, t.begin, t.end);
+        bvh->max_depth = std::max(bvh->max_depth, t.depth);
+        // below QF_BVH_SAH_DEPTH: halve the index range, so the remaining depth is at most log2(count)
+        const int32_t mid = t.depth >= sah_depth ? t.begin + (t.end - t.begin) / 2
+                                                        : partition(ids, boxes, cent, t.begin, t.end);
         const int32_t rng[2][2] = {{t.begin, mid}, {mid, t.end}};
         for (int side = 0; side < 2; ++side) {
             const int32_t b0 = rng[side][0], b1 = rng[side][1];
@@ -207,7 +211,7 @@ void build_host(qf_bvh *bvh, const float *tri_verts, int64_t n_tri)
                 const int32_t child = (int32_t)(nodes.size() / 16);
                 nodes.resize(nodes.size() + 16, 0.f);
                 store_child(&nodes[(size_t)t.node * 16], side, b, eps, child, 0);
-                stack.push_back({child, b0, b1});
+                stack.push_back({child, b0, b1, t.depth + 1});
             }
         }
     }
@@ -248,15 +252,24 @@ void refit_host(qf_bvh *bvh, const float *tri_verts)
 
 extern "C" int qf_bvh_create(const float *tri_verts, int64_t n_tri, qf_bvh **out)
 {
+    return qf_bvh_create_ex(tri_verts, n_tri, QF_BVH_SAH_DEPTH, out);
+}
+
+extern "C" int qf_bvh_create_ex(const float *tri_verts, int64_t n_tri, int32_t sah_depth, qf_bvh **out)
+{
     if (!out || n_tri < 0 || n_tri > 0x3fffffff || (n_tri > 0 && !tri_verts)) return QF_ERR_INVALID_ARGUMENT;
+    if (sah_depth < 1 || sah_depth > QF_BVH_SAH_DEPTH) return QF_ERR_INVALID_ARGUMENT;
     qf_bvh *bvh = new (std::nothrow) qf_bvh();
     if (!bvh) return QF_ERR_INVALID_ARGUMENT;
-    build_host(bvh, tri_verts, n_tri);
+    build_host(bvh, tri_verts, n_tri, sah_depth);
+    if (bvh->max_depth > QF_BVH_MAX_DEPTH) { qf_bvh_destroy(bvh); return QF_ERR_UNSUPPORTED; }   // cannot happen, see bvh.h
     int rc = upload(bvh, tri_verts);
     if (rc != QF_OK) { qf_bvh_destroy(bvh); return rc; }
     *out = bvh;
     return QF_OK;
 }
+
+extern "C" int32_t qf_bvh_max_depth(const qf_bvh *bvh) { return bvh ? bvh->max_depth : -1; }
 
 extern "C" int qf_bvh_refit(qf_bvh *bvh, const float *tri_verts, int64_t n_tri)
 {

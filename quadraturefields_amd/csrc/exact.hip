@@ -17,7 +17,7 @@
 namespace {
 
 constexpr int kMaxHits = QF_BVH_MAX_HITS;
-constexpr int kStack = 64;
+constexpr int kStack = QF_BVH_MAX_DEPTH;   // one deferred sibling per level; the builder bounds the depth (bvh.h)
 
 // fp32 Moller-Trumbore, operation order shared verbatim (as a contract, not as code) with the oracle.
 __device__ __forceinline__ bool mt_hit(const float4 a, const float4 b, const float4 c, const float ox, const float oy,

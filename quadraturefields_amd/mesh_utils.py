@@ -40,7 +40,7 @@ class RayIntersector:
     """Multi-hit ray/mesh intersector.  Duck-types trimesh's ``RayMeshIntersector`` and the reference's OptiX
     adapter (``intersects_id``, ``update_intersector``; mesh_utils.py:75-109)."""
 
-    def __init__(self, mesh: TriMesh, max_hits: int = 10, device="cuda:0"):
+    def __init__(self, mesh: TriMesh, max_hits: int = 10, device="cuda:0", sah_depth: int = 32):
         if max_hits < 1 or max_hits > _C.QF_BVH_MAX_HITS:
             raise ValueError(f"max_hits must be in 1..{_C.QF_BVH_MAX_HITS}")
         self.mesh = mesh
@@ -52,8 +52,8 @@ class RayIntersector:
         self._handle = ctypes.c_void_p()
         tri = np.ascontiguousarray(mesh.vertices.astype(np.float32)[mesh.faces].reshape(-1, 9))
         with torch.cuda.device(self.device):
-            _C.check(_C.lib().qf_bvh_create(tri.ctypes.data_as(ctypes.c_void_p), tri.shape[0],
-                                            ctypes.byref(self._handle)), "qf_bvh_create")
+            _C.check(_C.lib().qf_bvh_create_ex(tri.ctypes.data_as(ctypes.c_void_p), tri.shape[0], int(sah_depth),
+                                               ctypes.byref(self._handle)), "qf_bvh_create_ex")
 
     def __del__(self):
         h = getattr(self, "_handle", None)
@@ -67,6 +67,10 @@ class RayIntersector:
     @property
     def num_nodes(self) -> int:
         return int(_C.lib().qf_bvh_num_nodes(self._handle))
+
+    @property
+    def max_depth(self) -> int:
+        return int(_C.lib().qf_bvh_max_depth(self._handle))
 
     def update_intersector(self, vertices) -> None:
         """New vertex positions, same faces (Intersector.update_vertices; train_finetune.py:716-718).

@@ -339,3 +339,36 @@ def test_resort_samples_fused_equals_lexsort(device):
                                 e((0,), dtype=torch.int64, device=device), e((0,), device=device),
                                 e((0,), dtype=torch.int64, device=device))
     assert out0[0].shape == (0, 3) and out0[2].shape == (0,)
+
+
+def test_bvh_depth_is_bounded_on_lopsided_input(device):
+    """The traversal stack holds 64 entries, so the builder bounds the depth for ANY input: below ``sah_depth`` it
+    halves the index range instead of taking the SAH split.  Geometrically growing triangles (every SAH split peels a
+    few off the far end) built with the default and with a tiny ``sah_depth`` (which forces the halving path): depth
+    within the bound, hits those of the brute force, bit for bit."""
+    from quadraturefields_amd.mesh_io import TriMesh
+    from quadraturefields_amd.mesh_utils import RayIntersector
+    n = 3000
+    k = np.arange(n, dtype=np.float64)
+    x = 1e-6 * 1.03 ** k                                    # 1e-6 .. ~3e32
+    s = x * 0.02
+    v = np.stack([np.stack([x, -s, -s], 1), np.stack([x, s, -s], 1), np.stack([x, np.zeros(n), s], 1)], 1).reshape(-1, 3)
+    mesh = TriMesh(v.astype(np.float32).astype(np.float64), np.arange(3 * n).reshape(n, 3))
+    rng = np.random.default_rng(0)
+    m = 300
+    o = np.zeros((m, 3), np.float32)
+    o[:, 0] = -1.0
+    d = np.stack([np.ones(m), rng.normal(size=m) * 5e-3, rng.normal(size=m) * 5e-3], 1)
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    tri_o, t_o, cnt_o = om.BruteForceIntersector(mesh.vertices, mesh.faces).hits(o, d, 64)
+    assert int(cnt_o.max()) >= 10
+    depths = []
+    for sah_depth in (32, 3):
+        ri = RayIntersector(mesh, max_hits=64, sah_depth=sah_depth)
+        depths.append(ri.max_depth)
+        assert 1 <= ri.max_depth <= 64
+        tri, t, cnt, _, _ = ri.hits(o, d)
+        assert np.array_equal(cnt.cpu().numpy(), cnt_o) and np.array_equal(tri.cpu().numpy(), tri_o)
+        assert np.array_equal(t.cpu().numpy(), t_o)
+    assert depths[0] >= 25                                  # lopsided under SAH ...
+    assert depths[1] <= 3 + 12                              # ... and at most sah_depth + ceil(log2(3000)) when halving
