@@ -96,10 +96,15 @@ class Stages:
         if rastered and ri._raster_backoff > before:
             self.fallbacks = getattr(self, "fallbacks", 0) + 1
         xyz, dirs, index_ray, ts, index_tri, org = data
-        order = order if self.coherent else None
-        rgbs, sigmas = self._timed("field", lambda: self.field(xyz, dirs, order=order), record)
+        layout = ri.last_layout if self.coherent else None
+        if layout is not None:      # stream the coherent copies; compositing picks colour / density up through the inverse map
+            inverse, xyz_c, dirs_c = layout
+            rgbs, sigmas = self._timed("field", lambda: self.field(xyz_c, dirs_c), record)
+        else:
+            inverse = None
+            rgbs, sigmas = self._timed("field", lambda: self.field(xyz, dirs, order=order if self.coherent else None), record)
         out = self._timed("composite", lambda: utils.derive_properties(
-            rgbs, sigmas.reshape(-1), ts, STEP, None, index_ray, bg_color="white", N=n_rays), record)
+            rgbs, sigmas.reshape(-1), ts, STEP, None, index_ray, bg_color="white", N=n_rays, sample_index=inverse), record)
         rgb, alpha, _, depth, _ = out
         return rgb, alpha, depth, xyz.shape[0]
 

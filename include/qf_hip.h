@@ -166,7 +166,10 @@ int qf_sum_reduce(const float *feats /* [n,c] */, int32_t c, const int64_t *seg_
  * per ray tau = sigma*delta, w = exp(-excl cumsum tau)(1-exp(-tau)); writes the reference's
  * full-image buffers rgb [n_rays,3], alpha [n_rays,1], depth [n_rays,1] (rays without samples:
  * white unless bg_mode == black, alpha 0, depth 0) and weights [n].
- * bg_mode: 0 white, 1 black, 2 "random" (uses bkgd[3]); the double-alpha quirk is reproduced. */
+ * bg_mode: 0 white, 1 black, 2 "random" (uses bkgd[3]); the double-alpha quirk is reproduced.
+ * sample_index: NULL, or int32 [n]: sample i's colour and density are rgb_s[sample_index[i]] / sigma[sample_index[i]]
+ * (they were produced in the field kernel's processing order, see qf_coherent_layout); depth, deltas, index_ray and
+ * the weights output stay indexed by i.                                                         */
 #define QF_BG_WHITE 0
 #define QF_BG_BLACK 1
 #define QF_BG_CUSTOM 2
@@ -174,8 +177,8 @@ int qf_derive_properties(const float *rgb_s /* [n,3] */, const float *sigma /* [
                          const float *depth /* [n] */, const float *deltas /* [n] or NULL */,
                          float delta_const, const int64_t *index_ray /* [n] */, int64_t n,
                          int64_t n_rays, int32_t bg_mode, const float *bkgd /* [3] or NULL */,
-                         float *out_rgb, float *out_alpha, float *out_depth, float *weights,
-                         void *stream);
+                         const int32_t *sample_index, float *out_rgb, float *out_alpha, float *out_depth,
+                         float *weights, void *stream);
 
 /* Backward of qf_derive_properties (training side: the loss of examples/train_finetune.py:489-533 back-propagates
  * through utils.py:139-186).  g_rgb [n_rays,3], g_alpha / g_depth [n_rays] or NULL -> grad_rgb_s [n,3],
@@ -298,11 +301,17 @@ int qf_sample_offsets(const int32_t *hit_count, int64_t n_rays, int32_t max_hits
  * (mesh_utils.py:359-387), already sorted by (ray, depth): location = o + t d in float64,
  * dirs = d/(|d|+1e-7), depth = |location - o| (float64, rounded to fp32 at the end).
  * The per-ray lists may be in any order (they are sorted by (t, tri) first); counts above max_hits are clamped.
- * ray_offset [n_rays] = exclusive prefix sum of min(hit_count, max_hits).                       */
+ * ray_offset [n_rays] = exclusive prefix sum of min(hit_count, max_hits).
+ * inverse (NULL to skip; from qf_coherent_layout): sample -> position in the field kernel's processing order;
+ * xyz_c / dirs_c [n,3] then receive a second copy of the positions / directions IN that order, so that
+ * qf_field_forward can stream them (order = NULL) and write its outputs sequentially, and
+ * qf_derive_properties picks colour and density back up through sample_index = inverse.  Measured: the indirection
+ * through `order` costs the field kernel 10 % (two scattered sector reads and a scattered write per point).  */
 int qf_pack_samples(const float *rays_o, const float *rays_d, int64_t n_rays, int32_t max_hits,
                     const int32_t *hit_tri, const float *hit_t, const int32_t *hit_count,
                     const int64_t *ray_offset, float *xyz, float *dirs, int64_t *index_ray,
-                    float *depth, int64_t *index_tri, float *origins, void *stream);
+                    float *depth, int64_t *index_tri, float *origins, const int32_t *inverse,
+                    float *xyz_c, float *dirs_c, void *stream);
 
 /* Spatially coherent PROCESSING order for qf_field_forward when the rays are a row-major width x height image:
  * (8x8 pixel tile, hit rank, pixel in tile).  Two steps around one exclusive scan the caller does:
@@ -313,6 +322,9 @@ int qf_pack_samples(const float *rays_o, const float *rays_d, int64_t n_rays, in
 int qf_tile_totals(const int32_t *hit_count, int32_t width, int32_t height, int64_t *tile_total, void *stream);
 int qf_coherent_order(const int32_t *hit_count, const int64_t *ray_offset, const int64_t *tile_base,
                       int32_t width, int32_t height, int32_t *order, void *stream);
+/* Same order together with its inverse: inverse[sample] = position (see qf_pack_samples).      */
+int qf_coherent_layout(const int32_t *hit_count, const int64_t *ray_offset, const int64_t *tile_base,
+                       int32_t width, int32_t height, int32_t *order, int32_t *inverse, void *stream);
 
 /* Stable per-ray re-sort by depth after deformation (sampling_indexing, mesh_utils.py:394-403):
  * perm[i] = source index of the sample that lands at i.  index_ray must be grouped by ray.   */

@@ -66,7 +66,7 @@ _SIGNATURES = {
     "qf_mark_pack_boundaries": (c_int, [_P, c_int64, _P, _P]),
     "qf_exponential_integration": (c_int, [_P, c_int32, _P, _P, c_int64, c_int64, c_int32, _P, _P, _P]),
     "qf_sum_reduce": (c_int, [_P, c_int32, _P, c_int64, c_int64, _P, _P]),
-    "qf_derive_properties": (c_int, [_P, _P, _P, _P, c_float, _P, c_int64, c_int64, c_int32, _P, _P, _P, _P, _P, _P]),
+    "qf_derive_properties": (c_int, [_P, _P, _P, _P, c_float, _P, c_int64, c_int64, c_int32, _P, _P, _P, _P, _P, _P, _P]),
     "qf_derive_properties_backward": (c_int, [_P, _P, _P, _P, c_float, _P, c_int64, c_int32, _P, _P, _P, _P, _P, _P, _P, _P]),
     "qf_pack_info": (c_int, [_P, c_int64, c_int64, _P, _P]),
     "qf_exclusive_scan": (c_int, [_P, _P, c_int64, c_int64, c_int32, _P, _P]),
@@ -91,9 +91,10 @@ _SIGNATURES = {
     "qf_scatter_max": (c_int, [_P, _P, c_int64, c_int64, _P, _P]),
     "qf_sample_offsets_temp_bytes": (c_int64, [c_int64]),
     "qf_sample_offsets": (c_int, [_P, c_int64, c_int32, _P, _P, c_int64, _P]),
-    "qf_pack_samples": (c_int, [_P, _P, c_int64, c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "qf_pack_samples": (c_int, [_P, _P, c_int64, c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "qf_tile_totals": (c_int, [_P, c_int32, c_int32, _P, _P]),
     "qf_coherent_order": (c_int, [_P, _P, _P, c_int32, c_int32, _P, _P]),
+    "qf_coherent_layout": (c_int, [_P, _P, _P, c_int32, c_int32, _P, _P, _P]),
     "qf_resort_by_depth": (c_int, [_P, _P, c_int64, _P, _P]),
     "qf_resort_samples": (c_int, [_P, _P, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "qf_texel_indices": (c_int, [_P, _P, _P, _P, _P, c_int64, c_int32, _P, _P]),

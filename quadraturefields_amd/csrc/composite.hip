@@ -40,8 +40,8 @@ constexpr int DP_STAGE = DP_CHUNK + DP_HALO;
 
 __global__ __launch_bounds__(DP_THREADS) void derive_properties_kernel(
     const float *rgb_s, const float *sigma, const float *depth_s, const float *deltas, float delta_const,
-    const int64_t *index_ray, int64_t n, int bg_mode, const float *bkgd, float *out_rgb, float *out_alpha,
-    float *out_depth, float *weights)
+    const int64_t *index_ray, int64_t n, int bg_mode, const float *bkgd, const int32_t *sample_index, float *out_rgb,
+    float *out_alpha, float *out_depth, float *weights)
 {
     __shared__ float s_tau[DP_STAGE];
     __shared__ float s_alpha[DP_STAGE];              // 1 - exp(-tau), computed by all lanes before the serial part
@@ -62,14 +62,22 @@ __global__ __launch_bounds__(DP_THREADS) void derive_properties_kernel(
             s_nheads = 0;
         }
         for (int k = threadIdx.x; k < staged; k += DP_THREADS) {
-            const float tau = sigma[b0 + k] * (deltas ? deltas[b0 + k] : delta_const);
+            // sample_index: colour and density live at another position (the field kernel's processing order)
+            const int64_t src = sample_index ? (int64_t)sample_index[b0 + k] : b0 + k;
+            const float tau = sigma[src] * (deltas ? deltas[b0 + k] : delta_const);
             s_tau[k] = tau;
             s_alpha[k] = 1.0f - expf(-tau);
             s_dep[k] = depth_s[b0 + k];
             s_ray[k + 1] = index_ray[b0 + k];
             s_mine[k] = 0;
+            if (sample_index) {
+                s_rgb[3 * k + 0] = rgb_s[src * 3 + 0];
+                s_rgb[3 * k + 1] = rgb_s[src * 3 + 1];
+                s_rgb[3 * k + 2] = rgb_s[src * 3 + 2];
+            }
         }
-        for (int k = threadIdx.x; k < 3 * staged; k += DP_THREADS) s_rgb[k] = rgb_s[b0 * 3 + k];
+        if (!sample_index)
+            for (int k = threadIdx.x; k < 3 * staged; k += DP_THREADS) s_rgb[k] = rgb_s[b0 * 3 + k];
         __syncthreads();
         for (int k = threadIdx.x; k < own; k += DP_THREADS)
             if (b0 + k == 0 || s_ray[k] != s_ray[k + 1]) s_heads[atomicAdd(&s_nheads, 1)] = k;
@@ -93,13 +101,14 @@ __global__ __launch_bounds__(DP_THREADS) void derive_properties_kernel(
             }
             if (j == staged) {                       // the ray runs past the staged window
                 for (int64_t g = b0 + staged; g < n && index_ray[g] == ray; ++g) {
-                    const float tau = sigma[g] * (deltas ? deltas[g] : delta_const);
+                    const int64_t src = sample_index ? (int64_t)sample_index[g] : g;
+                    const float tau = sigma[src] * (deltas ? deltas[g] : delta_const);
                     const float w = expf(-cum) * (1.0f - expf(-tau));
                     cum += tau;
                     weights[g] = w;
-                    cr += w * rgb_s[g * 3 + 0];
-                    cg += w * rgb_s[g * 3 + 1];
-                    cb += w * rgb_s[g * 3 + 2];
+                    cr += w * rgb_s[src * 3 + 0];
+                    cg += w * rgb_s[src * 3 + 1];
+                    cb += w * rgb_s[src * 3 + 2];
                     cd += w * depth_s[g];
                     ca += w;
                 }
@@ -295,8 +304,8 @@ extern "C" int qf_sum_reduce(const float *feats, int32_t c, const int64_t *seg_s
 
 extern "C" int qf_derive_properties(const float *rgb_s, const float *sigma, const float *depth, const float *deltas,
                                     float delta_const, const int64_t *index_ray, int64_t n, int64_t n_rays,
-                                    int32_t bg_mode, const float *bkgd, float *out_rgb, float *out_alpha,
-                                    float *out_depth, float *weights, void *stream)
+                                    int32_t bg_mode, const float *bkgd, const int32_t *sample_index, float *out_rgb,
+                                    float *out_alpha, float *out_depth, float *weights, void *stream)
 {
     if (n < 0 || n_rays < 0 || bg_mode < 0 || bg_mode > 2) return QF_ERR_INVALID_ARGUMENT;
     if (n_rays > 0 && (!out_rgb || !out_alpha || !out_depth)) return QF_ERR_INVALID_ARGUMENT;
@@ -309,8 +318,8 @@ extern "C" int qf_derive_properties(const float *rgb_s, const float *sigma, cons
     if (!rgb_s || !sigma || !depth || !index_ray || !weights) return QF_ERR_INVALID_ARGUMENT;
     const int64_t n_chunks = (n + DP_CHUNK - 1) / DP_CHUNK;
     hipLaunchKernelGGL(derive_properties_kernel, dim3((unsigned)(n_chunks < 65536 ? n_chunks : 65536)), dim3(DP_THREADS), 0,
-                       qf_stream(stream), rgb_s, sigma, depth, deltas, delta_const, index_ray, n, (int)bg_mode, bkgd, out_rgb,
-                       out_alpha, out_depth, weights);
+                       qf_stream(stream), rgb_s, sigma, depth, deltas, delta_const, index_ray, n, (int)bg_mode, bkgd, sample_index,
+                       out_rgb, out_alpha, out_depth, weights);
     QF_LAUNCH_CHECK();
     return QF_OK;
 }
@@ -398,9 +407,10 @@ __global__ __launch_bounds__(64) void tile_totals_kernel(const int32_t *hit_coun
     if (lane == 0) tile_total[tile] = cnt;
 }
 
+// order[pos] = sample (ray-major index) for every position of the coherent sequence; optionally the inverse map too.
 __global__ __launch_bounds__(64) void coherent_order_kernel(const int32_t *hit_count, const int64_t *ray_offset,
                                                             const int64_t *tile_base, int w, int h, int tiles_x,
-                                                            int32_t *order)
+                                                            int32_t *order, int32_t *inverse)
 {
     const int tile = blockIdx.x, lane = threadIdx.x;
     int64_t ray = 0;
@@ -412,7 +422,11 @@ __global__ __launch_bounds__(64) void coherent_order_kernel(const int32_t *hit_c
     for (int k = 0;; ++k) {
         const unsigned long long mask = __ballot(cnt > k);
         if (mask == 0ull) break;                      // wave-uniform exit
-        if (cnt > k) order[base + __popcll(mask & below)] = (int32_t)(first + k);
+        if (cnt > k) {
+            const int64_t pos = base + __popcll(mask & below), smp = first + k;
+            order[pos] = (int32_t)smp;
+            if (inverse) inverse[smp] = (int32_t)pos;
+        }
         base += __popcll(mask);
     }
 }
@@ -435,7 +449,19 @@ extern "C" int qf_coherent_order(const int32_t *hit_count, const int64_t *ray_of
     if (width < 1 || height < 1 || !hit_count || !ray_offset || !tile_base || !order) return QF_ERR_INVALID_ARGUMENT;
     const int tiles_x = (width + 7) / 8, tiles_y = (height + 7) / 8;
     hipLaunchKernelGGL(coherent_order_kernel, dim3(tiles_x * tiles_y), dim3(64), 0, qf_stream(stream), hit_count,
-                       ray_offset, tile_base, (int)width, (int)height, tiles_x, order);
+                       ray_offset, tile_base, (int)width, (int)height, tiles_x, order, (int32_t *)nullptr);
+    QF_LAUNCH_CHECK();
+    return QF_OK;
+}
+
+extern "C" int qf_coherent_layout(const int32_t *hit_count, const int64_t *ray_offset, const int64_t *tile_base,
+                                  int32_t width, int32_t height, int32_t *order, int32_t *inverse, void *stream)
+{
+    if (width < 1 || height < 1 || !hit_count || !ray_offset || !tile_base || !order || !inverse)
+        return QF_ERR_INVALID_ARGUMENT;
+    const int tiles_x = (width + 7) / 8, tiles_y = (height + 7) / 8;
+    hipLaunchKernelGGL(coherent_order_kernel, dim3(tiles_x * tiles_y), dim3(64), 0, qf_stream(stream), hit_count,
+                       ray_offset, tile_base, (int)width, (int)height, tiles_x, order, inverse);
     QF_LAUNCH_CHECK();
     return QF_OK;
 }

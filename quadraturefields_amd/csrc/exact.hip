@@ -347,7 +347,8 @@ __global__ __launch_bounds__(kPackRays) void pack_samples_kernel(
     const int32_t *__restrict__ hit_tri, const float *__restrict__ hit_t, const int32_t *__restrict__ hit_count,
     const int64_t *__restrict__ ray_offset, float *__restrict__ xyz, float *__restrict__ dirs,
     int64_t *__restrict__ index_ray, float *__restrict__ depth, int64_t *__restrict__ index_tri,
-    float *__restrict__ origins)
+    float *__restrict__ origins, const int32_t *__restrict__ inverse, float *__restrict__ xyz_c,
+    float *__restrict__ dirs_c)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int K = max_hits, Kp = max_hits | 1;            // odd row stride: conflict-free column access
@@ -437,6 +438,15 @@ __global__ __launch_bounds__(kPackRays) void pack_samples_kernel(
         index_ray[o] = ray;
         depth[o] = (float)dep;
         index_tri[o] = (int64_t)s_tri[rl * Kp + k];
+        if (inverse) {          // a second copy at the sample's place in the field kernel's processing order
+            const int64_t c = inverse[o];
+            xyz_c[c * 3 + 0] = (float)p[0];
+            xyz_c[c * 3 + 1] = (float)p[1];
+            xyz_c[c * 3 + 2] = (float)p[2];
+            dirs_c[c * 3 + 0] = dx / nrm;
+            dirs_c[c * 3 + 1] = dy / nrm;
+            dirs_c[c * 3 + 2] = dz / nrm;
+        }
     }
 }
 
@@ -831,18 +841,20 @@ extern "C" int qf_bvh_intersect(const qf_bvh *bvh, const float *rays_o, const fl
 extern "C" int qf_pack_samples(const float *rays_o, const float *rays_d, int64_t n_rays, int32_t max_hits,
                                const int32_t *hit_tri, const float *hit_t, const int32_t *hit_count,
                                const int64_t *ray_offset, float *xyz, float *dirs, int64_t *index_ray, float *depth,
-                               int64_t *index_tri, float *origins, void *stream)
+                               int64_t *index_tri, float *origins, const int32_t *inverse, float *xyz_c, float *dirs_c,
+                               void *stream)
 {
     if (n_rays < 0 || max_hits < 1 || max_hits > kMaxHits) return QF_ERR_INVALID_ARGUMENT;
     if (n_rays == 0) return QF_OK;
     if (!rays_o || !rays_d || !hit_tri || !hit_t || !hit_count || !ray_offset) return QF_ERR_INVALID_ARGUMENT;
+    if (inverse && (!xyz_c || !dirs_c)) return QF_ERR_INVALID_ARGUMENT;
     const int Kp = max_hits | 1;
     const size_t lds = (size_t)kPackRays * Kp * 8 + (size_t)kPackRays * max_hits * 2 + 64;
     const int64_t blocks = qf_div_up(n_rays, kPackRays);
     if (blocks > 0x7fffffff) return QF_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(pack_samples_kernel, dim3((unsigned)blocks), dim3(kPackRays), lds, qf_stream(stream), rays_o, rays_d,
                        n_rays, (int)max_hits, hit_tri, hit_t, hit_count, ray_offset, xyz, dirs, index_ray, depth, index_tri,
-                       origins);
+                       origins, inverse, xyz_c, dirs_c);
     QF_LAUNCH_CHECK();
     return QF_OK;
 }

@@ -49,6 +49,7 @@ class RayIntersector:
         self.last_order = None           # coherent processing order of the most recent image-shaped sample_device()
         self._raster_backoff = 0         # frames left to skip the camera-coherent intersector after an overflow
         self._scratch = {}               # per-ray-count frame scratch, see _frame_scratch
+        self.last_layout = None          # (inverse, xyz, dirs) of the most recent image-shaped pack, in the coherent order
         self._handle = ctypes.c_void_p()
         tri = np.ascontiguousarray(mesh.vertices.astype(np.float32)[mesh.faces].reshape(-1, 9))
         with torch.cuda.device(self.device):
@@ -205,27 +206,32 @@ class RayIntersector:
         index_ray = torch.empty((cap,), dtype=torch.int64, device=dev)
         index_tri = torch.empty((cap,), dtype=torch.int64, device=dev)
         depth = torch.empty((cap,), dtype=torch.float32, device=dev)
+        order = inverse = xyz_c = dirs_c = layout = None
+        if width > 0 and n % width == 0:      # image-shaped: the coherent order, its inverse, and streamed copies
+            order, inverse = self.coherent_layout(hit_count, buf, cap, width)
+            xyz_c, dirs_c = torch.empty_like(xyz), torch.empty_like(dirs)
+            layout = (inverse, xyz_c, dirs_c)
         _C.check(_C.lib().qf_pack_samples(_C.ptr(o), _C.ptr(d), n, k, _C.ptr(hit_tri), _C.ptr(hit_t),
                                           _C.ptr(hit_count), _C.ptr(buf), _C.ptr(xyz), _C.ptr(dirs),
                                           _C.ptr(index_ray), _C.ptr(depth), _C.ptr(index_tri), _C.ptr(org),
-                                          _C.stream()), "qf_pack_samples")
-        order = None
-        if width > 0 and n % width == 0:
-            order = self.coherent_order(hit_count, buf, cap, width)
-        return (o, d, k, width, host, ev, [xyz, dirs, index_ray, depth, index_tri, org], order,
+                                          _C.ptr(inverse), _C.ptr(xyz_c), _C.ptr(dirs_c), _C.stream()), "qf_pack_samples")
+        return (o, d, k, width, host, ev, [xyz, dirs, index_ray, depth, index_tri, org], order, layout,
                 (hit_tri, hit_t, hit_count))          # the lists stay referenced until the kernels reading them ran
 
     def pack_hits_end(self, pending):
         """Wait for the 16-byte readback of ``pack_hits_begin`` and slice the results (same stream as ``begin``)."""
-        o, d, k, width, host, ev, arrays, order, _lists = pending
+        o, d, k, width, host, ev, arrays, order, layout, _lists = pending
         ev.synchronize()
         total, ovf = int(host[0]), int(host[1])
         if ovf:
             self.raster_overflowed()
             hit_tri, hit_t, hit_count = self._hits_bvh(o, d, k, width)
             return self.pack_hits(o, d, k, hit_tri, hit_t, hit_count, None, width)
+        self.last_layout = None
         if total == 0:
             return None, None
+        if layout is not None:      # (inverse, xyz, dirs) in the coherent order: see coherent_layout
+            self.last_layout = tuple(t[:total] for t in layout)
         return [t[:total] for t in arrays], (order[:total] if order is not None else None)
 
     def sample_device(self, origins, vectors, max_hits: Optional[int] = None, image_width: int = 0, camera=None):
@@ -247,6 +253,23 @@ class RayIntersector:
             overflow = None
         data, self.last_order = self.pack_hits(o, d, k, hit_tri, hit_t, hit_count, overflow, int(image_width))
         return data
+
+    def coherent_layout(self, hit_count, ray_offset, total: int, width: int):
+        """``coherent_order`` and its inverse map (``inverse[sample] = position``).  Given the inverse,
+        ``qf_pack_samples`` also writes ``xyz[order]`` / ``dirs[order]``, so ``field(xyz_c, dirs_c)`` reads and writes
+        sequentially (the indirection through ``order`` costs it 10 %), and
+        ``derive_properties(..., sample_index=inverse)`` picks colour and density back up per ray."""
+        height = hit_count.shape[0] // width
+        tiles = ((width + 7) // 8) * ((height + 7) // 8)
+        dev = hit_count.device
+        totals = torch.empty((tiles,), dtype=torch.int64, device=dev)
+        _C.check(_C.lib().qf_tile_totals(_C.ptr(hit_count), width, height, _C.ptr(totals), _C.stream()), "qf_tile_totals")
+        base = (torch.cumsum(totals, dim=0) - totals).contiguous()
+        order = torch.empty((total,), dtype=torch.int32, device=dev)
+        inverse = torch.empty((total,), dtype=torch.int32, device=dev)
+        _C.check(_C.lib().qf_coherent_layout(_C.ptr(hit_count), _C.ptr(ray_offset), _C.ptr(base), width, height,
+                                             _C.ptr(order), _C.ptr(inverse), _C.stream()), "qf_coherent_layout")
+        return order, inverse
 
     def coherent_order(self, hit_count: torch.Tensor, ray_offset: torch.Tensor, total: int, width: int) -> torch.Tensor:
         """int32 permutation of the ``total`` packed samples of a row-major ``width``-wide image, ordered

@@ -58,8 +58,8 @@ class _DerivePropertiesFn(torch.autograd.Function):
     reference only uses them detached -- examples/field.py:246-252)."""
 
     @staticmethod
-    def forward(ctx, color, density, depths, deltas_t, delta_c, index_ray, N, mode, bk):
-        n = color.shape[0]
+    def forward(ctx, color, density, depths, deltas_t, delta_c, index_ray, N, mode, bk, sample_index=None):
+        n = depths.shape[0]
         dev = color.device
         rgb = torch.empty((N, 3), dtype=torch.float32, device=dev)
         alpha = torch.empty((N, 1), dtype=torch.float32, device=dev)
@@ -67,8 +67,11 @@ class _DerivePropertiesFn(torch.autograd.Function):
         weights = torch.empty((n, 1), dtype=torch.float32, device=dev)
         _C.check(_C.lib().qf_derive_properties(
             _C.ptr(color), _C.ptr(density), _C.ptr(depths), _C.ptr(deltas_t), delta_c, _C.ptr(index_ray), n, N, mode,
-            _C.ptr(bk), _C.ptr(rgb), _C.ptr(alpha), _C.ptr(depth_out), _C.ptr(weights), _C.stream()),
-            "qf_derive_properties")
+            _C.ptr(bk), _C.ptr(sample_index, torch.int32), _C.ptr(rgb), _C.ptr(alpha), _C.ptr(depth_out), _C.ptr(weights),
+            _C.stream()), "qf_derive_properties")
+        if sample_index is not None:
+            ctx.mark_non_differentiable(rgb, alpha, depth_out, weights)     # the indexed form is inference only
+            return rgb, alpha, depth_out, weights
         ctx.save_for_backward(color, density, depths, deltas_t, index_ray, bk)
         ctx.delta_c, ctx.mode = delta_c, mode
         ctx.mark_non_differentiable(weights)
@@ -86,17 +89,21 @@ class _DerivePropertiesFn(torch.autograd.Function):
                 _C.ptr(color), _C.ptr(density), _C.ptr(depths), _C.ptr(deltas_t), ctx.delta_c, _C.ptr(index_ray), n,
                 ctx.mode, _C.ptr(bk), _C.ptr(_C.f32c(g_rgb)), _C.ptr(_C.f32c(g_alpha)), _C.ptr(_C.f32c(g_depth)),
                 _C.ptr(g_color), _C.ptr(g_sigma), _C.ptr(g_t), _C.stream()), "qf_derive_properties_backward")
-        return g_color, g_sigma, g_t, None, None, None, None, None, None
+        return g_color, g_sigma, g_t, None, None, None, None, None, None, None
 
 
-def derive_properties(color, density, depths, deltas, boundary, index_ray, render_bkgd=None, bg_color="white", N=0):
+def derive_properties(color, density, depths, deltas, boundary, index_ray, render_bkgd=None, bg_color="white", N=0,
+                      sample_index=None):
     """Per-ray colour / alpha / depth buffers from packed samples sorted by (ray, depth): one fused launch
     (the reference runs three kaolin scans + three scatters, utils.py:863-898).
 
     Returns (rgb [N,3], alpha [N,1], index_ray[boundary], Depth [N,1], weights [S,1]).  Background handling
     follows the reference, quirks included: white (or any non-"black" name) fills untouched rays with 1 and
     blends ``(1-a) + a*sum(w c)``; "black" uses ``a*sum(w c)``; other names blend with ``render_bkgd``.
-    Differentiable w.r.t. colour, density and depths when autograd is recording (training)."""
+    Differentiable w.r.t. colour, density and depths when autograd is recording (training).
+    ``sample_index`` (extension, inference only): int32 [S]; sample i's colour and density are
+    ``color[sample_index[i]]`` / ``density[sample_index[i]]`` -- they were evaluated in the field kernel's coherent
+    order (``RayIntersector.coherent_layout``); depths, deltas and index_ray stay indexed by i."""
     color = _C.f32c(color.reshape(-1, 3))
     dev = color.device
     density = _C.f32c(density.reshape(-1))
@@ -111,8 +118,10 @@ def derive_properties(color, density, depths, deltas, boundary, index_ray, rende
     bk = None
     if mode == _C.BG_CUSTOM:
         bk = _C.f32c(render_bkgd.detach().reshape(3).to(dev))
+    if sample_index is not None and (torch.is_grad_enabled() and (color.requires_grad or density.requires_grad)):
+        raise ValueError("sample_index is an inference-only path")
     rgb, alpha, depth_out, weights = _DerivePropertiesFn.apply(color, density, depths, deltas_t, delta_c, index_ray,
-                                                               N, mode, bk)
+                                                               N, mode, bk, sample_index)
     hit_rays = index_ray[boundary] if boundary is not None else None
     return rgb, alpha, hit_rays, depth_out, weights
 

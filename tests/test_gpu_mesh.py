@@ -255,6 +255,9 @@ def test_coherent_order_is_the_tile_rank_pixel_permutation(device):
         tiles_x = (w + 7) // 8
         key = ((py // 8) * tiles_x + px // 8) * (64 * 64) + k * 64 + (py % 8) * 8 + px % 8
         assert torch.equal(order.cpu().long(), torch.argsort(key))
+        inverse, xyz_c, dirs_c = mi.rayintersector.last_layout     # the same order as inverse map + streamed copies
+        assert torch.equal(inverse[order.long()].cpu(), torch.arange(n, dtype=torch.int32))
+        assert torch.equal(xyz_c, data[0][order.long()]) and torch.equal(dirs_c, data[1][order.long()])
         field = NGPRadianceField(aabb=[-1.5] * 3 + [1.5] * 3, log2_hashmap_size=12)
         field.load_state_dict(synthetic.seeded_ngp_state(12, field.mlp_base.grid.n_rows), strict=False)
         field = field.to(device)
@@ -262,6 +265,14 @@ def test_coherent_order_is_the_tile_rank_pixel_permutation(device):
         b = field(data[0], data[1], order=order)
         c = field(data[0], data[1], order=torch.randperm(n, device=device).to(torch.int32))
         assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[0], c[0]) and torch.equal(a[1], c[1])
+        # streaming the coherent copies and compositing through the inverse map == the plain pipeline, bit for bit
+        from quadraturefields_amd import utils
+        e = field(xyz_c, dirs_c)
+        assert torch.equal(e[0][inverse.long()], a[0]) and torch.equal(e[1][inverse.long()], a[1])
+        ref = utils.derive_properties(a[0], a[1].reshape(-1), data[3], 0.005, None, data[2], N=w * h)
+        got = utils.derive_properties(e[0], e[1].reshape(-1), data[3], 0.005, None, data[2], N=w * h, sample_index=inverse)
+        for x, y in zip((ref[0], ref[1], ref[3], ref[4]), (got[0], got[1], got[3], got[4])):
+            assert torch.equal(x, y)
     # rays that are not an image: no order
     mi.sampling_raytrace_device(d[:100], o[:100])
     assert mi.rayintersector.last_order is None

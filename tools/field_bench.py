@@ -17,6 +17,7 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"])
     ap.add_argument("--order", default="coherent", choices=["ray", "tile", "tile4", "random", "coherent"])
+    ap.add_argument("--physical", action="store_true", help="permute the inputs into the processing order instead of indexing through it")
     ap.add_argument("--deform-log2-t", type=int, default=24)
     ap.add_argument("--stage", default="field", choices=["field", "traverse", "raster", "pack", "composite", "frame", "deform"])
     args = ap.parse_args()
@@ -53,6 +54,9 @@ def main():
             key = torch.randperm(n, device=dev)
         order = torch.argsort(key).to(torch.int32).contiguous()
 
+    if args.physical and order is not None:
+        xyz, dirs = xyz[order.long()].contiguous(), dirs[order.long()].contiguous()
+        order = None
     net = None
     if args.stage == "deform":      # the deformation field of train_finetune.py:387-399 (T = 2^24: a 1 GB fp32 table)
         from quadraturefields_amd.field import Field
