@@ -38,11 +38,21 @@ class FrameRenderer:
             fill = 0.0 if self.bg_color == "black" else 1.0
             return (torch.full((n_rays, 3), fill, device=dev), torch.zeros((n_rays, 1), device=dev),
                     torch.zeros((n_rays, 1), device=dev), 0)
+        ri = self.mesh_intersect.rayintersector
+        if (self.field_net is None or scaling == 0) and ri.last_layout is not None:
+            # No deformation: the samples are already sorted by (ray, depth), the re-sort of sampling_indexing is the
+            # identity, and the field can stream the copies laid out in its processing order (same bits).
+            inverse, xyz_c, dirs_c = ri.last_layout
+            rgbs, sigmas = self.radiance_field(xyz_c, dirs_c)
+            rgb, alpha, _, depth, _ = utils.derive_properties(
+                rgbs, sigmas.reshape(-1), data[3], self.render_step_size, None, data[2], render_bkgd=render_bkgd,
+                bg_color=self.bg_color, N=n_rays, sample_index=inverse)
+            return rgb, alpha, depth, data[0].shape[0]
         rays = Rays(origins=origins, viewdirs=viewdirs)
         rgb, alpha, depth, n_samples, *_ = utils.render_image_finetune_with_occgrid(
             self.radiance_field, self.field_net, None, rays, data, render_step_size=self.render_step_size,
             render_bkgd=render_bkgd, mesh_intersect=self.mesh_intersect, mesh_finetune=None, scaling=scaling,
-            bg_color=self.bg_color, order=self.mesh_intersect.rayintersector.last_order)
+            bg_color=self.bg_color, order=ri.last_order)
         return rgb, alpha, depth, n_samples
 
     @torch.no_grad()

@@ -148,6 +148,10 @@ def test_frame_renderer_and_upsample(device):
     img_o = om.area_downsample(rgb_o.reshape(h, w, 3), 2)
     assert img.shape == (48, 48, 3)
     assert psnr(img, img_o) >= 70.0
+    # the streamed fast path (image-shaped rays) and the reference-shaped path (no image width: sampling_indexing,
+    # field on the ray-major arrays) give the same pixels, bit for bit
+    rgb_b, alpha_b, depth_b, n_b = fr.render(o.to(device), d.to(device))
+    assert n_b == n and torch.equal(rgb_b, rgb) and torch.equal(alpha_b, alpha) and torch.equal(depth_b, depth)
     # nothing in view
     rgb, alpha, depth, n = fr.render(o.to(device) + 100.0, d.to(device))
     assert n == 0 and bool((rgb == 1).all()) and float(alpha.sum()) == 0.0
