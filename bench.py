@@ -82,8 +82,8 @@ class Stages:
         else:
             hits = self._timed("traverse", lambda: ri._hits_bvh(o, d, MAX_HITS, W) + (None,), record)
         hit_tri, hit_t, hit_count, overflow = hits
-        pending = self._timed("pack", lambda: ri.pack_hits_begin(o, d, MAX_HITS, hit_tri, hit_t, hit_count, overflow, W),
-                              record)
+        pending = self._timed("pack", lambda: ri.pack_hits_begin(o, d, MAX_HITS, hit_tri, hit_t, hit_count, overflow, W,
+                                                                 lean=self.coherent), record)
         return pending, overflow is not None, record, o.shape[0]
 
     def finish(self, begun):
@@ -106,7 +106,7 @@ class Stages:
         out = self._timed("composite", lambda: utils.derive_properties(
             rgbs, sigmas.reshape(-1), ts, STEP, None, index_ray, bg_color="white", N=n_rays, sample_index=inverse), record)
         rgb, alpha, _, depth, _ = out
-        return rgb, alpha, depth, xyz.shape[0]
+        return rgb, alpha, depth, index_ray.shape[0]
 
     def _pack(self, hits):
         """(tools/field_bench.py) hits = (hit_tri, hit_t, hit_count, overflow, o, d) -> packed samples; sets .order."""

@@ -306,7 +306,9 @@ int qf_sample_offsets(const int32_t *hit_count, int64_t n_rays, int32_t max_hits
  * xyz_c / dirs_c [n,3] then receive a second copy of the positions / directions IN that order, so that
  * qf_field_forward can stream them (order = NULL) and write its outputs sequentially, and
  * qf_derive_properties picks colour and density back up through sample_index = inverse.  Measured: the indirection
- * through `order` costs the field kernel 10 % (two scattered sector reads and a scattered write per point).  */
+ * through `order` costs the field kernel 10 % (two scattered sector reads and a scattered write per point).
+ * xyz / dirs / origins may then be NULL (all three) for a caller that only renders: the ray-major copies of the
+ * positions are skipped; index_ray, depth and index_tri are always written.                      */
 int qf_pack_samples(const float *rays_o, const float *rays_d, int64_t n_rays, int32_t max_hits,
                     const int32_t *hit_tri, const float *hit_t, const int32_t *hit_count,
                     const int64_t *ray_offset, float *xyz, float *dirs, int64_t *index_ray,

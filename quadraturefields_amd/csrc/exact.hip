@@ -426,15 +426,17 @@ __global__ __launch_bounds__(kPackRays) void pack_samples_kernel(
         // vectors / (|vectors| + 1e-7) in float32 (mesh_utils.py:369-370)
         const float nrm = sqrtf((dx * dx + dy * dy) + dz * dz) + 1e-7f;
         const int64_t o = block_base + j;
-        xyz[o * 3 + 0] = (float)p[0];
-        xyz[o * 3 + 1] = (float)p[1];
-        xyz[o * 3 + 2] = (float)p[2];
-        dirs[o * 3 + 0] = dx / nrm;
-        dirs[o * 3 + 1] = dy / nrm;
-        dirs[o * 3 + 2] = dz / nrm;
-        origins[o * 3 + 0] = ox;
-        origins[o * 3 + 1] = oy;
-        origins[o * 3 + 2] = oz;
+        if (xyz) {              // the ray-major position / direction / origin arrays are optional (see qf_hip.h)
+            xyz[o * 3 + 0] = (float)p[0];
+            xyz[o * 3 + 1] = (float)p[1];
+            xyz[o * 3 + 2] = (float)p[2];
+            dirs[o * 3 + 0] = dx / nrm;
+            dirs[o * 3 + 1] = dy / nrm;
+            dirs[o * 3 + 2] = dz / nrm;
+            origins[o * 3 + 0] = ox;
+            origins[o * 3 + 1] = oy;
+            origins[o * 3 + 2] = oz;
+        }
         index_ray[o] = ray;
         depth[o] = (float)dep;
         index_tri[o] = (int64_t)s_tri[rl * Kp + k];
@@ -848,6 +850,9 @@ extern "C" int qf_pack_samples(const float *rays_o, const float *rays_d, int64_t
     if (n_rays == 0) return QF_OK;
     if (!rays_o || !rays_d || !hit_tri || !hit_t || !hit_count || !ray_offset) return QF_ERR_INVALID_ARGUMENT;
     if (inverse && (!xyz_c || !dirs_c)) return QF_ERR_INVALID_ARGUMENT;
+    if (!index_ray || !depth || !index_tri) return QF_ERR_INVALID_ARGUMENT;
+    if ((xyz || dirs || origins) && (!xyz || !dirs || !origins)) return QF_ERR_INVALID_ARGUMENT;
+    if (!xyz && !inverse) return QF_ERR_INVALID_ARGUMENT;      // the positions have to go somewhere
     const int Kp = max_hits | 1;
     const size_t lds = (size_t)kPackRays * Kp * 8 + (size_t)kPackRays * max_hits * 2 + 64;
     const int64_t blocks = qf_div_up(n_rays, kPackRays);

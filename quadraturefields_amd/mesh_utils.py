@@ -176,7 +176,7 @@ class RayIntersector:
         hit_count.clamp_(max=k)      # overflowing pixels counted past K; everything downstream indexes with <= K
         return hit_tri, hit_t, hit_count, overflow
 
-    def pack_hits(self, o, d, k, hit_tri, hit_t, hit_count, overflow, width):
+    def pack_hits(self, o, d, k, hit_tri, hit_t, hit_count, overflow, width, lean=False):
         """Per-ray hit lists -> ([xyzs, dirs, index_ray, ts, index_tri, origins] or None, coherent order or None).
 
         The output size is data dependent.  Instead of stalling on it, the offsets are scanned on the device, the
@@ -186,10 +186,12 @@ class RayIntersector:
         ``overflow`` (from ``_hits_raster_frame``) marks lists with more than K candidates: the frame is redone with
         the exact K-nearest BVH traversal.  ``pack_hits_begin`` / ``pack_hits_end`` are the two halves, for callers
         that keep several frames in flight on different streams."""
-        return self.pack_hits_end(self.pack_hits_begin(o, d, k, hit_tri, hit_t, hit_count, overflow, width))
+        return self.pack_hits_end(self.pack_hits_begin(o, d, k, hit_tri, hit_t, hit_count, overflow, width, lean))
 
-    def pack_hits_begin(self, o, d, k, hit_tri, hit_t, hit_count, overflow, width):
-        """Enqueue scan, readback, pack and ordering on the current stream; no host wait."""
+    def pack_hits_begin(self, o, d, k, hit_tri, hit_t, hit_count, overflow, width, lean=False):
+        """Enqueue scan, readback, pack and ordering on the current stream; no host wait.  ``lean`` (image-shaped
+        batches only): skip the ray-major xyz / dirs / origins arrays -- a caller that only renders reads the copies
+        in ``last_layout`` -- and return None in their places."""
         n = o.shape[0]
         dev = self.device
         buf, temp, host, ev = self._frame_scratch(n)
@@ -200,41 +202,47 @@ class RayIntersector:
         host.copy_(buf[n:], non_blocking=True)
         ev.record()
         cap = n * k
-        xyz = torch.empty((cap, 3), dtype=torch.float32, device=dev)
-        dirs = torch.empty((cap, 3), dtype=torch.float32, device=dev)
-        org = torch.empty((cap, 3), dtype=torch.float32, device=dev)
+        image = width > 0 and n % width == 0
+        lean = bool(lean) and image
+        xyz = dirs = org = None
+        if not lean:
+            xyz = torch.empty((cap, 3), dtype=torch.float32, device=dev)
+            dirs = torch.empty((cap, 3), dtype=torch.float32, device=dev)
+            org = torch.empty((cap, 3), dtype=torch.float32, device=dev)
         index_ray = torch.empty((cap,), dtype=torch.int64, device=dev)
         index_tri = torch.empty((cap,), dtype=torch.int64, device=dev)
         depth = torch.empty((cap,), dtype=torch.float32, device=dev)
         order = inverse = xyz_c = dirs_c = layout = None
-        if width > 0 and n % width == 0:      # image-shaped: the coherent order, its inverse, and streamed copies
+        if image:                             # the coherent order, its inverse, and streamed copies
             order, inverse = self.coherent_layout(hit_count, buf, cap, width)
-            xyz_c, dirs_c = torch.empty_like(xyz), torch.empty_like(dirs)
+            xyz_c = torch.empty((cap, 3), dtype=torch.float32, device=dev)
+            dirs_c = torch.empty((cap, 3), dtype=torch.float32, device=dev)
             layout = (inverse, xyz_c, dirs_c)
         _C.check(_C.lib().qf_pack_samples(_C.ptr(o), _C.ptr(d), n, k, _C.ptr(hit_tri), _C.ptr(hit_t),
                                           _C.ptr(hit_count), _C.ptr(buf), _C.ptr(xyz), _C.ptr(dirs),
                                           _C.ptr(index_ray), _C.ptr(depth), _C.ptr(index_tri), _C.ptr(org),
                                           _C.ptr(inverse), _C.ptr(xyz_c), _C.ptr(dirs_c), _C.stream()), "qf_pack_samples")
-        return (o, d, k, width, host, ev, [xyz, dirs, index_ray, depth, index_tri, org], order, layout,
+        return (o, d, k, width, lean, host, ev, [xyz, dirs, index_ray, depth, index_tri, org], order, layout,
                 (hit_tri, hit_t, hit_count))          # the lists stay referenced until the kernels reading them ran
 
     def pack_hits_end(self, pending):
         """Wait for the 16-byte readback of ``pack_hits_begin`` and slice the results (same stream as ``begin``)."""
-        o, d, k, width, host, ev, arrays, order, layout, _lists = pending
+        o, d, k, width, lean, host, ev, arrays, order, layout, _lists = pending
         ev.synchronize()
         total, ovf = int(host[0]), int(host[1])
         if ovf:
             self.raster_overflowed()
             hit_tri, hit_t, hit_count = self._hits_bvh(o, d, k, width)
-            return self.pack_hits(o, d, k, hit_tri, hit_t, hit_count, None, width)
+            return self.pack_hits(o, d, k, hit_tri, hit_t, hit_count, None, width, lean)
         self.last_layout = None
         if total == 0:
             return None, None
         if layout is not None:      # (inverse, xyz, dirs) in the coherent order: see coherent_layout
             self.last_layout = tuple(t[:total] for t in layout)
-        return [t[:total] for t in arrays], (order[:total] if order is not None else None)
+        return [None if t is None else t[:total] for t in arrays], (order[:total] if order is not None else None)
 
-    def sample_device(self, origins, vectors, max_hits: Optional[int] = None, image_width: int = 0, camera=None):
+    def sample_device(self, origins, vectors, max_hits: Optional[int] = None, image_width: int = 0, camera=None,
+                      lean: bool = False):
         """Packed, sorted samples on the device: [xyzs, dirs, index_ray, ts, index_tri, origins] -- the six
         tensors the reference's DataLoader hands to the renderers (nerf_synthetic.py:256-257) -- or None
         when no ray hits anything."""
@@ -251,7 +259,7 @@ class RayIntersector:
         else:
             hit_tri, hit_t, hit_count = self._hits_bvh(o, d, k, image_width)
             overflow = None
-        data, self.last_order = self.pack_hits(o, d, k, hit_tri, hit_t, hit_count, overflow, int(image_width))
+        data, self.last_order = self.pack_hits(o, d, k, hit_tri, hit_t, hit_count, overflow, int(image_width), lean)
         return data
 
     def coherent_layout(self, hit_count, ray_offset, total: int, width: int):

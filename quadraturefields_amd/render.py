@@ -32,7 +32,12 @@ class FrameRenderer:
                render_bkgd: Optional[torch.Tensor] = None, camera=None):
         """(rgb [R,3], alpha [R,1], depth [R,1], n_samples) for R rays."""
         n_rays = origins.shape[0]
-        data = self.quadrature_points(origins, viewdirs, image_width, camera)
+        if camera is not None:
+            image_width = camera.width
+        # without deformation only the streamed copies are read: skip the ray-major position arrays
+        lean = self.field_net is None or scaling == 0
+        data = self.mesh_intersect.rayintersector.sample_device(origins, viewdirs, self.mesh_intersect.num_intersections,
+                                                                image_width, camera, lean=lean)
         if data is None:
             dev = origins.device
             fill = 0.0 if self.bg_color == "black" else 1.0
@@ -47,7 +52,7 @@ class FrameRenderer:
             rgb, alpha, _, depth, _ = utils.derive_properties(
                 rgbs, sigmas.reshape(-1), data[3], self.render_step_size, None, data[2], render_bkgd=render_bkgd,
                 bg_color=self.bg_color, N=n_rays, sample_index=inverse)
-            return rgb, alpha, depth, data[0].shape[0]
+            return rgb, alpha, depth, data[2].shape[0]
         rays = Rays(origins=origins, viewdirs=viewdirs)
         rgb, alpha, depth, n_samples, *_ = utils.render_image_finetune_with_occgrid(
             self.radiance_field, self.field_net, None, rays, data, render_step_size=self.render_step_size,
