@@ -176,7 +176,7 @@ class RayIntersector:
         hit_count.clamp_(max=k)      # overflowing pixels counted past K; everything downstream indexes with <= K
         return hit_tri, hit_t, hit_count, overflow
 
-    def pack_hits(self, o, d, k, hit_tri, hit_t, hit_count, overflow, width, lean=False):
+    def pack_hits(self, o, d, k, hit_tri, hit_t, hit_count, overflow, width, lean=False, layout=True):
         """Per-ray hit lists -> ([xyzs, dirs, index_ray, ts, index_tri, origins] or None, coherent order or None).
 
         The output size is data dependent.  Instead of stalling on it, the offsets are scanned on the device, the
@@ -186,12 +186,13 @@ class RayIntersector:
         ``overflow`` (from ``_hits_raster_frame``) marks lists with more than K candidates: the frame is redone with
         the exact K-nearest BVH traversal.  ``pack_hits_begin`` / ``pack_hits_end`` are the two halves, for callers
         that keep several frames in flight on different streams."""
-        return self.pack_hits_end(self.pack_hits_begin(o, d, k, hit_tri, hit_t, hit_count, overflow, width, lean))
+        return self.pack_hits_end(self.pack_hits_begin(o, d, k, hit_tri, hit_t, hit_count, overflow, width, lean, layout))
 
-    def pack_hits_begin(self, o, d, k, hit_tri, hit_t, hit_count, overflow, width, lean=False):
+    def pack_hits_begin(self, o, d, k, hit_tri, hit_t, hit_count, overflow, width, lean=False, layout=True):
         """Enqueue scan, readback, pack and ordering on the current stream; no host wait.  ``lean`` (image-shaped
         batches only): skip the ray-major xyz / dirs / origins arrays -- a caller that only renders reads the copies
-        in ``last_layout`` -- and return None in their places."""
+        in ``last_layout`` -- and return None in their places.  ``layout=False``: no processing order at all (callers that
+        do not evaluate a field on the samples, e.g. the baked-texture render)."""
         n = o.shape[0]
         dev = self.device
         buf, temp, host, ev = self._frame_scratch(n)
@@ -202,8 +203,9 @@ class RayIntersector:
         host.copy_(buf[n:], non_blocking=True)
         ev.record()
         cap = n * k
-        image = width > 0 and n % width == 0
+        image = bool(layout) and width > 0 and n % width == 0
         lean = bool(lean) and image
+        want_layout = layout
         xyz = dirs = org = None
         if not lean:
             xyz = torch.empty((cap, 3), dtype=torch.float32, device=dev)
@@ -212,7 +214,7 @@ class RayIntersector:
         index_ray = torch.empty((cap,), dtype=torch.int64, device=dev)
         index_tri = torch.empty((cap,), dtype=torch.int64, device=dev)
         depth = torch.empty((cap,), dtype=torch.float32, device=dev)
-        order = inverse = xyz_c = dirs_c = layout = None
+        order = inverse = xyz_c = dirs_c = layout = None          # (from here on ``layout`` is the result tuple)
         if image:                             # the coherent order, its inverse, and streamed copies
             order, inverse = self.coherent_layout(hit_count, buf, cap, width)
             xyz_c = torch.empty((cap, 3), dtype=torch.float32, device=dev)
@@ -222,7 +224,7 @@ class RayIntersector:
                                           _C.ptr(hit_count), _C.ptr(buf), _C.ptr(xyz), _C.ptr(dirs),
                                           _C.ptr(index_ray), _C.ptr(depth), _C.ptr(index_tri), _C.ptr(org),
                                           _C.ptr(inverse), _C.ptr(xyz_c), _C.ptr(dirs_c), _C.stream()), "qf_pack_samples")
-        return (o, d, k, width, lean, host, ev, [xyz, dirs, index_ray, depth, index_tri, org], order, layout,
+        return (o, d, k, width, (lean, want_layout), host, ev, [xyz, dirs, index_ray, depth, index_tri, org], order, layout,
                 (hit_tri, hit_t, hit_count))          # the lists stay referenced until the kernels reading them ran
 
     def pack_hits_end(self, pending):
@@ -233,7 +235,7 @@ class RayIntersector:
         if ovf:
             self.raster_overflowed()
             hit_tri, hit_t, hit_count = self._hits_bvh(o, d, k, width)
-            return self.pack_hits(o, d, k, hit_tri, hit_t, hit_count, None, width, lean)
+            return self.pack_hits(o, d, k, hit_tri, hit_t, hit_count, None, width, *lean)
         self.last_layout = None
         if total == 0:
             return None, None
@@ -242,7 +244,7 @@ class RayIntersector:
         return [None if t is None else t[:total] for t in arrays], (order[:total] if order is not None else None)
 
     def sample_device(self, origins, vectors, max_hits: Optional[int] = None, image_width: int = 0, camera=None,
-                      lean: bool = False):
+                      lean: bool = False, layout: bool = True):
         """Packed, sorted samples on the device: [xyzs, dirs, index_ray, ts, index_tri, origins] -- the six
         tensors the reference's DataLoader hands to the renderers (nerf_synthetic.py:256-257) -- or None
         when no ray hits anything."""
@@ -259,7 +261,8 @@ class RayIntersector:
         else:
             hit_tri, hit_t, hit_count = self._hits_bvh(o, d, k, image_width)
             overflow = None
-        data, self.last_order = self.pack_hits(o, d, k, hit_tri, hit_t, hit_count, overflow, int(image_width), lean)
+        data, self.last_order = self.pack_hits(o, d, k, hit_tri, hit_t, hit_count, overflow, int(image_width), lean,
+                                               layout)
         return data
 
     def coherent_layout(self, hit_count, ray_offset, total: int, width: int):
@@ -363,10 +366,11 @@ class MeshIntersection:
         """Constant step for every sample (mesh_utils.py:225-231; B-4)."""
         return torch.full((depth.shape[0],), self.render_step_size, dtype=torch.float32, device=self.device)
 
-    def sampling_raytrace_device(self, vectors, origins, image_width: int = 0, camera=None):
+    def sampling_raytrace_device(self, vectors, origins, image_width: int = 0, camera=None, layout: bool = True):
         """Fast path of ``sampling_raytrace_numpy``: same six arrays, on the device, no host round trip.
         ``camera`` (``make_camera``): the rays are that camera's full pixel grid -> camera-coherent intersector."""
-        return self.rayintersector.sample_device(origins, vectors, self.num_intersections, image_width, camera)
+        return self.rayintersector.sample_device(origins, vectors, self.num_intersections, image_width, camera,
+                                                 layout=layout)
 
     def sampling_raytrace_numpy(self, vectors, origins, random=0):
         """numpy 7-tuple (points, dirs, index_ray, depth, index_tri, 0, origins) sorted by (ray, depth), or None

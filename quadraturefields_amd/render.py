@@ -64,7 +64,8 @@ class FrameRenderer:
     def render_baked(self, origins, viewdirs, uv, compressor, image_width: int = 0, camera=None):
         """Baked-texture variant (test_baking_texture_images.py:355-371)."""
         n_rays = origins.shape[0]
-        data = self.quadrature_points(origins, viewdirs, image_width, camera)
+        data = self.mesh_intersect.sampling_raytrace_device(viewdirs, origins, image_width=image_width, camera=camera,
+                                                            layout=False)     # no field evaluation: no processing order
         if data is None:
             dev = origins.device
             return (torch.ones((n_rays, 3), device=dev), torch.zeros((n_rays, 1), device=dev),

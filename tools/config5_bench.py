@@ -49,7 +49,7 @@ def main():
         marks = [torch.cuda.Event(enable_timing=True) for _ in range(3)] if record else None
         if record:
             marks[0].record()
-        data = mi.sampling_raytrace_device(d, o, camera=cameras[i])
+        data = mi.sampling_raytrace_device(d, o, camera=cameras[i], layout=False)
         if record:
             marks[1].record()
         out = utils.render_image_bake_texture_images_with_occgrid(
