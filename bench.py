@@ -155,6 +155,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--up-sample", type=int, default=1, choices=[1, 2],
+                    help="render at up_sample x 800 per side as the reference's eval does with up_sample 2 "
+                         "(train_finetune.py:620-627); the headline configuration is 1")
     ap.add_argument("--pipeline", type=int, default=1, choices=[1, 2, 3],
                     help="frames in flight (one HIP stream each); 1 = strictly one frame after the other.  Measured: "
                          "2 or 3 frames in flight are 4-5 %% SLOWER (the fabric-bound field kernels of two frames "
@@ -163,6 +166,8 @@ def main():
                     help="raster: camera-coherent intersector (BVH fallback on overflow); bvh: BVH traversal only")
     args = ap.parse_args()
     torch.set_grad_enabled(False)          # inference: the fields take the fused kernels
+    global W, H
+    W = H = 800 * args.up_sample
 
     from quadraturefields_amd import parallel, synthetic
     rank, local_rank, world = parallel.init_from_env("nccl")
@@ -256,7 +261,7 @@ def main():
     field_s = (ms["field"] or 0.0) * 1e-3
     achieved = pts_per_launch * ALG_BYTES_PER_POINT / field_s / 1e9 if field_s > 0 else 0.0
     result = {
-        "metric": "rays/sec at 800x800 Lego (mesh-quadrature render: BVH traversal + hash-grid/MLP field + compositing)",
+        "metric": f"rays/sec at {W}x{H} Lego (mesh-quadrature render: BVH traversal + hash-grid/MLP field + compositing)",
         "value": rays_total / elapsed,
         "unit": "rays/s",
         "n_gpus": world,
@@ -269,9 +274,9 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
         "config": {
-            "workload": "Lego 800x800 (configs[1]), 1xMI355X per frame, fp32 hash-grid + tiny-MLP HIP kernels",
+            "workload": f"Lego {W}x{H} (configs[1]), 1xMI355X per frame, fp32 hash-grid + tiny-MLP HIP kernels",
             "rays_per_frame": W * H, "max_hits": MAX_HITS, "triangles": int(mesh.faces.shape[0]),
-            "log2_hashmap_size": LOG2_T, "render_step_size": STEP, "up_sample": 1,
+            "log2_hashmap_size": LOG2_T, "render_step_size": STEP, "up_sample": args.up_sample,
             "intersector": args.intersector, "bvh_fallback_frames": getattr(stages, "fallbacks", 0),
             "frames_in_flight": len(streams),
             "parallelism": f"{world} rank(s), one frame per rank per step" + (", all_gather of tiles" if world > 1 else ""),
