@@ -170,3 +170,33 @@ def test_derive_properties_closed_forms(device):
     assert torch.equal(rgb[3].cpu(), torch.ones(3)) and float(alpha[3]) == 0.0            # zero density
     assert torch.equal(rgb[4].cpu(), torch.ones(3))
     assert w.shape == (4, 1)
+
+
+def test_derive_properties_chunking_long_rays_and_sample_index(device):
+    """The compositing kernel stages 1024-sample chunks (+64 halo) in LDS: rays that straddle chunks, rays longer than
+    the staged window (occupancy-grid marching: hundreds of samples, finished from global memory), a sample count that
+    is not a multiple of the chunk; against the oracle, and the ``sample_index`` form (colour / density stored in another order) bit-identical to the direct one."""
+    from quadraturefields_amd import utils
+    rng = np.random.default_rng(3)
+    counts = rng.integers(0, 40, size=3000)
+    counts[rng.random(3000) < 0.02] = rng.integers(200, 2500, size=int((rng.random(3000) < 0.02).sum()) or 1)[0]
+    counts[17] = 1500                                   # longer than chunk + halo
+    counts[18] = 0
+    ridx = torch.from_numpy(np.repeat(np.arange(3000), counts)).long()
+    n = ridx.shape[0]
+    assert n % 1024 != 0
+    g = torch.Generator().manual_seed(8)
+    color, density = torch.rand(n, 3, generator=g), torch.rand(n, generator=g) * 30
+    depth, deltas = torch.rand(n, generator=g) * 5, torch.rand(n, generator=g) * 0.01
+    want = ov.derive_properties(color, density, depth, deltas, ov.mark_pack_boundaries(ridx), ridx, bg_color="white", N=3000)
+    dev = lambda t: t.to(device)
+    got = utils.derive_properties(dev(color), dev(density), dev(depth), dev(deltas), None, dev(ridx), N=3000)
+    for k in (0, 1, 3, 4):
+        _close(got[k], want[k], atol=5e-6, rtol=5e-5)
+    perm = torch.randperm(n, generator=g)
+    inv = torch.empty(n, dtype=torch.int32)
+    inv[perm] = torch.arange(n, dtype=torch.int32)
+    got2 = utils.derive_properties(dev(color[perm]), dev(density[perm]), dev(depth), dev(deltas), None, dev(ridx), N=3000,
+                                   sample_index=dev(inv))
+    for k in (0, 1, 3, 4):
+        assert torch.equal(got2[k], got[k])
