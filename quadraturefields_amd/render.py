@@ -57,7 +57,8 @@ class FrameRenderer:
         rgb, alpha, depth, n_samples, *_ = utils.render_image_finetune_with_occgrid(
             self.radiance_field, self.field_net, None, rays, data, render_step_size=self.render_step_size,
             render_bkgd=render_bkgd, mesh_intersect=self.mesh_intersect, mesh_finetune=None, scaling=scaling,
-            bg_color=self.bg_color, order=ri.last_order)
+            bg_color=self.bg_color, order=ri.last_order,
+            order_inverse=ri.last_layout[0] if ri.last_layout is not None else None)
         return rgb, alpha, depth, n_samples
 
     @torch.no_grad()

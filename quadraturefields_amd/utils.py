@@ -160,10 +160,11 @@ def render_image_finetune_with_occgrid(
     near_plane: float = 0.0, far_plane: float = 1e10, render_step_size: float = 1e-3,
     render_bkgd: Optional[torch.Tensor] = None, cone_angle: float = 0.0, alpha_thre: float = 0.0,
     test_chunk_size: int = 8192, timestamps: Optional[torch.Tensor] = None, mesh_intersect=None,
-    mesh_finetune=None, scaling=1 / 128, bg_color="white", order=None,
+    mesh_finetune=None, scaling=1 / 128, bg_color="white", order=None, order_inverse=None,
 ):
     """Render the samples of one split through the (deformed) quadrature points -- utils.py:465-607.
-    ``order`` (extension, optional): coherent processing order from ``RayIntersector.coherent_order``.
+    ``order`` (extension, optional): coherent processing order from ``RayIntersector.coherent_order``;
+    ``order_inverse``: its inverse map if the caller has it (``RayIntersector.last_layout[0]``).
 
     Returns the reference's 9-tuple (colors, opacities, depths, n_samples, weights, positions, index_ray,
     loss, index_tri).
@@ -203,13 +204,26 @@ def render_image_finetune_with_occgrid(
     # scaling == 0 multiplies the displacement by zero in the reference (utils.py:566-571): skipping is exact.
     points, deltas, boundary, dirs, index_ray, depth, index_tri_s, _ = mesh_intersect.sampling_indexing(
         xyzs, origins, dirs, index_ray, ts, index_tri)
+    sample_index = None
     if order is not None and order.shape[0] == points.shape[0]:
-        rgbs, sigmas = radiance_field(points, dirs, order=order)    # coherent processing order: locality only
+        # coherent processing order: locality only
+        if torch.is_grad_enabled() and (points.requires_grad or _module_trains(radiance_field)):
+            rgbs, sigmas = radiance_field(points, dirs, order=order)
+        else:
+            # inference: lay the (deformed, re-sorted) points out IN that order so that the field kernel streams, and
+            # let compositing pick colour / density up through the inverse map (same bits, see qf_pack_samples)
+            o64 = order.long()
+            rgbs, sigmas = radiance_field(points[o64], dirs[o64])
+            if order_inverse is not None and order_inverse.shape[0] == points.shape[0]:
+                sample_index = order_inverse
+            else:
+                sample_index = torch.empty_like(order)
+                sample_index[o64] = torch.arange(order.shape[0], dtype=order.dtype, device=order.device)
     else:
         rgbs, sigmas = radiance_field(points, dirs)
     rgb, opacity, _, depth_img, weights = derive_properties(
         rgbs, sigmas.reshape(-1), depth, deltas, boundary, index_ray, bg_color=bg_color, render_bkgd=render_bkgd,
-        N=num_rays)
+        N=num_rays, sample_index=sample_index)
     if mesh_finetune is not None:
         if dh is None:
             dh = torch.zeros_like(xyzs)
