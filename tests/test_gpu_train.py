@@ -318,3 +318,83 @@ def test_finetune_training_step_matches_oracle(device):
     img = utils.render_image_finetune_with_occgrid(field, net, None, rays, data, render_step_size=5e-3,
                                                    mesh_intersect=mi, scaling=scaling)
     assert not img[0].requires_grad and (img[0].reshape(-1, 3).cpu() - rgb_o.detach()).abs().max().item() <= 3e-4
+
+
+@pytest.mark.gpu
+def test_finetune_loop_end_to_end(device):
+    """A miniature train_finetune.py: target images from one field, a perturbed copy trained against them through the
+    reference-named entry points (intersect -> render_image_finetune_with_occgrid -> loss -> backward -> Adam, with
+    MeshFinetune.update_d every step), then update_faces + BVH refit (train_finetune.py:708-718) and evaluation.
+    The image error must drop and the refitted intersector must agree with a freshly built one."""
+    from quadraturefields_amd import synthetic, utils
+    from quadraturefields_amd.datasets.utils import Rays
+    from quadraturefields_amd.field import Field
+    from quadraturefields_amd.mesh_utils import MeshFinetune, MeshIntersection, RayIntersector
+    from quadraturefields_amd.radiance_fields.ngp import NGPRadianceField
+    from quadraturefields_amd.render import FrameRenderer, psnr
+    torch.manual_seed(0)
+    mesh = synthetic.shell_mesh(n_shells=3, subdivisions=3)
+    mi = MeshIntersection(mesh, simplify_mesh=False, scale=1.0, num_intersections=25)
+    aabb = [-1.5] * 3 + [1.5] * 3
+    target_field = NGPRadianceField(aabb=aabb, log2_hashmap_size=13)
+    state = synthetic.seeded_ngp_state(13, target_field.mlp_base.grid.n_rows)
+    target_field.load_state_dict(state, strict=False)
+    target_field = target_field.to(device)
+    field = NGPRadianceField(aabb=aabb, log2_hashmap_size=13)
+    g = torch.Generator().manual_seed(1)
+    noisy = {k: v + 0.15 * v.abs().mean() * torch.randn(v.shape, generator=g) for k, v in state.items()}
+    field.load_state_dict(noisy, strict=False)
+    field = field.to(device)
+    net = Field(scale=1.5, precision=16, log2_T=13, L=16, max_res=512, min_res=16, output_dim=1, hidden_size=32,
+                num_features=2, back_prop=False, nl="relu").to(device)
+    scaling = 0.02
+    w = h = 40
+    cams = synthetic.orbit_cameras(4, seed=9)
+    focal = synthetic.lego_focal(800) * w / 800.0
+    views = []
+    with torch.no_grad():
+        for c2w in cams:
+            o, d = synthetic.camera_rays(c2w, focal, w, h, device=device)
+            views.append((o, d, FrameRenderer(mi, target_field).render(o, d, image_width=w)[0]))
+    finetune = MeshFinetune(mesh.vertices, mesh.faces, scaling, device=device)
+    params = list(field.parameters()) + list(net.parameters())
+    opt = torch.optim.Adam(params, lr=2e-3, eps=1e-15)
+
+    def evaluate():
+        with torch.no_grad():
+            return float(np.mean([psnr(FrameRenderer(mi, field, field_net=net).render(o, d, image_width=w, scaling=scaling)[0], t)
+                                  for o, d, t in views]))
+
+    before = evaluate()
+    losses = []
+    with torch.enable_grad():
+        for step in range(40):
+            o, d, tgt = views[step % len(views)]
+            pick = torch.randperm(w * h, device=device)[:600]               # a random ray batch: BVH intersector
+            data = mi.sampling_raytrace_device(d[pick], o[pick])
+            rays = Rays(origins=o[pick], viewdirs=d[pick])
+            out = utils.render_image_finetune_with_occgrid(field, net, None, rays, data, render_step_size=5e-3,
+                                                           mesh_intersect=mi, mesh_finetune=finetune, scaling=scaling)
+            loss = torch.nn.functional.smooth_l1_loss(out[0], tgt[pick]) + out[7].sum()
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            losses.append(float(loss.detach()))
+    after = evaluate()
+    assert np.mean(losses[-8:]) < 0.7 * np.mean(losses[:8]), (losses[:8], losses[-8:])
+    assert after > before + 1.0, (before, after)
+    # mesh update and refit (train_finetune.py:708-718)
+    assert float(finetune.cache_w.sum()) > 1.0
+    finetune.update_faces()
+    finetune.reset_d()
+    assert np.isfinite(finetune.vertices).all() and np.abs(finetune.vertices - mesh.vertices).max() <= scaling + 1e-6
+    mi.mesh.vertices = finetune.vertices
+    mi.vertices = torch.from_numpy(finetune.vertices).to(device)
+    mi.rayintersector.update_intersector(finetune.vertices)
+    o, d, _ = views[0]
+    a = mi.rayintersector.hits(o, d, image_width=w)
+    fresh = RayIntersector(mi.mesh, max_hits=25)
+    b = fresh.hits(o, d, image_width=w)
+    for x, y in zip(a[:3], b[:3]):
+        assert torch.equal(x, y)
+    assert np.isfinite(evaluate())
