@@ -70,6 +70,15 @@ int qf_grid_encode(const qf_grid_desc *desc /* host */, const float *table /* [r
 int qf_grid_encode_backward(const qf_grid_desc *desc /* host */, const float *table, const float *x01,
                             const float *dfeat, int64_t n, float *grad_table, float *grad_x01, void *stream);
 
+/* Second order: the backward of the INPUT gradient above, grad_x01 = J(x; table)^T dfeat, which the reference
+ * reaches through Field.field_grad(create_graph=True) (examples/field.py:206-238) and the losses on it
+ * (field.py:253-270).  v [n,3] = dL/d(grad_x01).  Outputs, each optional (NULL to skip): g_dfeat [n,32] =
+ * dL/d(dfeat); g_x01 [n,3] = dL/d(x01) (mixed second derivatives of the trilinear blend); grad_table [rows,2],
+ * ACCUMULATED into with fp32 atomics.                                                            */
+int qf_grid_encode_double_backward(const qf_grid_desc *desc /* host */, const float *table, const float *x01,
+                                   const float *dfeat, const float *v, int64_t n, float *g_dfeat,
+                                   float *g_x01, float *grad_table, void *stream);
+
 /* Grid + 1-hidden-layer 64-wide MLP: x01 [n,3] -> raw [n,16].  Replaces
  * tcnn.NetworkWithInputEncoding.forward for mlp_base (ngp.py:764-768); base_w as below.       */
 int qf_grid_mlp_forward(const qf_grid_desc *grid /* host */, const float *table, const float *base_w,

@@ -57,6 +57,7 @@ _SIGNATURES = {
     "qf_grid_desc_init": (c_int, [POINTER(GridDesc), c_uint32, c_uint32, c_uint32, c_double]),
     "qf_grid_encode": (c_int, [POINTER(GridDesc), _P, _P, c_int64, _P, _P]),
     "qf_grid_encode_backward": (c_int, [POINTER(GridDesc), _P, _P, _P, c_int64, _P, _P, _P]),
+    "qf_grid_encode_double_backward": (c_int, [POINTER(GridDesc), _P, _P, _P, _P, c_int64, _P, _P, _P, _P]),
     "qf_grid_mlp_forward": (c_int, [POINTER(GridDesc), _P, _P, _P, c_int64, _P, _P]),
     "qf_field_forward": (c_int, [POINTER(FieldDesc), _P, _P, _P, POINTER(SGHead), _P, _P, c_int64, _P, _P, _P, _P, _P, _P]),
     "qf_field_forward_bf16": (c_int, [POINTER(FieldDesc), _P, _P, _P, POINTER(SGHead), _P, _P, c_int64, _P, _P, _P, _P, _P]),

@@ -79,6 +79,56 @@ __global__ void grid_backward_input_kernel(GridArgs ga, const float2 *table, con
     }
 }
 
+// Second order (Field.field_grad(create_graph=True), examples/field.py:229-238, and the losses on it): the backward
+// of  gx = J(x; table)^T dfeat  given v = dL/dgx [n,3].  With D_l(c) = sum_d v_d scale_l (dw_c / dfrac_d), the
+// derivative of corner c's weight along v:
+//   dL/ddfeat_{l,f}      = sum_c D_l(c) table[c][f]                     (one lane per point, no atomics)
+//   dL/dtable[c][f]     += D_l(c) dfeat_{l,f}                           (atomic scatter, like the first order)
+//   dL/dx_e              = sum_l scale_l sum_{d != e} v_d scale_l sum_c (d2 w_c / dfrac_d dfrac_e) g_c,  g_c = dfeat . table[c]
+// (the weights are products of one linear factor per axis: the pure second derivatives vanish, the mixed ones are
+// sign_d sign_e times the third factor).
+__global__ void grid_double_backward_kernel(GridArgs ga, const float2 *table, const float *x01, const float *dfeat,
+                                            const float *v, int64_t n, float *g_dfeat, float *g_x, float *grad_table)
+{
+    for (int64_t pt = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; pt < n; pt += (int64_t)gridDim.x * blockDim.x) {
+        const float x = x01[pt * 3], y = x01[pt * 3 + 1], z = x01[pt * 3 + 2];
+        const float vx = v[pt * 3], vy = v[pt * 3 + 1], vz = v[pt * 3 + 2];
+        float hx = 0.0f, hy = 0.0f, hz = 0.0f;
+        for (int level = 0; level < QF_MAX_LEVELS; ++level) {
+            const float d0 = dfeat[pt * 32 + 2 * level], d1 = dfeat[pt * 32 + 2 * level + 1];
+            const LevelConst lc = level_const(ga, level);
+            uint32_t idx[8];
+            float frac[3];
+            level_indices(lc, x, y, z, idx, frac);
+            const float wx = frac[0], wy = frac[1], wz = frac[2];
+            float o0 = 0.0f, o1 = 0.0f, mxy = 0.0f, mxz = 0.0f, myz = 0.0f;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const float2 t = table[idx[c]];
+                const float ax = (c & 1) ? wx : 1.0f - wx, ay = (c & 2) ? wy : 1.0f - wy, az = (c & 4) ? wz : 1.0f - wz;
+                const float sx = (c & 1) ? 1.0f : -1.0f, sy = (c & 2) ? 1.0f : -1.0f, sz = (c & 4) ? 1.0f : -1.0f;
+                const float D = lc.scale * (vx * sx * ay * az + vy * sy * ax * az + vz * sz * ax * ay);
+                o0 += D * t.x;
+                o1 += D * t.y;
+                if (grad_table && (d0 != 0.0f || d1 != 0.0f)) {
+                    atomicAdd(grad_table + 2 * (int64_t)idx[c], D * d0);
+                    atomicAdd(grad_table + 2 * (int64_t)idx[c] + 1, D * d1);
+                }
+                const float g = d0 * t.x + d1 * t.y;
+                mxy += sx * sy * az * g;
+                mxz += sx * sz * ay * g;
+                myz += sy * sz * ax * g;
+            }
+            if (g_dfeat) { g_dfeat[pt * 32 + 2 * level] = o0; g_dfeat[pt * 32 + 2 * level + 1] = o1; }
+            const float s2 = lc.scale * lc.scale;
+            hx += s2 * (vy * mxy + vz * mxz);
+            hy += s2 * (vx * mxy + vz * myz);
+            hz += s2 * (vx * mxz + vy * myz);
+        }
+        if (g_x) { g_x[pt * 3] = hx; g_x[pt * 3 + 1] = hy; g_x[pt * 3 + 2] = hz; }
+    }
+}
+
 }  // namespace
 
 extern "C" int qf_grid_encode_backward(const qf_grid_desc *desc, const float *table, const float *x01,
@@ -100,5 +150,21 @@ extern "C" int qf_grid_encode_backward(const qf_grid_desc *desc, const float *ta
                            reinterpret_cast<const float2 *>(table), x01, dfeat, n, grad_x01);
         QF_LAUNCH_CHECK();
     }
+    return QF_OK;
+}
+
+extern "C" int qf_grid_encode_double_backward(const qf_grid_desc *desc, const float *table, const float *x01,
+                                              const float *dfeat, const float *v, int64_t n, float *g_dfeat,
+                                              float *g_x01, float *grad_table, void *stream)
+{
+    if (!desc || n < 0) return QF_ERR_INVALID_ARGUMENT;
+    GridArgs ga;
+    int rc = fill_grid_args(desc, &ga);
+    if (rc != QF_OK) return rc;
+    if (n == 0) return QF_OK;
+    if (!table || !x01 || !dfeat || !v || (!g_dfeat && !g_x01 && !grad_table)) return QF_ERR_INVALID_ARGUMENT;
+    hipLaunchKernelGGL(grid_double_backward_kernel, dim3(qf_grid_1d(n, 256)), dim3(256), 0, qf_stream(stream), ga,
+                       reinterpret_cast<const float2 *>(table), x01, dfeat, v, n, g_dfeat, g_x01, grad_table);
+    QF_LAUNCH_CHECK();
     return QF_OK;
 }

@@ -3,8 +3,8 @@
 Mirrors ``Field`` of ``examples/field.py:130-270`` as the render path uses it
 (``examples/utils.py:555-566``: ``field_net(x, return_grad=False)[0]``): hash grid (tcnn ``Encoding``)
 followed by ``cat[x01, h] -> BasicDecoder``.  Inference is one fused launch; when autograd is recording the
-differentiable route (HIP grid forward/backward + library GEMMs) is taken, which also serves ``field_grad``
-(first order; ``create_graph=True`` through the grid is not implemented).
+differentiable route (HIP grid forward/backward + library GEMMs) is taken, which also serves ``field_grad`` --
+including ``create_graph=True`` (the reference's default), through the second-order grid kernel.
 """
 import numpy as np
 import torch
@@ -88,11 +88,21 @@ class Field(nn.Module):
         if not x.requires_grad:
             x.requires_grad = True
         field = self.field(x)
-        return field, self.field_grad(x, field, create_graph=False)
+        return field, self.field_grad(x, field, create_graph=True)
 
-    def field_grad(self, coords, field, create_graph=False):
-        """d field / d coords, field.py:229-238.  First order only: the grid backward is once-differentiable."""
-        if create_graph:
-            raise NotImplementedError("second-order gradients through the hash grid are not implemented")
+    def field_grad(self, coords, field, create_graph=True):
+        """d field / d coords, field.py:229-238 (``create_graph=True`` keeps it differentiable for the losses of
+        field.py:240-270)."""
         field = field.flatten()
-        return torch.autograd.grad(field, [coords], grad_outputs=torch.ones_like(field), retain_graph=True)[0]
+        return torch.autograd.grad(field, [coords], grad_outputs=torch.ones_like(field), create_graph=create_graph,
+                                   retain_graph=True)[0]
+
+    def compute_field_loss(self, weights, weights_rev, field_norm, view_dirs):
+        """field.py:253-259."""
+        view_dirs = view_dirs / torch.norm(view_dirs, dim=1, keepdim=True)
+        return torch.abs(torch.maximum(weights.detach(), weights_rev.detach())
+                         - torch.abs(torch.sum(field_norm * view_dirs.detach(), 1))).mean()
+
+    def compute_abs_loss(self, field_norm):
+        """field.py:261-264."""
+        return torch.linalg.norm(field_norm, ord=1, dim=1).mean()

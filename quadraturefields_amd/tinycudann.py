@@ -74,33 +74,77 @@ def _xavier_flat(dims, generator=None) -> torch.Tensor:
     return torch.cat(chunks)
 
 
+class _GridInputGradFn(torch.autograd.Function):
+    """gx = J(x01; table)^T dfeat -- the input gradient of the grid, itself differentiable (second order:
+    ``Field.field_grad(create_graph=True)``, examples/field.py:229-238).  Backward: qf_grid_encode_double_backward."""
+
+    @staticmethod
+    def forward(ctx, dfeat, x01, table, desc):
+        dfeat, x01, table = _C.f32c(dfeat.detach()), _C.f32c(x01.detach()), _C.f32c(table.detach())
+        n = x01.shape[0]
+        gx = torch.empty_like(x01)
+        if n:
+            _C.check(_C.lib().qf_grid_encode_backward(desc, _C.ptr(table), _C.ptr(x01), _C.ptr(dfeat), n, None,
+                                                      _C.ptr(gx), _C.stream()), "qf_grid_encode_backward")
+        ctx.save_for_backward(dfeat, x01, table)
+        ctx.desc = desc
+        return gx
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, v):
+        dfeat, x01, table = ctx.saved_tensors
+        need_d, need_x, need_t = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
+        v = _C.f32c(v)
+        n = x01.shape[0]
+        g_d = torch.empty_like(dfeat) if need_d else None
+        g_x = torch.empty_like(x01) if need_x else None
+        g_t = torch.zeros_like(table) if need_t else None
+        if n and (need_d or need_x or need_t):
+            _C.check(_C.lib().qf_grid_encode_double_backward(
+                ctx.desc, _C.ptr(table), _C.ptr(x01), _C.ptr(dfeat), _C.ptr(v), n, _C.ptr(g_d), _C.ptr(g_x), _C.ptr(g_t),
+                _C.stream()), "qf_grid_encode_double_backward")
+        return g_d, g_x, g_t, None
+
+
 class _GridEncodeFn(torch.autograd.Function):
     """feat = grid(x01; table).  Backward: table gradient by atomic scatter, input gradient by the analytic
-    derivative of the trilinear blend (tcnn's kernel_grid_backward / kernel_grid_backward_input)."""
+    derivative of the trilinear blend (tcnn's kernel_grid_backward / kernel_grid_backward_input).  The input
+    gradient is differentiable once more (``_GridInputGradFn``); the table gradient is not (nothing in the reference
+    differentiates a parameter gradient)."""
 
     @staticmethod
     def forward(ctx, x01, table, desc):
-        x01 = _C.f32c(x01.detach().reshape(-1, 3))
-        table = _C.f32c(table.detach())
-        n = x01.shape[0]
-        out = torch.empty((n, 32), dtype=torch.float32, device=x01.device)
-        _C.check(_C.lib().qf_grid_encode(desc, _C.ptr(table), _C.ptr(x01), n, _C.ptr(out), _C.stream()), "qf_grid_encode")
-        ctx.save_for_backward(x01, table)
+        x01_c = _C.f32c(x01.detach().reshape(-1, 3))
+        table_c = _C.f32c(table.detach())
+        n = x01_c.shape[0]
+        out = torch.empty((n, 32), dtype=torch.float32, device=x01_c.device)
+        _C.check(_C.lib().qf_grid_encode(desc, _C.ptr(table_c), _C.ptr(x01_c), n, _C.ptr(out), _C.stream()), "qf_grid_encode")
+        ctx.save_for_backward(x01, table)        # the graph tensors: the second-order path differentiates w.r.t. them
         ctx.desc = desc
         return out
 
     @staticmethod
-    @once_differentiable
     def backward(ctx, dfeat):
         x01, table = ctx.saved_tensors
         need_x, need_t = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
-        dfeat = _C.f32c(dfeat)
-        n = x01.shape[0]
-        gx = torch.empty_like(x01) if need_x else None
-        gt = torch.zeros_like(table) if need_t else None
-        if n and (need_x or need_t):
-            _C.check(_C.lib().qf_grid_encode_backward(ctx.desc, _C.ptr(table), _C.ptr(x01), _C.ptr(dfeat), n,
-                                                      _C.ptr(gt), _C.ptr(gx), _C.stream()), "qf_grid_encode_backward")
+        x01_c = _C.f32c(x01.detach().reshape(-1, 3))
+        table_c = _C.f32c(table.detach())
+        n = x01_c.shape[0]
+        gx = gt = None
+        if need_t:
+            gt = torch.zeros_like(table_c)
+            if n:
+                _C.check(_C.lib().qf_grid_encode_backward(ctx.desc, _C.ptr(table_c), _C.ptr(x01_c),
+                                                          _C.ptr(_C.f32c(dfeat.detach())), n, _C.ptr(gt), None,
+                                                          _C.stream()), "qf_grid_encode_backward")
+        if need_x:
+            if torch.is_grad_enabled() and (dfeat.requires_grad or x01.requires_grad or table.requires_grad):
+                # create_graph=True: keep the input gradient in the graph
+                gx = _GridInputGradFn.apply(dfeat, x01.reshape(-1, 3) if x01.dim() != 2 else x01, table, ctx.desc)
+            else:
+                gx = _GridInputGradFn.apply(dfeat.detach(), x01_c, table_c, ctx.desc)
+            gx = gx.reshape(x01.shape)
         return gx, gt, None
 
 

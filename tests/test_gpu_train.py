@@ -398,3 +398,46 @@ def test_finetune_loop_end_to_end(device):
     for x, y in zip(a[:3], b[:3]):
         assert torch.equal(x, y)
     assert np.isfinite(evaluate())
+
+
+@pytest.mark.gpu
+def test_field_second_order_gradients(device):
+    """Field.forward(x, return_grad=True) keeps field_grad in the graph (create_graph=True, field.py:206-238); a loss
+    on it (field.py:253-264) back-propagates through the second-order grid kernel.  Against double autograd through
+    the oracle: the table, the decoder and the input."""
+    from quadraturefields_amd import synthetic
+    from quadraturefields_amd.field import Field
+    f = Field(scale=1.5, back_prop=1, log2_T=13, L=16, max_res=512, hidden_size=32, nl="relu")
+    f.load_state_dict(synthetic.seeded_deform_state(f.xyz_encoder.grid.n_params), strict=False)
+    wts = helpers.oracle_deform_weights(f)
+    wts.table = _leaf(wts.table)
+    wts.layers = [(_leaf(w), _leaf(b)) for w, b in wts.layers]
+    f = f.to(device)
+    x, d = helpers.random_points(1500, aabb_half=1.4, seed=12, outside_frac=0.0)
+    g = torch.Generator().manual_seed(4)
+    w1, w2 = torch.rand(1500, generator=g), torch.rand(1500, generator=g)
+
+    def loss_fn(field, grad, mod, w1, w2, d):
+        return mod.compute_field_loss(w1, w2, grad, d) + 0.1 * mod.compute_abs_loss(grad) + 0.01 * field.sum()
+
+    with torch.enable_grad():
+        xd = x.to(device)
+        val, grad = f(xd, return_grad=True)
+        assert grad.requires_grad
+        loss = loss_fn(val, grad, f, w1.to(device), w2.to(device), d.to(device))
+        loss.backward()
+        xo = _leaf(x)
+        vo = ofields.deform_field(xo, wts)
+        go = torch.autograd.grad(vo.sum(), xo, create_graph=True)[0]
+        loss_o = loss_fn(vo, go, f, w1, w2, d)
+        loss_o.backward()
+    assert abs(float(loss.detach()) - float(loss_o.detach())) <= 1e-4 * abs(float(loss_o.detach()))
+    pairs = [("table", f.xyz_encoder.params.grad.reshape(-1, 2), wts.table.grad),
+             ("l0.weight", f.decoder_field.layers[0].weight.grad, wts.layers[0][0].grad),
+             ("l1.weight", f.decoder_field.layers[1].weight.grad, wts.layers[1][0].grad),
+             ("lout.weight", f.decoder_field.lout.weight.grad, wts.layers[2][0].grad),
+             ("x", xd.grad, xo.grad)]
+    for name, got, want in pairs:
+        got, want = got.detach().cpu().double(), want.detach().double()
+        rel = float((got - want).norm() / want.norm())
+        assert float(want.norm()) > 0 and rel <= 2e-3, (name, rel)
