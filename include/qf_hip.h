@@ -182,6 +182,9 @@ int qf_sum_reduce(const float *feats /* [n,c] */, int32_t c, const int64_t *seg_
 #define QF_BG_WHITE 0
 #define QF_BG_BLACK 1
 #define QF_BG_CUSTOM 2
+#define QF_BG_NONE 3   /* no blend and no double alpha: rgb = sum(w c), rays without samples 0 -- the plain sums of
+                        * nerfacc's accumulate_along_rays (field_rendering.py:100-156), used by the differentiable
+                        * route of `rendering` */
 int qf_derive_properties(const float *rgb_s /* [n,3] */, const float *sigma /* [n] */,
                          const float *depth /* [n] */, const float *deltas /* [n] or NULL */,
                          float delta_const, const int64_t *index_ray /* [n] */, int64_t n,

@@ -17,7 +17,7 @@ QF_MAX_LOBES = 8
 QF_BVH_MAX_HITS = 64
 QF_TEXEL_RECORD_BYTES = 64
 HEAD_NONE, HEAD_NGP, HEAD_SG, HEAD_SG_FEATURES = 0, 1, 2, 3
-BG_WHITE, BG_BLACK, BG_CUSTOM = 0, 1, 2
+BG_WHITE, BG_BLACK, BG_CUSTOM, BG_NONE = 0, 1, 2, 3
 
 
 class GridDesc(Structure):

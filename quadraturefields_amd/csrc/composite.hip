@@ -122,6 +122,10 @@ __global__ __launch_bounds__(DP_THREADS) void derive_properties_kernel(
                 r = ca * cr;
                 g = ca * cg;
                 b = ca * cb;
+            } else if (bg_mode == QF_BG_NONE) {    // the plain sums (nerfacc's accumulate_along_rays): no blend, no quirk
+                r = cr;
+                g = cg;
+                b = cb;
             } else {
                 r = ca * cr + (1.0f - ca) * bkgd[0];
                 g = ca * cg + (1.0f - ca) * bkgd[1];
@@ -307,11 +311,11 @@ extern "C" int qf_derive_properties(const float *rgb_s, const float *sigma, cons
                                     int32_t bg_mode, const float *bkgd, const int32_t *sample_index, float *out_rgb,
                                     float *out_alpha, float *out_depth, float *weights, void *stream)
 {
-    if (n < 0 || n_rays < 0 || bg_mode < 0 || bg_mode > 2) return QF_ERR_INVALID_ARGUMENT;
+    if (n < 0 || n_rays < 0 || bg_mode < 0 || bg_mode > 3) return QF_ERR_INVALID_ARGUMENT;
     if (n_rays > 0 && (!out_rgb || !out_alpha || !out_depth)) return QF_ERR_INVALID_ARGUMENT;
     if (bg_mode == QF_BG_CUSTOM && !bkgd) return QF_ERR_INVALID_ARGUMENT;
     if (n_rays > 0) {
-        QF_SIMPLE_LAUNCH(fill_background_kernel, n_rays, n_rays, bg_mode == QF_BG_BLACK ? 0.0f : 1.0f, out_rgb,
+        QF_SIMPLE_LAUNCH(fill_background_kernel, n_rays, n_rays, (bg_mode == QF_BG_BLACK || bg_mode == QF_BG_NONE) ? 0.0f : 1.0f, out_rgb,
                          out_alpha, out_depth);
     }
     if (n == 0) return QF_OK;
@@ -565,11 +569,13 @@ __global__ void derive_properties_backward_kernel(const float *rgb_s, const floa
         }
         const float gr = g_rgb[ray * 3 + 0], gg = g_rgb[ray * 3 + 1], gb = g_rgb[ray * 3 + 2];
         const float gD = g_depth ? g_depth[ray] : 0.0f;
-        const float b0 = bg_mode == QF_BG_WHITE ? 1.0f : (bg_mode == QF_BG_BLACK ? 0.0f : bkgd[0]);
-        const float b1 = bg_mode == QF_BG_WHITE ? 1.0f : (bg_mode == QF_BG_BLACK ? 0.0f : bkgd[1]);
-        const float b2 = bg_mode == QF_BG_WHITE ? 1.0f : (bg_mode == QF_BG_BLACK ? 0.0f : bkgd[2]);
-        const float gA = (g_alpha ? g_alpha[ray] : 0.0f) + gr * (cr - b0) + gg * (cg - b1) + gb * (cb - b2);
-        const float gCr = ca * gr, gCg = ca * gg, gCb = ca * gb;
+        const bool plain = bg_mode == QF_BG_NONE;
+        const float b0 = bg_mode == QF_BG_WHITE ? 1.0f : (bg_mode == QF_BG_CUSTOM ? bkgd[0] : 0.0f);
+        const float b1 = bg_mode == QF_BG_WHITE ? 1.0f : (bg_mode == QF_BG_CUSTOM ? bkgd[1] : 0.0f);
+        const float b2 = bg_mode == QF_BG_WHITE ? 1.0f : (bg_mode == QF_BG_CUSTOM ? bkgd[2] : 0.0f);
+        const float gA = (g_alpha ? g_alpha[ray] : 0.0f) +
+                         (plain ? 0.0f : gr * (cr - b0) + gg * (cg - b1) + gb * (cb - b2));
+        const float gCr = plain ? gr : ca * gr, gCg = plain ? gg : ca * gg, gCb = plain ? gb : ca * gb;
         // backward sweep: cum holds the total optical depth; peel samples off the far end
         float suffix = 0.0f;
         for (int64_t j = end - 1; j >= i; --j) {
@@ -597,7 +603,7 @@ extern "C" int qf_derive_properties_backward(const float *rgb_s, const float *si
                                              const float *g_alpha, const float *g_depth, float *grad_rgb_s,
                                              float *grad_sigma, float *grad_depth, void *stream)
 {
-    if (n < 0 || bg_mode < 0 || bg_mode > 2 || (bg_mode == QF_BG_CUSTOM && !bkgd)) return QF_ERR_INVALID_ARGUMENT;
+    if (n < 0 || bg_mode < 0 || bg_mode > 3 || (bg_mode == QF_BG_CUSTOM && !bkgd)) return QF_ERR_INVALID_ARGUMENT;
     if (n == 0) return QF_OK;
     if (!rgb_s || !sigma || !depth || !index_ray || !g_rgb || !grad_rgb_s || !grad_sigma) return QF_ERR_INVALID_ARGUMENT;
     hipLaunchKernelGGL(derive_properties_backward_kernel, dim3(qf_grid_1d(n, 256)), dim3(256), 0, qf_stream(stream),

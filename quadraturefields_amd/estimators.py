@@ -95,6 +95,35 @@ class OccGridEstimator(nn.Module):
         return ray_indices, t_starts, t_ends
 
     @torch.no_grad()
+    def update_every_n_steps(self, step: int, occ_eval_fn: Callable, occ_thre: float = 1e-2, ema_decay: float = 0.95,
+                             warmup_steps: int = 256, n: int = 16) -> None:
+        """nerfacc 0.5.3 ``OccGridEstimator.update_every_n_steps`` (train_finetune.py:482-487): in training mode,
+        every ``n`` steps, re-estimate the occupancy of a subset of cells -- all of them during the first
+        ``warmup_steps`` steps, afterwards a quarter drawn uniformly plus the currently occupied ones -- at one random
+        point per cell: ``occs = max(occs * ema_decay, occ_eval_fn(x))``, ``binaries = occs > min(mean(occs),
+        occ_thre)``.  Restated from nerfacc's published algorithm (parity unpinned: the source is not vendored)."""
+        if not self.training or step % n != 0:
+            return
+        res = [int(v) for v in self.resolution.tolist()]
+        cells = res[0] * res[1] * res[2]
+        dev = self.aabbs.device
+        if step < warmup_steps:
+            indices = torch.arange(cells, device=dev)
+        else:
+            uniform = torch.randint(cells, (cells // 4,), device=dev)
+            occupied = torch.nonzero(self.binaries[0].flatten())[:, 0]
+            if occupied.shape[0] > cells // 4:
+                occupied = occupied[torch.randint(occupied.shape[0], (cells // 4,), device=dev)]
+            indices = torch.cat([uniform, occupied], dim=0)
+        coords = torch.stack([indices // (res[1] * res[2]), (indices // res[2]) % res[1], indices % res[2]], dim=-1)
+        x = (coords.to(torch.float32) + torch.rand((indices.shape[0], 3), device=dev)) / torch.tensor(res, device=dev)
+        x = self.aabbs[0, :3] + x * (self.aabbs[0, 3:] - self.aabbs[0, :3])
+        occ = occ_eval_fn(x).reshape(-1).to(torch.float32)
+        self.occs[indices] = torch.maximum(self.occs[indices] * ema_decay, occ)
+        thre = torch.clamp(self.occs[self.occs >= 0].mean(), max=occ_thre)
+        self.binaries.copy_((self.occs > thre).reshape(self.binaries.shape))
+
+    @torch.no_grad()
     def set_occupancy_from_density(self, density_fn: Callable, threshold: float = 0.01, chunk: int = 1 << 20) -> None:
         """Inference-side helper (no reference counterpart): fill ``occs`` / ``binaries`` by evaluating
         ``density_fn(points [N,3]) -> [N] or [N,1]`` at the cell centres; occupied where density > threshold."""

@@ -4,7 +4,9 @@ Mirrors ``examples/field_rendering.py`` of the reference (a vendored copy of ner
 plus ``rendering_field``) together with the ``nerfacc.pack.pack_info`` / ``nerfacc.scan.exclusive_sum``
 / ``exclusive_prod`` it imports (:10-11): same function names, arguments, assertions and return values.
 Flattened (packed) inputs run on the device kernels; ``rgb_sigma_fn`` / ``rgb_alpha_fn`` stay Python
-callables.  Batched [n_rays, n_samples] inputs are packed row by row.  Inference only (no autograd).
+callables.  Batched [n_rays, n_samples] inputs are packed row by row.  The kernels here have no autograd;
+``rendering`` alone has a differentiable route (density branch, packed input) for the ``rgb_full`` term of the
+finetune training step (examples/train_finetune.py:513-523).
 """
 from typing import Callable, Dict, Optional, Tuple
 
@@ -175,6 +177,19 @@ def rendering(t_starts: Tensor, t_ends: Tensor, ray_indices: Optional[Tensor] = 
         rgbs, sigmas = _query(rgb_sigma_fn, t_starts, t_ends, ray_indices)
         assert rgbs.shape[-1] == 3, "rgbs must have 3 channels, got {}".format(rgbs.shape)
         assert sigmas.shape == t_starts.shape, "sigmas must have shape of (N,)! Got {}".format(sigmas.shape)
+        if ray_indices is not None and torch.is_grad_enabled() and (rgbs.requires_grad or sigmas.requires_grad):
+            # Training: the same sums through the differentiable compositing (qf_derive_properties in its plain
+            # mode + qf_derive_properties_backward); background, depth normalisation and extras stay in torch.
+            from .utils import _DerivePropertiesFn
+            deltas = _C.f32c((t_ends - t_starts).detach())
+            mids = _C.f32c(((t_starts + t_ends) / 2.0).detach())
+            colors, opacities, depths, w = _DerivePropertiesFn.apply(
+                _C.f32c(rgbs), _C.f32c(sigmas), mids, deltas, 0.0, _C.i64c(ray_indices), int(n_rays), _C.BG_NONE, None)
+            depths = depths / opacities.clamp_min(torch.finfo(rgbs.dtype).eps)
+            if render_bkgd is not None:
+                colors = colors + render_bkgd * (1.0 - opacities)
+            extras = {"weights": w.reshape(-1), "sigmas": sigmas, "rgbs": rgbs}
+            return colors, opacities, depths, extras
         if ray_indices is not None:
             info = pack_info(ray_indices, n_rays)
             n = t_starts.shape[0]

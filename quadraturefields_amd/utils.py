@@ -279,7 +279,6 @@ def texel_indices(mesh_intersect, uv, points, index_tri, texture_size: int) -> t
     return texel
 
 
-@torch.no_grad()
 def render_image_with_occgrid(
     radiance_field: torch.nn.Module, estimator, rays: Rays, near_plane: float = 0.0, far_plane: float = 1e10,
     render_step_size: float = 1e-3, render_bkgd: Optional[torch.Tensor] = None, cone_angle: float = 0.0,
@@ -289,7 +288,10 @@ def render_image_with_occgrid(
     """Occupancy-grid ray marching + nerfacc ``rendering`` -- utils.py:65-172 of the reference (the stage-1/2 renderer
     and the ``rgb_full`` branch of finetuning).  Returns (colors, opacities, depths, n_samples, extras) with the
     image shape of ``rays``.  The reference splits evaluation into ``test_chunk_size`` ray chunks to bound memory;
-    one chunk of any size gives the same result here, so the whole image is marched at once."""
+    one chunk of any size gives the same result here, so the whole image is marched at once.
+    Under ``torch.no_grad()`` everything is a fused kernel; when autograd is recording and the field trains (the
+    ``rgb_full`` term of train_finetune.py:513-523) the sampling stays non-differentiable, as in nerfacc, and the
+    field + ``rendering`` take their differentiable routes."""
     from .field_rendering import rendering
     if timestamps is not None:
         raise NotImplementedError("dynamic (D-NeRF) fields are out of scope")

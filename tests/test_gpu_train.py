@@ -441,3 +441,103 @@ def test_field_second_order_gradients(device):
         got, want = got.detach().cpu().double(), want.detach().double()
         rel = float((got - want).norm() / want.norm())
         assert float(want.norm()) > 0 and rel <= 2e-3, (name, rel)
+
+
+@pytest.mark.gpu
+def test_rendering_differentiable_route_vs_oracle(device):
+    """nerfacc-style ``rendering`` (density branch, packed samples) with autograd recording: values and the gradients
+    w.r.t. per-sample colour and density against autograd through the oracle's restatement of field_rendering.py."""
+    from quadraturefields_amd import field_rendering as fr
+    n_rays = 400
+    ridx, _ = helpers.packed_segments(n_rays, 60, seed=21)
+    n = ridx.shape[0]
+    g = torch.Generator().manual_seed(5)
+    ts = torch.sort(torch.rand(n, generator=g) * 4)[0]
+    te = ts + 0.01 + torch.rand(n, generator=g) * 0.01
+    rgbs, sig = torch.rand(n, 3, generator=g), torch.rand(n, generator=g) * 40
+    bk = torch.tensor([0.3, 0.6, 0.9])
+    tgt = torch.rand(n_rays, 3, generator=g)
+
+    def loss_fn(c, o, d, tgt):
+        return ((c - tgt) ** 2).mean() + 0.1 * (o ** 2).mean() + 0.01 * d.mean()
+
+    with torch.enable_grad():
+        ro, so = _leaf(rgbs), _leaf(sig)
+        c_o, o_o, d_o, _ = ov.rendering(ts, te, ridx, n_rays, rgb_sigma_fn=lambda a, b, c: (ro, so), render_bkgd=bk)
+        loss_fn(c_o, o_o, d_o, tgt).backward()
+        rd, sd = _leaf(rgbs.to(device)), _leaf(sig.to(device))
+        c, o, d, extras = fr.rendering(ts.to(device), te.to(device), ridx.to(device), n_rays,
+                                       rgb_sigma_fn=lambda a, b, c: (rd, sd), render_bkgd=bk.to(device))
+        assert c.requires_grad and extras["weights"].shape == (n,)
+        loss_fn(c, o, d, tgt.to(device)).backward()
+    assert _close(c, c_o, atol=5e-6, rtol=0)[0] and _close(o, o_o, atol=5e-6, rtol=0)[0] and _close(d, d_o, atol=5e-5, rtol=0)[0]
+    for name, got, want in (("rgbs", rd.grad, ro.grad), ("sigmas", sd.grad, so.grad)):
+        ok, err, ref = _close(got, want, 1e-4)
+        assert ok and ref > 0, (name, err, ref)
+    # inference gives the same image through the fused kernel
+    c2 = fr.rendering(ts.to(device), te.to(device), ridx.to(device), n_rays,
+                      rgb_sigma_fn=lambda a, b, c: (rgbs.to(device), sig.to(device)), render_bkgd=bk.to(device))[0]
+    assert _close(c2, c, atol=5e-6, rtol=0)[0]
+
+
+@pytest.mark.gpu
+def test_occgrid_training_step_and_updates(device):
+    """The rgb_full half of the finetune step (train_finetune.py:476-533): occupancy refresh with
+    update_every_n_steps, stratified marching, differentiable field + rendering, one optimiser step."""
+    from quadraturefields_amd import synthetic, utils
+    from quadraturefields_amd.datasets.utils import Rays
+    from quadraturefields_amd.estimators import OccGridEstimator
+    from quadraturefields_amd.radiance_fields.ngp import NGPRadianceField
+    torch.manual_seed(3)
+    aabb = [-1.5] * 3 + [1.5] * 3
+    field = NGPRadianceField(aabb=aabb, log2_hashmap_size=12)
+    field.load_state_dict(synthetic.seeded_ngp_state(12, field.mlp_base.grid.n_rows), strict=False)
+    field = field.to(device)
+    est = OccGridEstimator(roi_aabb=aabb, resolution=32, levels=1).to(device)
+    step_size = 0.02
+    blob = lambda x: torch.exp(-(x ** 2).sum(-1) / 0.5)       # a smooth occupancy: one sample per cell is representative
+    est.eval()
+    est.update_every_n_steps(step=0, occ_eval_fn=blob, occ_thre=0.3)
+    assert not bool(est.binaries.any())                      # eval mode: no update (nerfacc)
+    est.train()
+    est.update_every_n_steps(step=7, occ_eval_fn=blob, occ_thre=0.3)
+    assert not bool(est.binaries.any())                      # not a multiple of n = 16
+    for step in range(0, 64, 16):
+        est.update_every_n_steps(step=step, occ_eval_fn=blob, occ_thre=0.3)
+    ref = OccGridEstimator(roi_aabb=aabb, resolution=32, levels=1).to(device)
+    ref.set_occupancy_from_density(blob, threshold=float(torch.clamp(est.occs.mean(), max=0.3)))
+    agree = float((est.binaries == ref.binaries).float().mean())
+    assert 0.02 < float(est.binaries.float().mean()) < 0.5 and agree > 0.95, agree
+    assert torch.equal(est.binaries.flatten(), est.occs > torch.clamp(est.occs.mean(), max=0.3))
+    before = est.occs.clone()
+    est.update_every_n_steps(step=512, occ_eval_fn=lambda x: torch.zeros(x.shape[0], device=device), occ_thre=0.3)
+    decayed = (est.occs < before).float().mean()             # past the warm-up only a subset of the cells is refreshed
+    assert 0.2 < float(decayed) < 0.9 and bool((est.occs[est.occs < before] >= 0.95 * before[est.occs < before] - 1e-7).all())
+    occ_fn = lambda x: field.query_density(x) * step_size
+    for step in range(0, 64, 16):                            # now the occupancy of the field that is trained below
+        est.update_every_n_steps(step=step, occ_eval_fn=occ_fn, occ_thre=0.05)
+    assert 0.02 < float(est.binaries.float().mean()) < 0.98
+    est.update_every_n_steps(step=512, occ_eval_fn=occ_fn, occ_thre=0.05)     # past the warm-up: subset refresh
+    w = h = 16
+    c2w = synthetic.orbit_cameras(1, seed=2)[0]
+    o, d = synthetic.camera_rays(c2w, synthetic.lego_focal(800) * w / 800.0, w, h, device=device)
+    rays = Rays(origins=o, viewdirs=d)
+    target = torch.rand(w * h, 3, device=device)
+    opt = torch.optim.Adam(field.parameters(), lr=1e-2, eps=1e-15)
+    field.train()
+    with torch.enable_grad():
+        losses = []
+        for _ in range(6):
+            rgb, acc, depth, n_samples, extras = utils.render_image_with_occgrid(
+                field, est, rays, render_step_size=step_size, render_bkgd=torch.ones(3, device=device))
+            assert rgb.requires_grad and n_samples > 0
+            loss = torch.nn.functional.smooth_l1_loss(rgb, target)
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            losses.append(float(loss.detach()))
+    assert losses[-1] < losses[0]
+    field.eval()
+    rgb = utils.render_image_with_occgrid(field, est, rays, render_step_size=step_size,
+                                          render_bkgd=torch.ones(3, device=device))[0]
+    assert not rgb.requires_grad and bool(torch.isfinite(rgb).all())
