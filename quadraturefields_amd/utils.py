@@ -2,7 +2,8 @@
 
 Mirrors the hot-path functions of ``examples/utils.py`` of the reference with the same names, arguments and
 return tuples: ``derive_properties`` (:863-898), ``render_image_finetune_with_occgrid`` (:465-607),
-``render_image_bake_texture_images_with_occgrid`` (:998-1095), ``compress_sigma`` /
+``render_image_fit_sg_with_occgrid`` (:610-730), ``render_image_bake_texture_images_with_occgrid`` (:998-1095),
+``compress_sigma`` /
 ``inverse_of_compressed_sigma`` (:54-63), plus ``generate_splits`` (``examples/train_finetune.py:419-439``).
 Every tensor stays on the device; the reference's 160 000-sample Python batch loops, its
 ``torch.cuda.empty_cache()`` calls and its host round trips (np.lexsort, trimesh barycentrics) are gone,
@@ -259,6 +260,34 @@ def render_image_bake_texture_images_with_occgrid(
         rgbs, sigmas, depth, deltas, boundary, index_ray, bg_color=bg_color, render_bkgd=None, N=num_rays)
     return (rgb.view((*rays_shape[:-1], -1)), opacity.view((*rays_shape[:-1], -1)),
             depth_img.view((*rays_shape[:-1], -1)), xyzs.shape[0], weights, points, rays, 0)
+
+
+def render_image_fit_sg_with_occgrid(
+    radiance_field: torch.nn.Module, radiance_field_sg: torch.nn.Module, estimator, rays: Rays, data,
+    near_plane: float = 0.0, far_plane: float = 1e10, render_step_size: float = 1e-3,
+    render_bkgd: Optional[torch.Tensor] = None, cone_angle: float = 0.0, alpha_thre: float = 0.0,
+    test_chunk_size: int = 8192, timestamps: Optional[torch.Tensor] = None, mesh_intersect=None,
+    mesh_finetune=None, scaling=1 / 128, bg_color="white",
+):
+    """The renderer of the spherical-Gaussian fitting stage -- utils.py:610-730 (train_fit_sg.py:439-452,513-528):
+    colour from ``radiance_field_sg`` (trained), density from ``radiance_field`` (frozen, evaluated without gradient
+    as the reference does), the samples as given (no deformation, no re-sort), ``derive_properties``.  Returns the
+    reference's 8-tuple (colors, opacities, depths, n_samples, weights, xyzs, index_ray, index_tri).  The 32 768-sample
+    Python batches of the reference are gone; nothing depends on them."""
+    if timestamps is not None:
+        raise NotImplementedError("dynamic (D-NeRF) fields are out of scope")
+    rays, rays_shape, num_rays = _flatten_rays(rays)
+    device = mesh_intersect.device if mesh_intersect is not None else rays.origins.device
+    xyzs, dirs, index_ray, ts, index_tri, origins = _to_device(data, device)
+    t_dirs = _C.f32c(rays.viewdirs.to(device))[index_ray]
+    rgbs, _ = radiance_field_sg(xyzs, t_dirs)
+    with torch.no_grad():
+        sigmas = radiance_field.query_density(xyzs).reshape(-1)
+    rgb, opacity, _, depth, weights = derive_properties(
+        rgbs, sigmas, ts, float(render_step_size), None, index_ray, bg_color=bg_color, render_bkgd=render_bkgd,
+        N=num_rays)
+    return (rgb.view((*rays_shape[:-1], -1)), opacity.view((*rays_shape[:-1], -1)), depth.view((*rays_shape[:-1], -1)),
+            xyzs.shape[0], weights, xyzs, index_ray, index_tri)
 
 
 def texel_indices(mesh_intersect, uv, points, index_tri, texture_size: int) -> torch.Tensor:

@@ -541,3 +541,51 @@ def test_occgrid_training_step_and_updates(device):
     rgb = utils.render_image_with_occgrid(field, est, rays, render_step_size=step_size,
                                           render_bkgd=torch.ones(3, device=device))[0]
     assert not rgb.requires_grad and bool(torch.isfinite(rgb).all())
+
+
+@pytest.mark.gpu
+def test_fit_sg_renderer_values_and_gradients(device):
+    """render_image_fit_sg_with_occgrid (utils.py:610-730): SG colours over the frozen field's densities, inference
+    and the training step of train_fit_sg.py:439-461, against the oracle."""
+    from quadraturefields_amd import synthetic, utils
+    from quadraturefields_amd.datasets.utils import Rays
+    from quadraturefields_amd.mesh_utils import MeshIntersection
+    from quadraturefields_amd.radiance_fields.ngp import NGPRadianceField, NGPRadianceFieldSGNew
+    from oracle import meshpath as om
+    mesh = synthetic.shell_mesh(n_shells=3, subdivisions=3)
+    mi = MeshIntersection(mesh, simplify_mesh=False, scale=1.0, num_intersections=25)
+    aabb = [-1.5] * 3 + [1.5] * 3
+    base = NGPRadianceField(aabb=aabb, log2_hashmap_size=12)
+    base.load_state_dict(synthetic.seeded_ngp_state(12, base.mlp_base.grid.n_rows), strict=False)
+    sg = NGPRadianceFieldSGNew(aabb=aabb, log2_hashmap_size=12, use_viewdirs=False, num_g_lobes=6)
+    sg.load_state_dict(synthetic.seeded_ngp_state(12, sg.mlp_base.grid.n_rows, seed=7, sg_lobes=6), strict=False)
+    w_base = helpers.oracle_ngp_weights(base)
+    w_sg = _oracle_leaves(helpers.oracle_ngp_weights(sg))
+    base, sg = base.to(device), sg.to(device)
+    for p in base.parameters():
+        p.requires_grad = False
+    w = h = 40
+    c2w = synthetic.orbit_cameras(1, seed=6)[0]
+    o, d = synthetic.camera_rays(c2w, synthetic.lego_focal(800) * w / 800.0, w, h)
+    data = om.to_loader_tensors(mi.sampling_raytrace_numpy(d.numpy(), o.numpy(), 0))
+    xyzs, dirs, index_ray, ts, index_tri, origins = data
+    rays = Rays(origins=o, viewdirs=d)
+    target = torch.rand(w * h, 3, generator=torch.Generator().manual_seed(2))
+    with torch.enable_grad():
+        out = utils.render_image_fit_sg_with_occgrid(base, sg, None, rays, data, render_step_size=5e-3, mesh_intersect=mi)
+        assert len(out) == 8 and out[0].requires_grad
+        torch.nn.functional.smooth_l1_loss(out[0], target.to(device)).backward()
+        rgbs_o, _ = ofields.sg_forward(xyzs, d[index_ray], w_sg)
+        sig_o = ofields.query_density(xyzs, w_base).reshape(-1).detach()
+        rgb_o = ov.derive_properties(rgbs_o, sig_o, ts, torch.full_like(ts, 5e-3), ov.mark_pack_boundaries(index_ray),
+                                     index_ray, bg_color="white", N=w * h)[0]
+        torch.nn.functional.smooth_l1_loss(rgb_o, target).backward()
+    assert (out[0].detach().cpu() - rgb_o.detach()).abs().max().item() <= 2e-4
+    assert base.mlp_base.params.grad is None                 # the density field is frozen and evaluated without gradient
+    n_net = sg.mlp_base.n_network_params
+    for name, got, want in (("sg table", sg.mlp_base.params.grad[n_net:], w_sg.table.grad.reshape(-1)),
+                            ("sg lout", sg.mlp_head.lout.weight.grad, w_sg.head_layers[2][0].grad)):
+        got, want = got.detach().cpu().double(), want.detach().double()
+        assert float(want.norm()) > 0 and float((got - want).norm() / want.norm()) <= 2e-3, name
+    img = utils.render_image_fit_sg_with_occgrid(base, sg, None, rays, data, render_step_size=5e-3, mesh_intersect=mi)[0]
+    assert not img.requires_grad and (img.cpu() - rgb_o.detach()).abs().max().item() <= 2e-4
