@@ -48,6 +48,8 @@ class RayIntersector:
         self.device = torch.device(device)
         self.last_order = None           # coherent processing order of the most recent image-shaped sample_device()
         self._raster_backoff = 0         # frames left to skip the camera-coherent intersector after an overflow
+        self._raster_streak = 0          # consecutive camera-coherent attempts that overflowed (see want_raster)
+        self._raster_trying = False
         self._scratch = {}               # per-ray-count frame scratch, see _frame_scratch
         self.last_layout = None          # (inverse, xyz, dirs) of the most recent image-shaped pack, in the coherent order
         self._handle = ctypes.c_void_p()
@@ -84,8 +86,9 @@ class RayIntersector:
         _C.check(_C.lib().qf_bvh_refit(self._handle, tri.ctypes.data_as(ctypes.c_void_p), tri.shape[0]), "qf_bvh_refit")
 
     #: After a frame on which some pixel collected more than K candidates (the camera-coherent pass is then wasted and
-    #: the BVH answers), go straight to the BVH for this many frames before trying the camera-coherent pass again.
-    RASTER_BACKOFF = 16
+    #: the BVH answers) the next frames go straight to the BVH: 1 frame after an isolated overflow, doubling while the
+    #: overflows keep coming (dense-shell scenes overflow on every frame), up to this many; a clean pass halves it.
+    RASTER_BACKOFF_MAX = 64
 
     def want_raster(self, camera) -> bool:
         if camera is None:
@@ -93,10 +96,15 @@ class RayIntersector:
         if self._raster_backoff > 0:
             self._raster_backoff -= 1
             return False
+        if self._raster_trying:             # the previous attempt was not reported as an overflow: a clean pass
+            self._raster_streak = 0
+        self._raster_trying = True
         return True
 
     def raster_overflowed(self) -> None:
-        self._raster_backoff = self.RASTER_BACKOFF
+        self._raster_trying = False
+        self._raster_streak += 1
+        self._raster_backoff = min(self.RASTER_BACKOFF_MAX, 1 << min(self._raster_streak - 1, 30))
 
     def _alloc_hits(self, n, k):
         return (torch.empty((n, k), dtype=torch.int32, device=self.device),
