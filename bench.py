@@ -278,6 +278,7 @@ def main():
             "rays_per_frame": W * H, "max_hits": MAX_HITS, "triangles": int(mesh.faces.shape[0]),
             "log2_hashmap_size": LOG2_T, "render_step_size": STEP, "up_sample": args.up_sample,
             "intersector": args.intersector, "bvh_fallback_frames": getattr(stages, "fallbacks", 0),
+            "overflow_repaired_frames": mi.rayintersector.repaired_frames,
             "frames_in_flight": len(streams),
             "parallelism": f"{world} rank(s), one frame per rank per step" + (", all_gather of tiles" if world > 1 else ""),
         },

@@ -277,6 +277,13 @@ typedef struct qf_camera {
 int qf_raster_intersect(const qf_bvh *bvh, const qf_camera *cam /* host */, const float *rays_o,
                         const float *rays_d, int64_t n_rays, int32_t max_hits, int32_t *hit_tri, float *hit_t,
                         int32_t *hit_count, int32_t *overflow, int32_t sort_lists, void *stream);
+/* The fall-back, per ray: after qf_raster_intersect with sort_lists = 0 (raw counts), re-traverses exactly the rays
+ * with hit_count > max_hits through the BVH (exact K nearest; their lists and counts are overwritten, in the layout of
+ * qf_bvh_intersect) and leaves every other ray alone.  No host round trip; a frame with a handful of overflowing
+ * pixels costs a few microseconds instead of a whole-image traversal.                            */
+int qf_bvh_repair_overflow(const qf_bvh *bvh, const float *rays_o, const float *rays_d, int64_t n_rays,
+                           int32_t max_hits, int32_t image_width, int32_t *hit_tri, float *hit_t,
+                           int32_t *hit_count, void *stream);
 
 /* Occupancy-grid ray marching: nerfacc 0.5.3 OccGridEstimator.sampling -> traverse_grids for one grid level and
  * cone_angle = 0 (examples/utils.py:137-147,266-285).  Samples are [t0 + k*step, t0 + (k+1)*step],

@@ -74,7 +74,7 @@ __global__ __launch_bounds__(64) void bvh_traverse_kernel(const float4 *__restri
                                                           const float *__restrict__ rays_d, int64_t n_rays, int max_hits,
                                                           int image_width, int image_height, int tiles_x,
                                                           int32_t *__restrict__ hit_tri, float *__restrict__ hit_t,
-                                                          int32_t *__restrict__ hit_count)
+                                                          int32_t *__restrict__ hit_count, int only_overflowed)
 {
     const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int64_t ray;
@@ -89,6 +89,8 @@ __global__ __launch_bounds__(64) void bvh_traverse_kernel(const float4 *__restri
         ray = tid;
     }
     if (ray >= n_rays) return;
+    // repair pass after the camera-coherent intersector: only the rays whose candidate list overflowed are traversed
+    if (only_overflowed && hit_count[ray] <= max_hits) return;
 
     const float ox = rays_o[ray * 3], oy = rays_o[ray * 3 + 1], oz = rays_o[ray * 3 + 2];
     const float dx = rays_d[ray * 3], dy = rays_d[ray * 3 + 1], dz = rays_d[ray * 3 + 2];
@@ -815,9 +817,9 @@ int fill_tex_args(const qf_texture_set *tex, TexArgs *t)
     hipLaunchKernelGGL(kernel, dim3(qf_grid_1d((count), 256)), dim3(256), 0, qf_stream(stream), __VA_ARGS__); \
     QF_LAUNCH_CHECK();
 
-extern "C" int qf_bvh_intersect(const qf_bvh *bvh, const float *rays_o, const float *rays_d, int64_t n_rays,
-                                int32_t max_hits, int32_t image_width, int32_t *hit_tri, float *hit_t,
-                                int32_t *hit_count, void *stream)
+static int bvh_launch(const qf_bvh *bvh, const float *rays_o, const float *rays_d, int64_t n_rays, int32_t max_hits,
+                      int32_t image_width, int32_t *hit_tri, float *hit_t, int32_t *hit_count, int only_overflowed,
+                      void *stream)
 {
     if (!bvh || n_rays < 0 || max_hits < 1 || max_hits > kMaxHits || image_width < 0) return QF_ERR_INVALID_ARGUMENT;
     if (n_rays == 0) return QF_OK;
@@ -835,9 +837,23 @@ extern "C" int qf_bvh_intersect(const qf_bvh *bvh, const float *rays_o, const fl
     hipLaunchKernelGGL(bvh_traverse_kernel, dim3((unsigned)blocks), dim3(64), 0, qf_stream(stream),
                        reinterpret_cast<const float4 *>(bvh->d_nodes), reinterpret_cast<const float4 *>(bvh->d_tris),
                        bvh->n_tri > 0 ? 1 : 0, rays_o, rays_d, n_rays, (int)max_hits, (int)image_width, height, tiles_x,
-                       hit_tri, hit_t, hit_count);
+                       hit_tri, hit_t, hit_count, only_overflowed);
     QF_LAUNCH_CHECK();
     return QF_OK;
+}
+
+extern "C" int qf_bvh_intersect(const qf_bvh *bvh, const float *rays_o, const float *rays_d, int64_t n_rays,
+                                int32_t max_hits, int32_t image_width, int32_t *hit_tri, float *hit_t,
+                                int32_t *hit_count, void *stream)
+{
+    return bvh_launch(bvh, rays_o, rays_d, n_rays, max_hits, image_width, hit_tri, hit_t, hit_count, 0, stream);
+}
+
+extern "C" int qf_bvh_repair_overflow(const qf_bvh *bvh, const float *rays_o, const float *rays_d, int64_t n_rays,
+                                      int32_t max_hits, int32_t image_width, int32_t *hit_tri, float *hit_t,
+                                      int32_t *hit_count, void *stream)
+{
+    return bvh_launch(bvh, rays_o, rays_d, n_rays, max_hits, image_width, hit_tri, hit_t, hit_count, 1, stream);
 }
 
 extern "C" int qf_pack_samples(const float *rays_o, const float *rays_d, int64_t n_rays, int32_t max_hits,

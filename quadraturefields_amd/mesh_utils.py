@@ -48,6 +48,7 @@ class RayIntersector:
         self.device = torch.device(device)
         self.last_order = None           # coherent processing order of the most recent image-shaped sample_device()
         self._raster_backoff = 0         # frames left to skip the camera-coherent intersector after an overflow
+        self.repaired_frames = 0         # frames on which some pixels overflowed K and were repaired through the BVH
         self._raster_streak = 0          # consecutive camera-coherent attempts that overflowed (see want_raster)
         self._raster_trying = False
         self._scratch = {}               # per-ray-count frame scratch, see _frame_scratch
@@ -181,7 +182,11 @@ class RayIntersector:
         _C.check(_C.lib().qf_raster_intersect(self._handle, ctypes.byref(camera), _C.ptr(o), _C.ptr(d), n, k,
                                               _C.ptr(hit_tri), _C.ptr(hit_t), _C.ptr(hit_count), _C.ptr(overflow),
                                               0, _C.stream()), "qf_raster_intersect")
-        hit_count.clamp_(max=k)      # overflowing pixels counted past K; everything downstream indexes with <= K
+        # pixels that collected more than K candidates: exact K nearest through the BVH, those rays only, no host
+        # round trip (afterwards every count is <= K)
+        _C.check(_C.lib().qf_bvh_repair_overflow(self._handle, _C.ptr(o), _C.ptr(d), n, k, int(camera.width),
+                                                 _C.ptr(hit_tri), _C.ptr(hit_t), _C.ptr(hit_count), _C.stream()),
+                 "qf_bvh_repair_overflow")
         return hit_tri, hit_t, hit_count, overflow
 
     def pack_hits(self, o, d, k, hit_tri, hit_t, hit_count, overflow, width, lean=False, layout=True):
@@ -191,8 +196,8 @@ class RayIntersector:
         (total, raster overflow) pair starts its way to pinned host memory, and the pack and ordering kernels run
         into buffers sized for the worst case (n_rays * K samples -- 60 B each, ~1 GB for an 800x800 frame, nothing
         against 288 GB) while the host waits for those 16 bytes; the results are views of the first ``total`` rows.
-        ``overflow`` (from ``_hits_raster_frame``) marks lists with more than K candidates: the frame is redone with
-        the exact K-nearest BVH traversal.  ``pack_hits_begin`` / ``pack_hits_end`` are the two halves, for callers
+        ``overflow`` (from ``_hits_raster_frame``) counts candidates beyond K; those rays were already repaired on the
+        device, the count only steers the intersector policy.  ``pack_hits_begin`` / ``pack_hits_end`` are the two halves, for callers
         that keep several frames in flight on different streams."""
         return self.pack_hits_end(self.pack_hits_begin(o, d, k, hit_tri, hit_t, hit_count, overflow, width, lean, layout))
 
@@ -240,10 +245,10 @@ class RayIntersector:
         o, d, k, width, lean, host, ev, arrays, order, layout, _lists = pending
         ev.synchronize()
         total, ovf = int(host[0]), int(host[1])
-        if ovf:
-            self.raster_overflowed()
-            hit_tri, hit_t, hit_count = self._hits_bvh(o, d, k, width)
-            return self.pack_hits(o, d, k, hit_tri, hit_t, hit_count, None, width, *lean)
+        if ovf:                                # already repaired on the device (qf_bvh_repair_overflow); policy only
+            self.repaired_frames += 1
+            if ovf > 0.05 * o.shape[0]:        # most of the image overflows (dense shells): the camera-coherent pass is wasted
+                self.raster_overflowed()
         self.last_layout = None
         if total == 0:
             return None, None

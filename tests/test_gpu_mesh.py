@@ -221,6 +221,14 @@ def test_raster_intersector_identical_to_bvh(device, w, h, max_hits):
                 assert torch.equal(x, y)
         else:
             assert int(ri._hits_raster(a[3], a[4], max_hits, cam)[3].item()) > 0
+            # overflowing pixels are repaired per ray on the device: the packed samples equal the BVH path's
+            ri._raster_backoff = 0
+            before = ri.repaired_frames
+            s1 = ri.sample_device(o, d, image_width=w)
+            s2 = ri.sample_device(o, d, camera=cam)
+            assert ri.repaired_frames == before + 1
+            for x, y in zip(s1, s2):
+                assert torch.equal(x, y)
     # camera inside the object and a camera whose image plane cuts triangles: still identical
     c2w = synthetic.orbit_cameras(1, seed=3)[0].clone()
     c2w[:, 3] *= 0.12
