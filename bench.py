@@ -162,6 +162,9 @@ def main():
                     help="frames in flight (one HIP stream each); 1 = strictly one frame after the other.  Measured: "
                          "2 or 3 frames in flight are 4-5 %% SLOWER (the fabric-bound field kernels of two frames "
                          "overlap each other and the small kernels gain nothing), so the default stays 1")
+    ap.add_argument("--gather", action="store_true",
+                    help="N > 1: all_gather every finished frame (rgb, alpha, depth) to all ranks.  Off by default: the "
+                         "frames are independent units dealt to the ranks, the path has no exchange step")
     ap.add_argument("--intersector", default="raster", choices=["raster", "bvh"],
                     help="raster: camera-coherent intersector (BVH fallback on overflow); bvh: BVH traversal only")
     args = ap.parse_args()
@@ -190,12 +193,13 @@ def main():
     # --pipeline N keeps N frames in flight: frame i's intersection / pack kernels are enqueued on one stream before
     # the host waits for frame i-1's sample count and launches its field + compositing kernels on another.
     streams = [torch.cuda.Stream(device=device) for _ in range(max(1, args.pipeline))]
-    gather_bufs = {s: torch.empty((world * W * H, 5), dtype=torch.float32, device=device) for s in streams} if world > 1 else {}
+    gather = args.gather and world > 1
+    gather_bufs = {s: torch.empty((world * W * H, 5), dtype=torch.float32, device=device) for s in streams} if gather else {}
 
     def complete(begun, s):
         with torch.cuda.stream(s):
             rgb, alpha, depth, n_pts = stages.finish(begun)
-            if world > 1:
+            if gather:
                 torch.distributed.all_gather_into_tensor(gather_bufs[s], torch.cat([rgb, alpha, depth], dim=1))
         return rgb, n_pts
 
@@ -280,7 +284,8 @@ def main():
             "intersector": args.intersector, "bvh_fallback_frames": getattr(stages, "fallbacks", 0),
             "overflow_repaired_frames": mi.rayintersector.repaired_frames,
             "frames_in_flight": len(streams),
-            "parallelism": f"{world} rank(s), one frame per rank per step" + (", all_gather of tiles" if world > 1 else ""),
+            "parallelism": f"{world} rank(s), the frames dealt round-robin to the ranks, one frame per rank per step"
+                           + (", all_gather of the finished frames" if gather else ", no data-path collective"),
         },
         "quadrature_points_per_frame": pts_per_launch,
         "field_evals_per_s": pts_total / elapsed,
