@@ -165,6 +165,10 @@ def main():
     ap.add_argument("--gather", action="store_true",
                     help="N > 1: all_gather every finished frame (rgb, alpha, depth) to all ranks.  Off by default: the "
                          "frames are independent units dealt to the ranks, the path has no exchange step")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend for N > 1 (nccl = RCCL).  gloo + --single-device rehearses the multi-rank "
+                         "control flow on a one-GPU box (all ranks on cuda:0)")
+    ap.add_argument("--single-device", action="store_true", help="map every rank to cuda:0 (rehearsal only)")
     ap.add_argument("--intersector", default="raster", choices=["raster", "bvh"],
                     help="raster: camera-coherent intersector (BVH fallback on overflow); bvh: BVH traversal only")
     args = ap.parse_args()
@@ -173,7 +177,9 @@ def main():
     W = H = 800 * args.up_sample
 
     from quadraturefields_amd import parallel, synthetic
-    rank, local_rank, world = parallel.init_from_env("nccl")
+    if args.single_device:
+        os.environ["LOCAL_RANK"] = "0"
+    rank, local_rank, world = parallel.init_from_env(args.backend)
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
@@ -232,7 +238,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     log(f"timed region done: {elapsed:.3f} s for {args.steps} steps")
-    t = torch.tensor([elapsed, float(pts)], dtype=torch.float64, device=device)
+    t = torch.tensor([elapsed, float(pts)], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
     if world > 1:
         tmax = t.clone()
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
@@ -243,6 +249,7 @@ def main():
         pts_total = float(pts)
 
     if rank != 0:
+        parallel.shutdown()
         return
     ms = stages.stage_ms()                      # field: HIP events inside the timed region
     for i in range(min(5, n_frames)):           # the other stages: an extra, untimed pass with events everywhere
@@ -308,7 +315,8 @@ def main():
         mse = float(((rgb0.double() - rgb_o.double()) ** 2).mean())
         base["psnr_hip_vs_oracle_db"] = float("inf") if mse == 0 else -10.0 * float(np.log10(mse))
         result["cpu_baseline"] = base
-    print(json.dumps(result))
+    print(json.dumps(result), flush=True)
+    parallel.shutdown()
 
 
 if __name__ == "__main__":

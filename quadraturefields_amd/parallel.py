@@ -75,5 +75,17 @@ def init_from_env(backend: str = "nccl"):
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        if backend == "nccl" and torch.cuda.is_available():
+            # bind the rank to its GPU before RCCL comes up, and tell the process group which device it owns
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend=backend, rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local_rank, world
+
+
+def shutdown() -> None:
+    """Tear the process group down (no-op for a single process)."""
+    if dist.is_available() and dist.is_initialized():
+        dist.destroy_process_group()
