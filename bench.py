@@ -115,9 +115,11 @@ class Stages:
         self.order = order if self.coherent else None
         return data
 
-    def stage_ms(self):
+    def stage_ms(self, reduce=np.mean):
+        """HIP-event time per stage, averaged (the timed region) or as a median (the untimed stage pass, where a
+        one-off stall must not skew a stage)."""
         torch.cuda.synchronize()
-        return {k: (float(np.mean([a.elapsed_time(b) for a, b in v])) if v else None) for k, v in self.ev.items()}
+        return {k: (float(reduce([a.elapsed_time(b) for a, b in v])) if v else None) for k, v in self.ev.items()}
 
 
 def cpu_baseline(mesh, field, cam_o, cam_d, crop=200):
@@ -256,7 +258,7 @@ def main():
         stages.frame(rays[i][0], rays[i][1], cameras[i], True)
     field_ms = ms["field"]
     stages.ev["field"] = []
-    ms = stages.stage_ms()
+    ms = stages.stage_ms(np.median)
     ms["field"] = field_ms
     # HBM-side bytes of the dominant kernel come from PMC counters (separate rocprofv3 --pmc passes over this same
     # command, see profiles/r1/README.md); bench.py cannot sample them itself, so the committed measurement is scaled

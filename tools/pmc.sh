@@ -14,7 +14,7 @@ for PASS in \
   "TA_BUSY_avr TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TD_TD_BUSY_sum TD_TC_STALL_sum" \
   "GRBM_GUI_ACTIVE GRBM_COUNT SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_WR SQ_VALU_MFMA_COEXEC_CYCLES" ; do
   i=$((i+1))
-  timeout -k 10 240 rocprofv3 --pmc $PASS --output-format csv -d $R/gpurun_out/$OUT/p$i -- python3 $R/tools/field_bench.py --stage $STAGE --iters 3 > $R/gpurun_out/$OUT.p$i.log 2>&1 || echo "pass $i failed"
+  timeout -k 10 240 rocprofv3 --pmc $PASS --output-format csv -d $R/gpurun_out/$OUT/p$i -- python3 $R/tools/field_bench.py --stage $STAGE --iters 3 --physical > $R/gpurun_out/$OUT.p$i.log 2>&1 || echo "pass $i failed"
 done
 python3 $R/tools/pmc_summary.py $R/gpurun_out/$OUT > $R/gpurun_out/$OUT.summary.txt 2>&1
 cat $R/gpurun_out/$OUT.summary.txt
