@@ -136,6 +136,16 @@ int qf_field_forward_bf16(const qf_field_desc *desc /* host */, const uint16_t *
                           const qf_sg_head_bf16 *head_sg /* host */, const float *xyz, const float *dirs,
                           int64_t n, const int32_t *order, float *rgb, float *sigma, float *geo, void *stream);
 
+/* Backward of the two MLPs of NGPRadianceField (ngp.py:757-809), fused: recomputes the forward pass from the grid
+ * encodings, back-propagates dL/drgb [n,3] and dL/ddensity [n] to dL/denc [n,32] (-> qf_grid_encode_backward) and
+ * ACCUMULATES the weight gradients into grad_base_w [3072] / grad_head_w [7168] (zero them first; layouts as
+ * base_w / head NGP above).  selector [n] uint8: the point is inside the aabb (density = exp(raw-1)*selector).
+ * Replaces the backward of tcnn's FullyFusedMLP that torch autograd reaches in train_finetune.py:465-533.      */
+int qf_ngp_mlp_backward(const float *enc /* [n,32] */, const float *dirs /* [n,3] */, const uint8_t *selector,
+                        const float *d_rgb, const float *d_sigma, const float *base_w, const float *head_w,
+                        int64_t n, float *d_enc /* [n,32] */, float *grad_base_w, float *grad_head_w,
+                        void *stream);
+
 /* rgb = sigmoid(diffuse + sum_l c_l exp(|lambda_l| (a_l/|a_l| . d - 1))).
  * Replaces NGPRadianceFieldSGNew.features_to_rgb (ngp.py:456-461, discretize=False).
  * features [n, 3+7L] (row stride `feat_stride` floats), dirs [n,3] -> rgb [n,3].              */

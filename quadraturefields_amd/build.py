@@ -21,6 +21,7 @@ SOURCES = [
     ("field_eval.hip", []),
     ("field_eval_bf16.hip", []),
     ("grid_backward.hip", []),
+    ("mlp_train.hip", []),
     ("scan.hip", []),
     ("composite.hip", []),
     ("exact.hip", ["-ffp-contract=off"]),

@@ -1,0 +1,379 @@
+// Fused backward of the NGPRadianceField MLPs (training side).
+//
+// Replaces the backward of tcnn's FullyFusedMLP pair that torch autograd reaches when the reference trains
+// NGPRadianceField (examples/radiance_fields/ngp.py:757-809 under examples/train_finetune.py:465-533):
+//   enc [n,32] -> 64 (ReLU) -> 16 = [raw density | geo15];  density = exp(raw - 1) * selector
+//   [SH16(dir) | geo15 | 1] -> 64 (ReLU) -> 64 (ReLU) -> 16;  rgb = sigmoid(out[:3])
+// Given dL/drgb [n,3] and dL/ddensity [n], one launch recomputes the forward pass of 16 points per wave exactly as
+// field_kernel does (same MFMA chain, activations in registers) and then
+//   * back-propagates through the transposed weights with the SAME chained layout -- the D-layout accumulator of one
+//     layer is the B operand of the next, the k-order permutation lives in the (transposed) weight images in LDS --
+//     down to dL/denc [n,32], which goes to qf_grid_encode_backward;
+//   * accumulates the five weight gradients dW = sum_p dz[:,p] a[:,p]^T on the matrix cores: both operands are moved
+//     from the D layout (neuron quartet x point) to the A/B layout (neuron x point quartet) through a per-wave LDS
+//     transpose, and the 40 16x16 tiles of dW (10 240 parameters) stay in 160 accumulator registers per lane for the
+//     whole launch; at the end every wave adds its tiles to the fp32 gradient vectors with atomics.
+// v_mfma_f32_16x16x4_f32 throughout (exact fp32 products, fp32 accumulate).
+#include "field_common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kTrainBlock = 256;     // 4 waves: one per SIMD, so that a lane may use up to 512 registers
+constexpr int kFwdMfma = 160;        // 48 base + 112 head, program order of field_kernel<NGP>
+constexpr int kBwdMfma = 144;        // V3^T 16, V2^T 64, V1^T (geo rows) 16, W2^T 16, W1^T 32
+
+struct TrainArgs {
+    const float *enc, *dirs;
+    const uint8_t *sel;
+    const float *d_rgb, *d_sigma;
+    const float *base_w, *head_w;
+    int64_t n;
+    float *d_enc, *g_base, *g_head;
+};
+
+__device__ __forceinline__ f32x4 mfma(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+
+__device__ __forceinline__ int img_index(int m, int lane) { return ((((m >> 2) << 6) + lane) << 2) + (m & 3); }
+
+// column of the head's first layer fed by register 4+r of lane quartet kq: [geo | 1] part of [SH16 | geo15 | 1]
+__device__ __forceinline__ int geo_col(int o) { return o == 0 ? 31 : 15 + o; }
+
+// A operand of forward MFMA m (identical to field_kernel<QF_HEAD_NGP>)
+__device__ float fwd_weight(const TrainArgs &a, int m, int lane)
+{
+    const int i = lane & 15, kq = lane >> 4;
+    if (m < 32) {
+        const int s = m >> 2, mt = m & 3;
+        return a.base_w[(16 * mt + i) * 32 + 2 * (4 * (s >> 1) + kq) + (s & 1)];
+    }
+    if (m < 48) return a.base_w[2048 + i * 64 + hidden_col(m - 32, kq)];
+    m -= 48;
+    if (m < 32) {
+        const int s = m >> 2, mt = m & 3;
+        const int col = s < 4 ? 4 * kq + s : geo_col(4 * kq + (s - 4));
+        return a.head_w[(16 * mt + i) * 32 + col];
+    }
+    if (m < 96) {
+        const int q = m - 32, s = q >> 2, mt = q & 3;
+        return a.head_w[2048 + (16 * mt + i) * 64 + hidden_col(s, kq)];
+    }
+    return a.head_w[2048 + 4096 + i * 64 + hidden_col(m - 96, kq)];
+}
+
+// A operand of backward MFMA bm: rows = inputs of the layer, k = its outputs (see the plan in qf_hip.h)
+__device__ float bwd_weight(const TrainArgs &a, int bm, int lane)
+{
+    const int i = lane & 15, kq = lane >> 4;
+    if (bm < 16) {                        // V3^T: [64 x 16], s outer (4), mt' inner (4); k = out row 4kq + s
+        const int s = bm >> 2, mt = bm & 3;
+        return a.head_w[2048 + 4096 + (4 * kq + s) * 64 + 16 * mt + i];
+    }
+    if (bm < 80) {                        // V2^T: [64 x 64], s outer (16), mt' inner (4)
+        const int q = bm - 16, s = q >> 2, mt = q & 3;
+        return a.head_w[2048 + hidden_col(s, kq) * 64 + 16 * mt + i];
+    }
+    if (bm < 96) {                        // V1^T, the 16 rows that carry [1 | geo15]: k-steps 16
+        const int s = bm - 80;
+        return a.head_w[hidden_col(s, kq) * 32 + geo_col(i)];
+    }
+    if (bm < 112) {                       // W2^T: [64 x 16], s outer (4), mt' inner (4)
+        const int q = bm - 96, s = q >> 2, mt = q & 3;
+        return a.base_w[2048 + (4 * kq + s) * 64 + 16 * mt + i];
+    }
+    const int q = bm - 112, s = q >> 1, mt = q & 1;   // W1^T: [32 x 64], s outer (16), mt' inner (2)
+    return a.base_w[hidden_col(s, kq) * 32 + 16 * mt + i];
+}
+
+// D layout (lane (g,p): rows 4g..4g+3 of column p) -> A/B layout (lane (i,kq): row i, columns 4s+kq for s = 0..3),
+// through a 16 x 17 float scratch private to the wave.
+__device__ __forceinline__ f32x4 to_operand(const f32x4 d, volatile float *scratch, int lane)
+{
+    const int g = lane >> 4, p = lane & 15;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) scratch[(4 * g + r) * 17 + p] = d[r];
+    __builtin_amdgcn_wave_barrier();
+    f32x4 o;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) o[s] = scratch[p * 17 + 4 * s + g];   // row i = p, column 4s + kq, kq = g
+    __builtin_amdgcn_wave_barrier();
+    return o;
+}
+
+// acc += dz^T-tile x a^T-tile over the 16 points of the group (4 k-steps of 4 points)
+__device__ __forceinline__ f32x4 outer_acc(const f32x4 dz_op, const f32x4 a_op, f32x4 acc)
+{
+#pragma unroll
+    for (int s = 0; s < 4; ++s) acc = mfma(dz_op[s], a_op[s], acc);
+    return acc;
+}
+
+__global__ __launch_bounds__(kTrainBlock, 1) void ngp_mlp_backward_kernel(const TrainArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, p = lane & 15;
+    for (int e = tid; e < kFwdMfma * 64; e += kTrainBlock) lds[img_index(e >> 6, e & 63)] = fwd_weight(a, e >> 6, e & 63);
+    float *blds = lds + kFwdMfma * 64;
+    for (int e = tid; e < kBwdMfma * 64; e += kTrainBlock) blds[img_index(e >> 6, e & 63)] = bwd_weight(a, e >> 6, e & 63);
+    volatile float *scratch = blds + kBwdMfma * 64 + wave * (16 * 17);
+    __syncthreads();
+    const f32x4 *img = reinterpret_cast<const f32x4 *>(lds);
+    const f32x4 *bimg = reinterpret_cast<const f32x4 *>(blds);
+
+    const f32x4 zero = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 aV3[4], aV2[4][4], aV1[4][2], aW2[4], aW1[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        aV3[i] = zero;
+        aW2[i] = zero;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) aV2[i][j] = zero;
+        aV1[i][0] = aV1[i][1] = aW1[i][0] = aW1[i][1] = zero;
+    }
+
+    const int64_t n_groups = (a.n + 15) >> 4;
+    const int64_t wave_global = (int64_t)blockIdx.x * (kTrainBlock / 64) + wave;
+    const int64_t wave_stride = (int64_t)gridDim.x * (kTrainBlock / 64);
+    for (int64_t grp = wave_global; grp < n_groups; grp += wave_stride) {
+        const int64_t pt_raw = grp * 16 + p;
+        const bool valid = pt_raw < a.n;
+        const int64_t pt = valid ? pt_raw : a.n - 1;
+        int loff = lane;
+        asm volatile("" : "+v"(loff));              // keep the weight images in LDS (see field_kernel)
+        const f32x4 *im = img + loff;
+        const f32x4 *bi = bimg + loff;
+
+        // ---------------------------------------------------------------- forward, as field_kernel<NGP>
+        float feat[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) feat[s] = a.enc[pt * 32 + 2 * (4 * (s >> 1) + g) + (s & 1)];
+        f32x4 h[4] = {zero, zero, zero, zero};
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const f32x4 w4 = im[s * 64];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) h[mt] = mfma(w4[mt], feat[s], h[mt]);
+        }
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) h[mt][r] = fmaxf(h[mt][r], 0.0f);
+        f32x4 oa = zero, ob = zero;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 w4 = im[(8 + q) * 64];
+            oa = mfma(w4[0], h[q][0], oa);
+            ob = mfma(w4[1], h[q][1], ob);
+            oa = mfma(w4[2], h[q][2], oa);
+            ob = mfma(w4[3], h[q][3], ob);
+        }
+        const f32x4 base_out = oa + ob;
+        const float density = a.sel[pt] ? expf(base_out[0] - 1.0f) : 0.0f;
+        const float dx = a.dirs[pt * 3 + 0], dy = a.dirs[pt * 3 + 1], dzv = a.dirs[pt * 3 + 2];
+        const float ux = ((dx + 1.0f) / 2.0f) * 2.0f - 1.0f, uy = ((dy + 1.0f) / 2.0f) * 2.0f - 1.0f,
+                    uz = ((dzv + 1.0f) / 2.0f) * 2.0f - 1.0f;
+        float in[8];
+        sh4_quartet(g, ux, uy, uz, in);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) in[4 + r] = base_out[r];
+        if (g == 0) in[4] = 1.0f;
+        f32x4 h1[4] = {zero, zero, zero, zero};
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const f32x4 w4 = im[(12 + s) * 64];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) h1[mt] = mfma(w4[mt], in[s], h1[mt]);
+        }
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) h1[mt][r] = fmaxf(h1[mt][r], 0.0f);
+        f32x4 h2[4] = {zero, zero, zero, zero};
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const f32x4 w4 = im[(20 + s) * 64];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) h2[mt] = mfma(w4[mt], h1[s >> 2][s & 3], h2[mt]);
+        }
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) h2[mt][r] = fmaxf(h2[mt][r], 0.0f);
+        f32x4 ca = zero, cb = zero;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 w4 = im[(36 + q) * 64];
+            ca = mfma(w4[0], h2[q][0], ca);
+            cb = mfma(w4[1], h2[q][1], cb);
+            ca = mfma(w4[2], h2[q][2], ca);
+            cb = mfma(w4[3], h2[q][3], cb);
+        }
+        const f32x4 c = ca + cb;
+
+        // ---------------------------------------------------------------- backward through the head
+        f32x4 dz3 = zero;                      // rows 0..2 of the 16-row output tile live in lane quartet 0
+        if (g == 0 && valid) {
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const float sg = sigmoidf(c[r]);
+                dz3[r] = a.d_rgb[pt * 3 + r] * sg * (1.0f - sg);
+            }
+        }
+        f32x4 dz2[4] = {zero, zero, zero, zero};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const f32x4 w4 = bi[s * 64];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) dz2[mt] = mfma(w4[mt], dz3[s], dz2[mt]);
+        }
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dz2[mt][r] = h2[mt][r] > 0.0f ? dz2[mt][r] : 0.0f;
+        f32x4 dz1[4] = {zero, zero, zero, zero};
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const f32x4 w4 = bi[(4 + s) * 64];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) dz1[mt] = mfma(w4[mt], dz2[s >> 2][s & 3], dz1[mt]);
+        }
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dz1[mt][r] = h1[mt][r] > 0.0f ? dz1[mt][r] : 0.0f;
+        f32x4 da = zero, db = zero;            // d[1 | geo15]: lane (g,p) register r = d out16 row 4g + r (row 0 unused)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 w4 = bi[(20 + q) * 64];
+            da = mfma(w4[0], dz1[q][0], da);
+            db = mfma(w4[1], dz1[q][1], db);
+            da = mfma(w4[2], dz1[q][2], da);
+            db = mfma(w4[3], dz1[q][3], db);
+        }
+        f32x4 dout = da + db;
+        if (g == 0) dout[0] = valid ? a.d_sigma[pt] * density : 0.0f;   // d exp(raw - 1) * selector
+        if (!valid) dout = zero;
+
+        // ---------------------------------------------------------------- head weight gradients
+        {
+            const f32x4 t3 = to_operand(dz3, scratch, lane);
+            f32x4 th[4];
+#pragma unroll
+            for (int ti = 0; ti < 4; ++ti) th[ti] = to_operand(h2[ti], scratch, lane);
+#pragma unroll
+            for (int ti = 0; ti < 4; ++ti) aV3[ti] = outer_acc(t3, th[ti], aV3[ti]);
+#pragma unroll
+            for (int ti = 0; ti < 4; ++ti) th[ti] = to_operand(h1[ti], scratch, lane);
+#pragma unroll
+            for (int to = 0; to < 4; ++to) {
+                const f32x4 tz = to_operand(dz2[to], scratch, lane);
+#pragma unroll
+                for (int ti = 0; ti < 4; ++ti) aV2[to][ti] = outer_acc(tz, th[ti], aV2[to][ti]);
+            }
+            f32x4 tin[2];
+            tin[0] = to_operand((f32x4){in[0], in[1], in[2], in[3]}, scratch, lane);
+            tin[1] = to_operand((f32x4){in[4], in[5], in[6], in[7]}, scratch, lane);
+#pragma unroll
+            for (int to = 0; to < 4; ++to) {
+                const f32x4 tz = to_operand(dz1[to], scratch, lane);
+                aV1[to][0] = outer_acc(tz, tin[0], aV1[to][0]);
+                aV1[to][1] = outer_acc(tz, tin[1], aV1[to][1]);
+            }
+        }
+
+        // ---------------------------------------------------------------- backward through the base MLP
+        f32x4 dzh[4] = {zero, zero, zero, zero};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const f32x4 w4 = bi[(24 + s) * 64];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) dzh[mt] = mfma(w4[mt], dout[s], dzh[mt]);
+        }
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dzh[mt][r] = h[mt][r] > 0.0f ? dzh[mt][r] : 0.0f;
+        f32x4 de[2] = {zero, zero};
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const f32x4 w4 = bi[(28 + (s >> 1)) * 64];
+            de[0] = mfma(w4[2 * (s & 1) + 0], dzh[s >> 2][s & 3], de[0]);
+            de[1] = mfma(w4[2 * (s & 1) + 1], dzh[s >> 2][s & 3], de[1]);
+        }
+        if (valid) {
+            *reinterpret_cast<f32x4 *>(a.d_enc + pt * 32 + 4 * g) = de[0];
+            *reinterpret_cast<f32x4 *>(a.d_enc + pt * 32 + 16 + 4 * g) = de[1];
+        }
+        {
+            const f32x4 to_ = to_operand(dout, scratch, lane);
+            f32x4 th[4];
+#pragma unroll
+            for (int ti = 0; ti < 4; ++ti) th[ti] = to_operand(h[ti], scratch, lane);
+#pragma unroll
+            for (int ti = 0; ti < 4; ++ti) aW2[ti] = outer_acc(to_, th[ti], aW2[ti]);
+            f32x4 tf[2];
+            tf[0] = to_operand((f32x4){feat[0], feat[1], feat[2], feat[3]}, scratch, lane);
+            tf[1] = to_operand((f32x4){feat[4], feat[5], feat[6], feat[7]}, scratch, lane);
+#pragma unroll
+            for (int to = 0; to < 4; ++to) {
+                const f32x4 tz = to_operand(dzh[to], scratch, lane);
+                aW1[to][0] = outer_acc(tz, tf[0], aW1[to][0]);
+                aW1[to][1] = outer_acc(tz, tf[1], aW1[to][1]);
+            }
+        }
+    }
+
+    // ---- add this wave's 40 tiles to the gradient vectors: lane (g,p) register r = dW[16 to + 4g + r][column(ti, p)]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = 4 * g + r;
+#pragma unroll
+        for (int ti = 0; ti < 4; ++ti) {
+            atomicAdd(a.g_head + 2048 + 4096 + row * 64 + 16 * ti + p, aV3[ti][r]);
+            atomicAdd(a.g_base + 2048 + row * 64 + 16 * ti + p, aW2[ti][r]);
+#pragma unroll
+            for (int to = 0; to < 4; ++to) atomicAdd(a.g_head + 2048 + (16 * to + row) * 64 + 16 * ti + p, aV2[to][ti][r]);
+        }
+#pragma unroll
+        for (int to = 0; to < 4; ++to) {
+            atomicAdd(a.g_head + (16 * to + row) * 32 + p, aV1[to][0][r]);
+            atomicAdd(a.g_head + (16 * to + row) * 32 + geo_col(p), aV1[to][1][r]);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int s = 4 * t + (p & 3);
+                atomicAdd(a.g_base + (16 * to + row) * 32 + 2 * (4 * (s >> 1) + (p >> 2)) + (s & 1), aW1[to][t][r]);
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int qf_ngp_mlp_backward(const float *enc, const float *dirs, const uint8_t *selector, const float *d_rgb,
+                                   const float *d_sigma, const float *base_w, const float *head_w, int64_t n,
+                                   float *d_enc, float *grad_base_w, float *grad_head_w, void *stream)
+{
+    if (n < 0) return QF_ERR_INVALID_ARGUMENT;
+    if (n == 0) return QF_OK;
+    if (!enc || !dirs || !selector || !d_rgb || !d_sigma || !base_w || !head_w || !d_enc || !grad_base_w || !grad_head_w)
+        return QF_ERR_INVALID_ARGUMENT;
+    TrainArgs a;
+    a.enc = enc; a.dirs = dirs; a.sel = selector; a.d_rgb = d_rgb; a.d_sigma = d_sigma;
+    a.base_w = base_w; a.head_w = head_w; a.n = n; a.d_enc = d_enc; a.g_base = grad_base_w; a.g_head = grad_head_w;
+    const size_t lds_bytes = (size_t)((kFwdMfma + kBwdMfma) * 64 + (kTrainBlock / 64) * 16 * 17) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        QF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(ngp_mlp_backward_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        attr_set = true;
+    }
+    const int64_t n_groups = (n + 15) / 16;
+    int64_t blocks = qf_div_up(n_groups, kTrainBlock / 64);
+    const int64_t cap = (int64_t)qf_cu_count_cached();
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(ngp_mlp_backward_kernel, dim3((unsigned)blocks), dim3(kTrainBlock), lds_bytes, qf_stream(stream), a);
+    QF_LAUNCH_CHECK();
+    return QF_OK;
+}

@@ -246,8 +246,68 @@ class _FusedFieldBase(nn.Module):
         return density
 
 
+class _NGPTrainFn(torch.autograd.Function):
+    """(rgb, density) of NGPRadianceField with a fused backward: forward = the inference kernel (qf_field_forward),
+    backward = grid encode + qf_ngp_mlp_backward (recompute, back-propagate and accumulate both MLPs' weight
+    gradients on the matrix cores) + qf_grid_encode_backward (table scatter, input gradient).  First order only; the
+    module falls back to the library-GEMM route when a graph of the backward is requested."""
+
+    @staticmethod
+    def forward(ctx, positions, directions, base_params, head_params, module):
+        xyz = _C.f32c(positions.detach().reshape(-1, 3))
+        dirs = _C.f32c(directions.detach().reshape(-1, 3))
+        rgb, sigma, _, _ = module._launch(_C.HEAD_NGP, 0, xyz, dirs, want_rgb=True, want_sigma=True,
+                                          head_ngp=head_params.detach())
+        ctx.save_for_backward(xyz, dirs, base_params, head_params)
+        ctx.module = module
+        return rgb, sigma
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, d_rgb, d_sigma):
+        xyz, dirs, base_params, head_params = ctx.saved_tensors
+        m = ctx.module
+        n = xyz.shape[0]
+        dev = xyz.device
+        base = base_params.detach()
+        n_net = m.mlp_base.n_network_params
+        net_w, table = base[:n_net].contiguous(), base[n_net:].contiguous()
+        head_w = _C.f32c(head_params.detach())
+        selector, x01 = m.normalize(xyz)
+        x01 = _C.f32c(x01)
+        sel = selector.to(torch.uint8).contiguous()
+        lib = _C.lib()
+        desc = m.mlp_base.grid.desc
+        enc = torch.empty((n, 32), dtype=torch.float32, device=dev)
+        d_enc = torch.empty((n, 32), dtype=torch.float32, device=dev)
+        g_net = torch.zeros_like(net_w)
+        g_head = torch.zeros_like(head_w)
+        need_x, need_base, need_head = ctx.needs_input_grad[0], ctx.needs_input_grad[2], ctx.needs_input_grad[3]
+        g_table = torch.zeros_like(table) if need_base else None
+        g_x01 = torch.empty_like(x01) if need_x else None
+        if n:
+            _C.check(lib.qf_grid_encode(desc, _C.ptr(table), _C.ptr(x01), n, _C.ptr(enc), _C.stream()), "qf_grid_encode")
+            _C.check(lib.qf_ngp_mlp_backward(_C.ptr(enc), _C.ptr(dirs), _C.ptr(sel), _C.ptr(_C.f32c(d_rgb.reshape(-1, 3))),
+                                             _C.ptr(_C.f32c(d_sigma.reshape(-1))), _C.ptr(net_w), _C.ptr(head_w), n,
+                                             _C.ptr(d_enc), _C.ptr(g_net), _C.ptr(g_head), _C.stream()),
+                     "qf_ngp_mlp_backward")
+            if need_base or need_x:
+                _C.check(lib.qf_grid_encode_backward(desc, _C.ptr(table), _C.ptr(x01), _C.ptr(d_enc), n, _C.ptr(g_table),
+                                                     _C.ptr(g_x01), _C.stream()), "qf_grid_encode_backward")
+        g_pos = None
+        if need_x:
+            lo, hi = torch.split(m.aabb, 3, dim=-1)
+            g_pos = g_x01 / (hi - lo)
+        g_base = torch.cat([g_net, g_table]) if need_base else None
+        return g_pos, None, g_base, (g_head if need_head else None), None
+
+
 class NGPRadianceField(_FusedFieldBase):
     """Instant-NGP radiance field with the SH-degree-4 view-dependent head (ngp.py:657-809)."""
+
+    #: Training route of ``forward``: True = fused HIP backward (``_NGPTrainFn``: first order, position and parameter
+    #: gradients), False = hash-grid autograd Function + library GEMMs (also differentiable a second time).
+    fused_backward = True
 
     def __init__(self, aabb: Union[torch.Tensor, List[float]], num_dim: int = 3, use_viewdirs: bool = True,
                  density_activation: Callable = lambda x: trunc_exp(x - 1), unbounded: bool = False,
@@ -275,6 +335,9 @@ class NGPRadianceField(_FusedFieldBase):
         assert positions.shape == directions.shape, f"{positions.shape} v.s. {directions.shape}"
         lead = list(positions.shape[:-1])
         if self._recording(positions, directions):
+            if self.fused_backward and self.compute_dtype == "fp32" and not directions.requires_grad:
+                rgb, sigma = _NGPTrainFn.apply(positions, directions, self.mlp_base.params, self.mlp_head.params, self)
+                return rgb.reshape(lead + [3]), sigma.reshape(lead + [1])
             density, feat = self._query_density_train(positions)
             sh = self.direction_encoding((directions.reshape(-1, 3) + 1.0) / 2.0)
             rgb = torch.sigmoid(self.mlp_head(torch.cat([sh, feat], dim=-1)))
