@@ -90,8 +90,37 @@ __global__ void grid_backward_input_kernel(GridArgs ga, const float2 *table, con
 //   dL/dx_e              = sum_l scale_l sum_{d != e} v_d scale_l sum_c (d2 w_c / dfrac_d dfrac_e) g_c,  g_c = dfeat . table[c]
 // (the weights are products of one linear factor per axis: the pure second derivatives vanish, the mixed ones are
 // sign_d sign_e times the third factor).
+// table part of the second order: dL/dtable[c][f] += D_l(c) dfeat_{l,f}, four lanes per (point, level) like
+// grid_backward_table_kernel
+__global__ void grid_double_backward_table_kernel(GridArgs ga, const float *x01, const float *dfeat, const float *v,
+                                                  int64_t n, float *grad_table)
+{
+    const int64_t total = n * QF_MAX_LEVELS * 4;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int sub = (int)(e & 3), cx = sub >> 1, f = sub & 1;
+        const int64_t pl = e >> 2, pt = pl >> 4;
+        const int level = (int)(pl & 15);
+        const float df = dfeat[pt * 32 + 2 * level + f];
+        if (df == 0.0f) continue;
+        const LevelConst lc = level_const(ga, level);
+        uint32_t idx[8];
+        float frac[3];
+        level_indices(lc, x01[pt * 3], x01[pt * 3 + 1], x01[pt * 3 + 2], idx, frac);
+        const float vx = v[pt * 3], vy = v[pt * 3 + 1], vz = v[pt * 3 + 2];
+        const float wx = frac[0], wy = frac[1], wz = frac[2];
+        const float ax = cx ? wx : 1.0f - wx, sx = cx ? 1.0f : -1.0f;
+#pragma unroll
+        for (int yz = 0; yz < 4; ++yz) {
+            const float ay = (yz & 1) ? wy : 1.0f - wy, az = (yz & 2) ? wz : 1.0f - wz;
+            const float sy = (yz & 1) ? 1.0f : -1.0f, sz = (yz & 2) ? 1.0f : -1.0f;
+            const float D = lc.scale * (vx * sx * ay * az + vy * sy * ax * az + vz * sz * ax * ay);
+            atomicAdd(grad_table + 2 * (int64_t)idx[cx | (yz << 1)] + f, D * df);
+        }
+    }
+}
+
 __global__ void grid_double_backward_kernel(GridArgs ga, const float2 *table, const float *x01, const float *dfeat,
-                                            const float *v, int64_t n, float *g_dfeat, float *g_x, float *grad_table)
+                                            const float *v, int64_t n, float *g_dfeat, float *g_x)
 {
     for (int64_t pt = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; pt < n; pt += (int64_t)gridDim.x * blockDim.x) {
         const float x = x01[pt * 3], y = x01[pt * 3 + 1], z = x01[pt * 3 + 2];
@@ -113,10 +142,6 @@ __global__ void grid_double_backward_kernel(GridArgs ga, const float2 *table, co
                 const float D = lc.scale * (vx * sx * ay * az + vy * sy * ax * az + vz * sz * ax * ay);
                 o0 += D * t.x;
                 o1 += D * t.y;
-                if (grad_table && (d0 != 0.0f || d1 != 0.0f)) {
-                    atomicAdd(grad_table + 2 * (int64_t)idx[c], D * d0);
-                    atomicAdd(grad_table + 2 * (int64_t)idx[c] + 1, D * d1);
-                }
                 const float g = d0 * t.x + d1 * t.y;
                 mxy += sx * sy * az * g;
                 mxz += sx * sz * ay * g;
@@ -166,8 +191,15 @@ extern "C" int qf_grid_encode_double_backward(const qf_grid_desc *desc, const fl
     if (rc != QF_OK) return rc;
     if (n == 0) return QF_OK;
     if (!table || !x01 || !dfeat || !v || (!g_dfeat && !g_x01 && !grad_table)) return QF_ERR_INVALID_ARGUMENT;
-    hipLaunchKernelGGL(grid_double_backward_kernel, dim3(qf_grid_1d(n, 256)), dim3(256), 0, qf_stream(stream), ga,
-                       reinterpret_cast<const float2 *>(table), x01, dfeat, v, n, g_dfeat, g_x01, grad_table);
-    QF_LAUNCH_CHECK();
+    if (g_dfeat || g_x01) {
+        hipLaunchKernelGGL(grid_double_backward_kernel, dim3(qf_grid_1d(n, 256)), dim3(256), 0, qf_stream(stream), ga,
+                           reinterpret_cast<const float2 *>(table), x01, dfeat, v, n, g_dfeat, g_x01);
+        QF_LAUNCH_CHECK();
+    }
+    if (grad_table) {
+        hipLaunchKernelGGL(grid_double_backward_table_kernel, dim3(qf_grid_1d(n * 64, 256, 32)), dim3(256), 0,
+                           qf_stream(stream), ga, x01, dfeat, v, n, grad_table);
+        QF_LAUNCH_CHECK();
+    }
     return QF_OK;
 }
