@@ -76,6 +76,8 @@ __global__ __launch_bounds__(64) void bvh_traverse_kernel(const float4 *__restri
                                                           int32_t *__restrict__ hit_tri, float *__restrict__ hit_t,
                                                           int32_t *__restrict__ hit_count, int only_overflowed)
 {
+    // one wave = one 8x8 pixel tile (or 64 consecutive rays); serving fewer rays per wave is slower (8x4: +10 %,
+    // 4x4: +48 %): the traversal is bound by instruction issue, not by the latency of one wave's path
     const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int64_t ray;
     if (image_width > 0) {
@@ -103,28 +105,45 @@ __global__ __launch_bounds__(64) void bvh_traverse_kernel(const float4 *__restri
     int worst_tri = 0x7fffffff, worst_slot = -1;
     float t_limit = INFINITY;
 
+    // "while-while" traversal: the inner loop walks inner nodes only, so the lanes of a wave stay together in it; a
+    // lane that reaches a leaf parks there until the others have one too (or are done), and the triangle tests then
+    // run for all of them at once.  Leaves travel through `cur` and the stack as negative tokens
+    // ~(first * 8 + count - 1) (count <= QF_BVH_LEAF_MAX = 4 <= 8; first < 2^28, checked on the host).
+    constexpr int kDone = (int)0x80000000;
     int stack[kStack];
     int sp = 0;
-    int node = root_is_valid ? 0 : -1;
-    while (node >= 0) {
-        const float4 n0 = nodes[node * 4 + 0];   // c0.lo.xyz, c0.hi.x
-        const float4 n1 = nodes[node * 4 + 1];   // c0.hi.yz, c1.lo.xy
-        const float4 n2 = nodes[node * 4 + 2];   // c1.lo.z, c1.hi.xyz
-        const float4 n3 = nodes[node * 4 + 3];   // child0, child1, count0, count1 (int bits)
-        float tn0, tn1;
-        const bool h0 = box_hit(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, ox, oy, oz, ix, iy, iz, t_limit, &tn0);
-        const bool h1 = box_hit(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, ox, oy, oz, ix, iy, iz, t_limit, &tn1);
-        const int c0 = __float_as_int(n3.x), c1 = __float_as_int(n3.y);
-        const int k0 = __float_as_int(n3.z), k1 = __float_as_int(n3.w);
-        int next = -1;
-#pragma unroll
-        for (int side = 0; side < 2; ++side) {
-            // leaves are tested immediately; inner children are queued near-first
-            const bool hit = side ? h1 : h0;
-            const int child = side ? c1 : c0;
-            const int cnt = side ? k1 : k0;
-            if (!hit || child >= 0) continue;
-            const int first = ~child;
+    int cur = root_is_valid ? 0 : kDone;
+    while (cur != kDone) {
+        while (cur >= 0) {
+            const float4 n0 = nodes[cur * 4 + 0];   // c0.lo.xyz, c0.hi.x
+            const float4 n1 = nodes[cur * 4 + 1];   // c0.hi.yz, c1.lo.xy
+            const float4 n2 = nodes[cur * 4 + 2];   // c1.lo.z, c1.hi.xyz
+            const float4 n3 = nodes[cur * 4 + 3];   // child0, child1, count0, count1 (int bits)
+            float tn0, tn1;
+            const bool h0 = box_hit(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, ox, oy, oz, ix, iy, iz, t_limit, &tn0);
+            const bool h1 = box_hit(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, ox, oy, oz, ix, iy, iz, t_limit, &tn1);
+            const int c0 = __float_as_int(n3.x), c1 = __float_as_int(n3.y);
+            const int k0 = __float_as_int(n3.z), k1 = __float_as_int(n3.w);
+            // tokens: inner child = its index; leaf = ~(first * 8 + count - 1); an empty leaf never passes box_hit
+            const int tok0 = c0 >= 0 ? c0 : ~(((~c0) << 3) | ((k0 - 1) & 7));
+            const int tok1 = c1 >= 0 ? c1 : ~(((~c1) << 3) | ((k1 - 1) & 7));
+            const bool v0 = h0 && (c0 >= 0 || k0 > 0), v1 = h1 && (c1 >= 0 || k1 > 0);
+            if (v0 && v1) {
+                const bool first0 = tn0 <= tn1;
+                cur = first0 ? tok0 : tok1;
+                if (sp < kStack) stack[sp++] = first0 ? tok1 : tok0;
+            } else if (v0) {
+                cur = tok0;
+            } else if (v1) {
+                cur = tok1;
+            } else {
+                cur = sp > 0 ? stack[--sp] : kDone;
+            }
+        }
+        if (cur == kDone) break;
+        {
+            const int packed = ~cur;
+            const int first = packed >> 3, cnt = (packed & 7) + 1;
             for (int k = 0; k < cnt; ++k) {
                 const float4 a = tris[(first + k) * 3 + 0];
                 const float4 b = tris[(first + k) * 3 + 1];
@@ -156,19 +175,7 @@ __global__ __launch_bounds__(64) void bvh_traverse_kernel(const float4 *__restri
                 }
             }
         }
-        const bool in0 = h0 && c0 >= 0, in1 = h1 && c1 >= 0;
-        if (in0 && in1) {
-            const bool first0 = tn0 <= tn1;
-            next = first0 ? c0 : c1;
-            if (sp < kStack) stack[sp++] = first0 ? c1 : c0;
-        } else if (in0) {
-            next = c0;
-        } else if (in1) {
-            next = c1;
-        } else {
-            next = sp > 0 ? stack[--sp] : -1;
-        }
-        node = next;
+        cur = sp > 0 ? stack[--sp] : kDone;
     }
 
     // ascending (t, tri); pad the tail
@@ -822,6 +829,7 @@ static int bvh_launch(const qf_bvh *bvh, const float *rays_o, const float *rays_
                       void *stream)
 {
     if (!bvh || n_rays < 0 || max_hits < 1 || max_hits > kMaxHits || image_width < 0) return QF_ERR_INVALID_ARGUMENT;
+    if (bvh->n_tri >= (1 << 28)) return QF_ERR_UNSUPPORTED;      // leaf tokens of the traversal pack (first, count)
     if (n_rays == 0) return QF_OK;
     if (!rays_o || !rays_d || !hit_tri || !hit_t || !hit_count) return QF_ERR_INVALID_ARGUMENT;
     int height = 0, tiles_x = 0;
