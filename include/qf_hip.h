@@ -151,6 +151,11 @@ int qf_ngp_mlp_backward(const float *enc /* [n,32] */, const float *dirs /* [n,3
  * features [n, 3+7L] (row stride `feat_stride` floats), dirs [n,3] -> rgb [n,3].              */
 int qf_sg_features_to_rgb(const float *features, int64_t feat_stride, const float *dirs,
                           int64_t n, int32_t n_lobes, float *rgb, void *stream);
+/* Its backward (the SG-fitting step, train_fit_sg.py:439-461): d_rgb [n,3] -> d_features (row stride d_stride; the
+ * first 3+7L columns of each row are written).                                                  */
+int qf_sg_features_to_rgb_backward(const float *features, int64_t feat_stride, const float *dirs,
+                                   const float *d_rgb, int64_t n, int32_t n_lobes, float *d_features,
+                                   int64_t d_stride, void *stream);
 
 /* Deformation field: examples/field.py Field.density (:186-203) as used at utils.py:555-566:
  * x01 = (x+scale)/(2 scale); cat[x01, grid(x01)] (35) -> hidden -> hidden -> 1, ReLU, biases.

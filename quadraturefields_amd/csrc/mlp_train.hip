@@ -349,6 +349,56 @@ __global__ __launch_bounds__(kTrainBlock, 1) void ngp_mlp_backward_kernel(const 
     }
 }
 
+// Backward of features_to_rgb (ngp.py:371-393,456-461): rgb = sigmoid(diffuse + sum_l c_l exp(|lambda_l| (a_l/|a_l| . d - 1))).
+// One lane per point; replaces ~20 elementwise torch kernels per lobe in the SG-fitting step (train_fit_sg.py:439-461).
+__global__ void sg_features_to_rgb_backward_kernel(const float *features, int64_t stride, const float *dirs,
+                                                   const float *d_rgb, int64_t n, int n_lobes, float *d_features,
+                                                   int64_t d_stride)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float *f = features + i * stride;
+        float *df = d_features + i * d_stride;
+        const float dx = dirs[i * 3], dy = dirs[i * 3 + 1], dz = dirs[i * 3 + 2];
+        float pre[3] = {f[0], f[1], f[2]};
+        for (int l = 0; l < n_lobes; ++l) {
+            const float *x = f + 3 + 7 * l;
+            const float nrm = sqrtf(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
+            const float dotp = (x[0] / nrm) * dx + (x[1] / nrm) * dy + (x[2] / nrm) * dz;
+            const float e = expf(fabsf(x[3]) * (dotp - 1.0f));
+            pre[0] += x[4] * e;
+            pre[1] += x[5] * e;
+            pre[2] += x[6] * e;
+        }
+        float g[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float sg = sigmoidf(pre[k]);
+            g[k] = d_rgb[i * 3 + k] * sg * (1.0f - sg);
+            df[k] = g[k];
+        }
+        for (int l = 0; l < n_lobes; ++l) {
+            const float *x = f + 3 + 7 * l;
+            float *o = df + 3 + 7 * l;
+            const float nrm = sqrtf(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
+            const float ax = x[0] / nrm, ay = x[1] / nrm, az = x[2] / nrm;
+            const float t = (ax * dx + ay * dy + az * dz) - 1.0f;
+            const float sh = fabsf(x[3]);
+            const float e = expf(sh * t);
+            const float dE = g[0] * x[4] + g[1] * x[5] + g[2] * x[6];
+            o[4] = g[0] * e;
+            o[5] = g[1] * e;
+            o[6] = g[2] * e;
+            const float dEe = dE * e;
+            o[3] = dEe * t * (x[3] > 0.0f ? 1.0f : (x[3] < 0.0f ? -1.0f : 0.0f));      // d|lambda|: 0 at 0, as torch.abs
+            const float dt = dEe * sh;                                                  // d(a_hat . d)
+            const float proj = ax * dx + ay * dy + az * dz;                             // d a_hat = dt * d; d a = (I - a_hat a_hat^T) d a_hat / |a|
+            o[0] = dt * (dx - ax * proj) / nrm;
+            o[1] = dt * (dy - ay * proj) / nrm;
+            o[2] = dt * (dz - az * proj) / nrm;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int qf_ngp_mlp_backward(const float *enc, const float *dirs, const uint8_t *selector, const float *d_rgb,
@@ -374,6 +424,20 @@ extern "C" int qf_ngp_mlp_backward(const float *enc, const float *dirs, const ui
     const int64_t cap = (int64_t)qf_cu_count_cached();
     if (blocks > cap) blocks = cap;
     hipLaunchKernelGGL(ngp_mlp_backward_kernel, dim3((unsigned)blocks), dim3(kTrainBlock), lds_bytes, qf_stream(stream), a);
+    QF_LAUNCH_CHECK();
+    return QF_OK;
+}
+
+extern "C" int qf_sg_features_to_rgb_backward(const float *features, int64_t feat_stride, const float *dirs,
+                                              const float *d_rgb, int64_t n, int32_t n_lobes, float *d_features,
+                                              int64_t d_stride, void *stream)
+{
+    if (n < 0 || n_lobes < 1 || n_lobes > QF_MAX_LOBES || feat_stride < 3 + 7 * n_lobes || d_stride < 3 + 7 * n_lobes)
+        return QF_ERR_INVALID_ARGUMENT;
+    if (n == 0) return QF_OK;
+    if (!features || !dirs || !d_rgb || !d_features) return QF_ERR_INVALID_ARGUMENT;
+    hipLaunchKernelGGL(sg_features_to_rgb_backward_kernel, dim3(qf_grid_1d(n, 256)), dim3(256), 0, qf_stream(stream),
+                       features, feat_stride, dirs, d_rgb, n, (int)n_lobes, d_features, d_stride);
     QF_LAUNCH_CHECK();
     return QF_OK;
 }

@@ -246,6 +246,35 @@ class _FusedFieldBase(nn.Module):
         return density
 
 
+class _SGMixtureFn(torch.autograd.Function):
+    """rgb = sigmoid(diffuse + SG mixture) with HIP forward and backward (gradient w.r.t. the features only; the view
+    directions are data).  Replaces ~20 elementwise torch kernels per lobe in the SG-fitting step."""
+
+    @staticmethod
+    def forward(ctx, features, dirs, n_lobes):
+        features = _C.f32c(features.detach())
+        dirs = _C.f32c(dirs.detach().reshape(-1, 3))
+        n = features.shape[0]
+        rgb = torch.empty((n, 3), dtype=torch.float32, device=features.device)
+        _C.check(_C.lib().qf_sg_features_to_rgb(_C.ptr(features), features.shape[1], _C.ptr(dirs), n, n_lobes, _C.ptr(rgb),
+                                                _C.stream()), "qf_sg_features_to_rgb")
+        ctx.save_for_backward(features, dirs)
+        ctx.n_lobes = n_lobes
+        return rgb
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, d_rgb):
+        features, dirs = ctx.saved_tensors
+        n = features.shape[0]
+        d_features = torch.zeros_like(features)           # columns past 3+7L (if any) get no gradient
+        if n:
+            _C.check(_C.lib().qf_sg_features_to_rgb_backward(
+                _C.ptr(features), features.shape[1], _C.ptr(dirs), _C.ptr(_C.f32c(d_rgb)), n, ctx.n_lobes,
+                _C.ptr(d_features), d_features.shape[1], _C.stream()), "qf_sg_features_to_rgb_backward")
+        return d_features, None, None
+
+
 class _NGPTrainFn(torch.autograd.Function):
     """(rgb, density) of NGPRadianceField with a fused backward: forward = the inference kernel (qf_field_forward),
     backward = grid encode + qf_ngp_mlp_backward (recompute, back-propagate and accumulate both MLPs' weight
@@ -388,6 +417,8 @@ class NGPRadianceFieldSGNew(_FusedFieldBase):
 
     def features_to_rgb(self, features, dir):
         """sigmoid(diffuse + SG mixture), ngp.py:456-461.  features [n, >= 3+7L] (extra columns ignored)."""
+        if torch.is_grad_enabled() and features.requires_grad and not dir.requires_grad:
+            return _SGMixtureFn.apply(features, dir, self.num_g_lobes)
         if torch.is_grad_enabled() and (features.requires_grad or dir.requires_grad):
             dir = dir.reshape(-1, 3)
             rgb = features[:, :3]
