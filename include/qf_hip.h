@@ -146,6 +146,16 @@ int qf_ngp_mlp_backward(const float *enc /* [n,32] */, const float *dirs /* [n,3
                         int64_t n, float *d_enc /* [n,32] */, float *grad_base_w, float *grad_head_w,
                         void *stream);
 
+/* The same for NGPRadianceFieldSGNew (ngp.py:404-470; the SG-fitting step train_fit_sg.py:439-461): base MLP +
+ * BasicDecoder 15 -> 64 -> 64 -> (3+7L) with biases.  d_features [n, >= 3+7L] (row stride d_stride) comes from
+ * qf_sg_features_to_rgb_backward.  grad_head: the six gradient arrays, same shapes as `head` (ACCUMULATED into, like
+ * grad_base_w [3072]).                                                                           */
+int qf_sg_mlp_backward(const float *enc /* [n,32] */, const uint8_t *selector, const float *d_features,
+                       int64_t d_stride, const float *d_sigma, const float *base_w,
+                       const qf_sg_head *head /* host */, int32_t n_lobes, int64_t n, float *d_enc,
+                       float *grad_base_w, const qf_sg_head *grad_head /* host: device pointers, written */,
+                       void *stream);
+
 /* rgb = sigmoid(diffuse + sum_l c_l exp(|lambda_l| (a_l/|a_l| . d - 1))).
  * Replaces NGPRadianceFieldSGNew.features_to_rgb (ngp.py:456-461, discretize=False).
  * features [n, 3+7L] (row stride `feat_stride` floats), dirs [n,3] -> rgb [n,3].              */

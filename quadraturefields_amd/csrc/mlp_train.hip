@@ -349,6 +349,314 @@ __global__ __launch_bounds__(kTrainBlock, 1) void ngp_mlp_backward_kernel(const 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// The same for NGPRadianceFieldSGNew (ngp.py:404-470): base MLP + BasicDecoder 15 -> 64 -> 64 -> (3+7L) with biases.
+// The spherical-Gaussian mixture is differentiated per point by sg_features_to_rgb_backward_kernel; this kernel takes
+// dL/dfeatures [n, 3+7L] and dL/ddensity.  Biases: b1 rides in the constant-1 slot of the first layer's input (as in
+// field_kernel), so its gradient is column 0 of that layer's weight-gradient tile; b2 / bout get theirs from one more
+// tile per output tile whose "activation" is a row of ones.
+constexpr int kSgFwdMfma = 128;      // 48 base + 16 (16 -> 64) + 64 (64 -> 64); the output layer is not recomputed
+constexpr int kSgBwdMfma = 192;      // Wout^T 64, W2^T 64, W1^T 16, base W2^T 16, base W1^T 32
+
+struct SgTrainArgs {
+    const float *enc;
+    const uint8_t *sel;
+    const float *d_feat;
+    int64_t d_stride;
+    const float *d_sigma;
+    const float *base_w;
+    qf_sg_head sg;
+    int32_t n_out, nt_out;
+    int64_t n;
+    float *d_enc, *g_base, *g_w1, *g_b1, *g_w2, *g_b2, *g_wout, *g_bout;
+};
+
+__device__ float sg_fwd_weight(const SgTrainArgs &a, int m, int lane)
+{
+    const int i = lane & 15, kq = lane >> 4;
+    if (m < 32) {
+        const int s = m >> 2, mt = m & 3;
+        return a.base_w[(16 * mt + i) * 32 + 2 * (4 * (s >> 1) + kq) + (s & 1)];
+    }
+    if (m < 48) return a.base_w[2048 + i * 64 + hidden_col(m - 32, kq)];
+    m -= 48;
+    if (m < 16) {
+        const int s = m >> 2, mt = m & 3, row = 16 * mt + i, o = 4 * kq + s;
+        return o == 0 ? a.sg.b1[row] : a.sg.w1[row * 15 + (o - 1)];
+    }
+    const int q = m - 16, s = q >> 2, mt = q & 3;
+    return a.sg.w2[(16 * mt + i) * 64 + hidden_col(s, kq)];
+}
+
+__device__ float sg_bwd_weight(const SgTrainArgs &a, int bm, int lane)
+{
+    const int i = lane & 15, kq = lane >> 4;
+    if (bm < 64) {                        // Wout^T: output tile t outer (4), k-step s (4), mt' inner (4)
+        const int t = bm >> 4, s = (bm >> 2) & 3, mt = bm & 3, row = 16 * t + 4 * kq + s;
+        return row < a.n_out ? a.sg.wout[row * 64 + 16 * mt + i] : 0.0f;
+    }
+    if (bm < 128) {                       // W2^T
+        const int q = bm - 64, s = q >> 2, mt = q & 3;
+        return a.sg.w2[hidden_col(s, kq) * 64 + 16 * mt + i];
+    }
+    if (bm < 144) {                       // W1^T: row i = input slot i ([1 | geo15]); the constant's row is not needed
+        const int s = bm - 128;
+        return i == 0 ? 0.0f : a.sg.w1[hidden_col(s, kq) * 15 + (i - 1)];
+    }
+    if (bm < 160) {
+        const int q = bm - 144, s = q >> 2, mt = q & 3;
+        return a.base_w[2048 + (4 * kq + s) * 64 + 16 * mt + i];
+    }
+    const int q = bm - 160, s = q >> 1, mt = q & 1;
+    return a.base_w[hidden_col(s, kq) * 32 + 16 * mt + i];
+}
+
+__global__ __launch_bounds__(kTrainBlock, 1) void sg_mlp_backward_kernel(const SgTrainArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, p = lane & 15;
+    for (int e = tid; e < kSgFwdMfma * 64; e += kTrainBlock) lds[img_index(e >> 6, e & 63)] = sg_fwd_weight(a, e >> 6, e & 63);
+    float *blds = lds + kSgFwdMfma * 64;
+    for (int e = tid; e < kSgBwdMfma * 64; e += kTrainBlock) blds[img_index(e >> 6, e & 63)] = sg_bwd_weight(a, e >> 6, e & 63);
+    float *b2_lds = blds + kSgBwdMfma * 64;
+    if (tid < 64) b2_lds[tid] = a.sg.b2[tid];
+    volatile float *scratch = b2_lds + 64 + wave * (16 * 17);
+    __syncthreads();
+    const f32x4 *img = reinterpret_cast<const f32x4 *>(lds);
+    const f32x4 *bimg = reinterpret_cast<const f32x4 *>(blds);
+    const f32x4 *b2v = reinterpret_cast<const f32x4 *>(b2_lds);
+
+    const f32x4 zero = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const f32x4 ones_op = p == 0 ? (f32x4){1.f, 1.f, 1.f, 1.f} : zero;     // operand form of "row 0 = 1 for every point"
+    f32x4 aWo[4][4], abo[4], aW2h[4][4], ab2[4], aW1h[4], aW2[4], aW1[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        abo[i] = ab2[i] = aW1h[i] = aW2[i] = zero;
+        aW1[i][0] = aW1[i][1] = zero;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) aWo[i][j] = aW2h[i][j] = zero;
+    }
+
+    const int64_t n_groups = (a.n + 15) >> 4;
+    const int64_t wave_global = (int64_t)blockIdx.x * (kTrainBlock / 64) + wave;
+    const int64_t wave_stride = (int64_t)gridDim.x * (kTrainBlock / 64);
+    for (int64_t grp = wave_global; grp < n_groups; grp += wave_stride) {
+        const int64_t pt_raw = grp * 16 + p;
+        const bool valid = pt_raw < a.n;
+        const int64_t pt = valid ? pt_raw : a.n - 1;
+        int loff = lane, goff = g;
+        asm volatile("" : "+v"(loff), "+v"(goff));
+        const f32x4 *im = img + loff;
+        const f32x4 *bi = bimg + loff;
+
+        // ---------------------------------------------------------------- forward up to the second hidden layer
+        float feat[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) feat[s] = a.enc[pt * 32 + 2 * (4 * (s >> 1) + g) + (s & 1)];
+        f32x4 h[4] = {zero, zero, zero, zero};
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const f32x4 w4 = im[s * 64];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) h[mt] = mfma(w4[mt], feat[s], h[mt]);
+        }
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) h[mt][r] = fmaxf(h[mt][r], 0.0f);
+        f32x4 oa = zero, ob = zero;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 w4 = im[(8 + q) * 64];
+            oa = mfma(w4[0], h[q][0], oa);
+            ob = mfma(w4[1], h[q][1], ob);
+            oa = mfma(w4[2], h[q][2], oa);
+            ob = mfma(w4[3], h[q][3], ob);
+        }
+        const f32x4 base_out = oa + ob;
+        const float density = a.sel[pt] ? expf(base_out[0] - 1.0f) : 0.0f;
+        f32x4 in = base_out;
+        if (g == 0) in[0] = 1.0f;                  // bias slot
+        f32x4 h1[4] = {zero, zero, zero, zero};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const f32x4 w4 = im[(12 + s) * 64];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) h1[mt] = mfma(w4[mt], in[s], h1[mt]);
+        }
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) h1[mt][r] = fmaxf(h1[mt][r], 0.0f);
+        f32x4 h2[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) h2[mt] = b2v[4 * mt + goff];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const f32x4 w4 = im[(16 + s) * 64];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) h2[mt] = mfma(w4[mt], h1[s >> 2][s & 3], h2[mt]);
+        }
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) h2[mt][r] = fmaxf(h2[mt][r], 0.0f);
+
+        // ---------------------------------------------------------------- backward through the decoder
+        f32x4 dzo[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            dzo[t] = zero;
+            if (t < a.nt_out && valid) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int o = 16 * t + 4 * g + r;
+                    if (o < a.n_out) dzo[t][r] = a.d_feat[pt * a.d_stride + o];
+                }
+            }
+        }
+        f32x4 dz2[4] = {zero, zero, zero, zero};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            if (t < a.nt_out) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const f32x4 w4 = bi[(4 * t + s) * 64];
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt) dz2[mt] = mfma(w4[mt], dzo[t][s], dz2[mt]);
+                }
+            }
+        }
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dz2[mt][r] = h2[mt][r] > 0.0f ? dz2[mt][r] : 0.0f;
+        f32x4 dz1[4] = {zero, zero, zero, zero};
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const f32x4 w4 = bi[(16 + s) * 64];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) dz1[mt] = mfma(w4[mt], dz2[s >> 2][s & 3], dz1[mt]);
+        }
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dz1[mt][r] = h1[mt][r] > 0.0f ? dz1[mt][r] : 0.0f;
+        f32x4 da = zero, db = zero;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 w4 = bi[(32 + q) * 64];
+            da = mfma(w4[0], dz1[q][0], da);
+            db = mfma(w4[1], dz1[q][1], db);
+            da = mfma(w4[2], dz1[q][2], da);
+            db = mfma(w4[3], dz1[q][3], db);
+        }
+        f32x4 dout = da + db;                      // d out16 rows 4g + r (row 0: see below)
+        if (g == 0) dout[0] = valid ? a.d_sigma[pt] * density : 0.0f;
+        if (!valid) dout = zero;
+
+        // ---------------------------------------------------------------- decoder weight / bias gradients
+        {
+            f32x4 th[4];
+#pragma unroll
+            for (int ti = 0; ti < 4; ++ti) th[ti] = to_operand(h2[ti], scratch, lane);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                if (t < a.nt_out) {
+                    const f32x4 tz = to_operand(dzo[t], scratch, lane);
+#pragma unroll
+                    for (int ti = 0; ti < 4; ++ti) aWo[t][ti] = outer_acc(tz, th[ti], aWo[t][ti]);
+                    abo[t] = outer_acc(tz, ones_op, abo[t]);
+                }
+            }
+#pragma unroll
+            for (int ti = 0; ti < 4; ++ti) th[ti] = to_operand(h1[ti], scratch, lane);
+#pragma unroll
+            for (int to = 0; to < 4; ++to) {
+                const f32x4 tz = to_operand(dz2[to], scratch, lane);
+#pragma unroll
+                for (int ti = 0; ti < 4; ++ti) aW2h[to][ti] = outer_acc(tz, th[ti], aW2h[to][ti]);
+                ab2[to] = outer_acc(tz, ones_op, ab2[to]);
+            }
+            const f32x4 tin = to_operand(in, scratch, lane);
+#pragma unroll
+            for (int to = 0; to < 4; ++to) aW1h[to] = outer_acc(to_operand(dz1[to], scratch, lane), tin, aW1h[to]);
+        }
+
+        // ---------------------------------------------------------------- base MLP
+        f32x4 dzh[4] = {zero, zero, zero, zero};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const f32x4 w4 = bi[(36 + s) * 64];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) dzh[mt] = mfma(w4[mt], dout[s], dzh[mt]);
+        }
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dzh[mt][r] = h[mt][r] > 0.0f ? dzh[mt][r] : 0.0f;
+        f32x4 de[2] = {zero, zero};
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const f32x4 w4 = bi[(40 + (s >> 1)) * 64];
+            de[0] = mfma(w4[2 * (s & 1) + 0], dzh[s >> 2][s & 3], de[0]);
+            de[1] = mfma(w4[2 * (s & 1) + 1], dzh[s >> 2][s & 3], de[1]);
+        }
+        if (valid) {
+            *reinterpret_cast<f32x4 *>(a.d_enc + pt * 32 + 4 * g) = de[0];
+            *reinterpret_cast<f32x4 *>(a.d_enc + pt * 32 + 16 + 4 * g) = de[1];
+        }
+        {
+            const f32x4 to_ = to_operand(dout, scratch, lane);
+            f32x4 th[4];
+#pragma unroll
+            for (int ti = 0; ti < 4; ++ti) th[ti] = to_operand(h[ti], scratch, lane);
+#pragma unroll
+            for (int ti = 0; ti < 4; ++ti) aW2[ti] = outer_acc(to_, th[ti], aW2[ti]);
+            f32x4 tf[2];
+            tf[0] = to_operand((f32x4){feat[0], feat[1], feat[2], feat[3]}, scratch, lane);
+            tf[1] = to_operand((f32x4){feat[4], feat[5], feat[6], feat[7]}, scratch, lane);
+#pragma unroll
+            for (int to = 0; to < 4; ++to) {
+                const f32x4 tz = to_operand(dzh[to], scratch, lane);
+                aW1[to][0] = outer_acc(tz, tf[0], aW1[to][0]);
+                aW1[to][1] = outer_acc(tz, tf[1], aW1[to][1]);
+            }
+        }
+    }
+
+    // ---- this wave's tiles -> gradient vectors: lane (g,p) register r = d[16 tile + 4g + r][column p of the in-tile]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = 4 * g + r;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int orow = 16 * t + row;
+            if (t < a.nt_out && orow < a.n_out) {
+#pragma unroll
+                for (int ti = 0; ti < 4; ++ti) atomicAdd(a.g_wout + orow * 64 + 16 * ti + p, aWo[t][ti][r]);
+                if (p == 0) atomicAdd(a.g_bout + orow, abo[t][r]);
+            }
+            const int hrow = 16 * t + row;          // t doubles as the tile of a 64-wide layer below
+#pragma unroll
+            for (int ti = 0; ti < 4; ++ti) atomicAdd(a.g_w2 + hrow * 64 + 16 * ti + p, aW2h[t][ti][r]);
+            if (p == 0) {
+                atomicAdd(a.g_b2 + hrow, ab2[t][r]);
+                atomicAdd(a.g_b1 + hrow, aW1h[t][r]);
+            } else {
+                atomicAdd(a.g_w1 + hrow * 15 + (p - 1), aW1h[t][r]);
+            }
+            atomicAdd(a.g_base + 2048 + row * 64 + 16 * t + p, aW2[t][r]);
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                const int s = 4 * tt + (p & 3);
+                atomicAdd(a.g_base + hrow * 32 + 2 * (4 * (s >> 1) + (p >> 2)) + (s & 1), aW1[t][tt][r]);
+            }
+        }
+    }
+}
+
 // Backward of features_to_rgb (ngp.py:371-393,456-461): rgb = sigmoid(diffuse + sum_l c_l exp(|lambda_l| (a_l/|a_l| . d - 1))).
 // One lane per point; replaces ~20 elementwise torch kernels per lobe in the SG-fitting step (train_fit_sg.py:439-461).
 __global__ void sg_features_to_rgb_backward_kernel(const float *features, int64_t stride, const float *dirs,
@@ -438,6 +746,43 @@ extern "C" int qf_sg_features_to_rgb_backward(const float *features, int64_t fea
     if (!features || !dirs || !d_rgb || !d_features) return QF_ERR_INVALID_ARGUMENT;
     hipLaunchKernelGGL(sg_features_to_rgb_backward_kernel, dim3(qf_grid_1d(n, 256)), dim3(256), 0, qf_stream(stream),
                        features, feat_stride, dirs, d_rgb, n, (int)n_lobes, d_features, d_stride);
+    QF_LAUNCH_CHECK();
+    return QF_OK;
+}
+
+extern "C" int qf_sg_mlp_backward(const float *enc, const uint8_t *selector, const float *d_features, int64_t d_stride,
+                                  const float *d_sigma, const float *base_w, const qf_sg_head *head, int32_t n_lobes,
+                                  int64_t n, float *d_enc, float *grad_base_w, const qf_sg_head *grad_head, void *stream)
+{
+    if (n < 0 || n_lobes < 1 || n_lobes > QF_MAX_LOBES || d_stride < 3 + 7 * n_lobes) return QF_ERR_INVALID_ARGUMENT;
+    if (n == 0) return QF_OK;
+    if (!enc || !selector || !d_features || !d_sigma || !base_w || !head || !d_enc || !grad_base_w || !grad_head)
+        return QF_ERR_INVALID_ARGUMENT;
+    if (!head->w1 || !head->b1 || !head->w2 || !head->b2 || !head->wout || !head->bout || !grad_head->w1 || !grad_head->b1 ||
+        !grad_head->w2 || !grad_head->b2 || !grad_head->wout || !grad_head->bout)
+        return QF_ERR_INVALID_ARGUMENT;
+    SgTrainArgs a;
+    a.enc = enc; a.sel = selector; a.d_feat = d_features; a.d_stride = d_stride; a.d_sigma = d_sigma; a.base_w = base_w;
+    a.sg = *head;
+    a.n_out = 3 + 7 * n_lobes;
+    a.nt_out = (a.n_out + 15) / 16;
+    a.n = n;
+    a.d_enc = d_enc; a.g_base = grad_base_w;
+    a.g_w1 = const_cast<float *>(grad_head->w1); a.g_b1 = const_cast<float *>(grad_head->b1);
+    a.g_w2 = const_cast<float *>(grad_head->w2); a.g_b2 = const_cast<float *>(grad_head->b2);
+    a.g_wout = const_cast<float *>(grad_head->wout); a.g_bout = const_cast<float *>(grad_head->bout);
+    const size_t lds_bytes = (size_t)((kSgFwdMfma + kSgBwdMfma) * 64 + 64 + (kTrainBlock / 64) * 16 * 17) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        QF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(sg_mlp_backward_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        attr_set = true;
+    }
+    const int64_t n_groups = (n + 15) / 16;
+    int64_t blocks = qf_div_up(n_groups, kTrainBlock / 64);
+    const int64_t cap = (int64_t)qf_cu_count_cached();
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(sg_mlp_backward_kernel, dim3((unsigned)blocks), dim3(kTrainBlock), lds_bytes, qf_stream(stream), a);
     QF_LAUNCH_CHECK();
     return QF_OK;
 }

@@ -331,6 +331,73 @@ class _NGPTrainFn(torch.autograd.Function):
         return g_pos, None, g_base, (g_head if need_head else None), None
 
 
+class _SGTrainFn(torch.autograd.Function):
+    """(rgb, density) of NGPRadianceFieldSGNew with a fused backward: forward = the inference kernels (features, then
+    the SG mixture), backward = SG-mixture backward + grid encode + qf_sg_mlp_backward + qf_grid_encode_backward."""
+
+    @staticmethod
+    def forward(ctx, positions, directions, base_params, w1, b1, w2, b2, wout, bout, module):
+        xyz = _C.f32c(positions.detach().reshape(-1, 3))
+        dirs = _C.f32c(directions.detach().reshape(-1, 3))
+        n = xyz.shape[0]
+        head = [_C.f32c(t.detach()) for t in (w1, b1, w2, b2, wout, bout)]
+        width = 3 + 7 * module.num_g_lobes + 1
+        _, _, _, feats = module._launch(_C.HEAD_SG_FEATURES, module.num_g_lobes, xyz, None, want_features=width,
+                                        head_sg=head)
+        rgb = torch.empty((n, 3), dtype=torch.float32, device=xyz.device)
+        _C.check(_C.lib().qf_sg_features_to_rgb(_C.ptr(feats), width, _C.ptr(dirs), n, module.num_g_lobes, _C.ptr(rgb),
+                                                _C.stream()), "qf_sg_features_to_rgb")
+        ctx.save_for_backward(xyz, dirs, feats, base_params, *head)
+        ctx.module = module
+        return rgb, feats[:, -1].contiguous()
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, d_rgb, d_sigma):
+        xyz, dirs, feats, base_params, w1, b1, w2, b2, wout, bout = ctx.saved_tensors
+        m = ctx.module
+        n = xyz.shape[0]
+        dev = xyz.device
+        lib = _C.lib()
+        L = m.num_g_lobes
+        width = feats.shape[1]
+        base = base_params.detach()
+        n_net = m.mlp_base.n_network_params
+        net_w, table = base[:n_net].contiguous(), base[n_net:].contiguous()
+        selector, x01 = m.normalize(xyz)
+        x01 = _C.f32c(x01)
+        sel = selector.to(torch.uint8).contiguous()
+        desc = m.mlp_base.grid.desc
+        need_x, need_base = ctx.needs_input_grad[0], ctx.needs_input_grad[2]
+        d_feat = torch.empty((n, 3 + 7 * L), dtype=torch.float32, device=dev)
+        enc = torch.empty((n, 32), dtype=torch.float32, device=dev)
+        d_enc = torch.empty((n, 32), dtype=torch.float32, device=dev)
+        g_net = torch.zeros_like(net_w)
+        grads = [torch.zeros_like(t) for t in (w1, b1, w2, b2, wout, bout)]
+        g_table = torch.zeros_like(table) if need_base else None
+        g_x01 = torch.empty_like(x01) if need_x else None
+        if n:
+            _C.check(lib.qf_sg_features_to_rgb_backward(_C.ptr(feats), width, _C.ptr(dirs), _C.ptr(_C.f32c(d_rgb.reshape(-1, 3))),
+                                                        n, L, _C.ptr(d_feat), d_feat.shape[1], _C.stream()),
+                     "qf_sg_features_to_rgb_backward")
+            _C.check(lib.qf_grid_encode(desc, _C.ptr(table), _C.ptr(x01), n, _C.ptr(enc), _C.stream()), "qf_grid_encode")
+            head = _C.SGHead(*[_C.ptr(t) for t in (w1, b1, w2, b2, wout, bout)])
+            ghead = _C.SGHead(*[_C.ptr(t) for t in grads])
+            _C.check(lib.qf_sg_mlp_backward(_C.ptr(enc), _C.ptr(sel), _C.ptr(d_feat), d_feat.shape[1],
+                                            _C.ptr(_C.f32c(d_sigma.reshape(-1))), _C.ptr(net_w), ctypes.byref(head), L, n,
+                                            _C.ptr(d_enc), _C.ptr(g_net), ctypes.byref(ghead), _C.stream()),
+                     "qf_sg_mlp_backward")
+            if need_base or need_x:
+                _C.check(lib.qf_grid_encode_backward(desc, _C.ptr(table), _C.ptr(x01), _C.ptr(d_enc), n, _C.ptr(g_table),
+                                                     _C.ptr(g_x01), _C.stream()), "qf_grid_encode_backward")
+        g_pos = None
+        if need_x:
+            lo, hi = torch.split(m.aabb, 3, dim=-1)
+            g_pos = g_x01 / (hi - lo)
+        g_base = torch.cat([g_net, g_table]) if need_base else None
+        return (g_pos, None, g_base, *grads, None)
+
+
 class NGPRadianceField(_FusedFieldBase):
     """Instant-NGP radiance field with the SH-degree-4 view-dependent head (ngp.py:657-809)."""
 
@@ -378,6 +445,9 @@ class NGPRadianceField(_FusedFieldBase):
 
 class NGPRadianceFieldSGNew(_FusedFieldBase):
     """Instant-NGP field with the spherical-Gaussian head (ngp.py:284-470)."""
+
+    #: Training route of ``forward``: True = fused HIP backward (``_SGTrainFn``), False = library GEMMs.
+    fused_backward = True
 
     def __init__(self, aabb: Union[torch.Tensor, List[float]], num_dim: int = 3, use_viewdirs: bool = True,
                  density_activation: Callable = lambda x: trunc_exp(x - 1), unbounded: bool = False,
@@ -441,6 +511,12 @@ class NGPRadianceFieldSGNew(_FusedFieldBase):
             raise ValueError("NGPRadianceFieldSGNew.forward needs view directions")
         lead = list(positions.shape[:-1])
         if self._recording(positions, directions):
+            if self.fused_backward and self.compute_dtype == "fp32" and not directions.requires_grad:
+                h = self.mlp_head
+                rgb, sigma = _SGTrainFn.apply(positions, directions, self.mlp_base.params, h.layers[0].weight,
+                                              h.layers[0].bias, h.layers[1].weight, h.layers[1].bias, h.lout.weight,
+                                              h.lout.bias, self)
+                return rgb.reshape(lead + [3]), sigma.reshape(lead + [1])
             f = self.features(positions)
             rgb = self.features_to_rgb(f[:, :-1], directions)
             return rgb.reshape(lead + [3]), f[:, -1:].reshape(lead + [1])

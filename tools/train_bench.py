@@ -32,13 +32,19 @@ def main():
     ap.add_argument("--n", type=int, default=1 << 20)
     ap.add_argument("--log2-t", type=int, default=19)
     ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--head", default="ngp", choices=["ngp", "sg"], help="ngp: SH head (finetune stage); sg: 6-lobe SG head")
     args = ap.parse_args()
     from quadraturefields_amd import _C, synthetic
     from quadraturefields_amd import tinycudann as tcnn
-    from quadraturefields_amd.radiance_fields.ngp import NGPRadianceField
+    from quadraturefields_amd.radiance_fields.ngp import NGPRadianceField, NGPRadianceFieldSGNew
     dev = torch.device("cuda:0")
-    field = NGPRadianceField(aabb=[-1.5] * 3 + [1.5] * 3, log2_hashmap_size=args.log2_t)
-    field.load_state_dict(synthetic.seeded_ngp_state(args.log2_t, field.mlp_base.grid.n_rows), strict=False)
+    if args.head == "sg":
+        field = NGPRadianceFieldSGNew(aabb=[-1.5] * 3 + [1.5] * 3, log2_hashmap_size=args.log2_t, use_viewdirs=False,
+                                      num_g_lobes=6)
+        field.load_state_dict(synthetic.seeded_ngp_state(args.log2_t, field.mlp_base.grid.n_rows, sg_lobes=6), strict=False)
+    else:
+        field = NGPRadianceField(aabb=[-1.5] * 3 + [1.5] * 3, log2_hashmap_size=args.log2_t)
+        field.load_state_dict(synthetic.seeded_ngp_state(args.log2_t, field.mlp_base.grid.n_rows), strict=False)
     field = field.to(dev)
     g = torch.Generator(device="cpu").manual_seed(0)
     x = ((torch.rand(args.n, 3, generator=g) * 2 - 1) * 1.45).to(dev)
@@ -61,7 +67,7 @@ def main():
         with torch.no_grad():
             return field(x, d)
 
-    out = {"n": args.n, "log2_T": args.log2_t}
+    out = {"n": args.n, "log2_T": args.log2_t, "head": args.head}
     out["fused_forward_ms"] = _time(fwd_fused, args.iters)
     out["train_forward_ms"] = _time(fwd_train, args.iters)
     out["train_step_ms"] = _time(step, args.iters)
