@@ -177,6 +177,16 @@ int qf_deform_field_forward(const qf_grid_desc *grid /* host */, const float *ta
                             const float *xyz, int64_t n, const int32_t *order, float *out /* [n] */,
                             void *stream);
 
+/* Backward of the decoder of qf_deform_field_forward, fused (training: the deformation field of
+ * train_finetune.py:387-399 is optimised together with the radiance field).  enc [n,32] = grid encoding of x01 [n,3],
+ * d_out [n] = dL/dfield.  d_enc [n,32] -> qf_grid_encode_backward; d_x01 (optional) = the part of dL/dx01 that enters
+ * through the first layer's three x01 columns.  The six gradient arrays (shapes of w1 [32,35], b1, w2 [32,32], b2,
+ * wout [32], bout [1]) are ACCUMULATED into.                                                    */
+int qf_deform_mlp_backward(const float *enc, const float *x01, const float *d_out, const float *w1,
+                           const float *b1, const float *w2, const float *b2, const float *wout, int64_t n,
+                           float *d_enc, float *d_x01, float *g_w1, float *g_b1, float *g_w2, float *g_b2,
+                           float *g_wout, float *g_bout, void *stream);
+
 /* xyz += (tanh(f)*scaling*(1,1,1) . dir) dir ; ts += same scalar.  utils.py:566-571.          */
 int qf_apply_deformation(const float *f /* [n] */, float scaling, const float *dirs,
                          float *xyz /* in/out [n,3] */, float *ts /* in/out [n] */, int64_t n,

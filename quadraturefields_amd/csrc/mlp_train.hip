@@ -657,6 +657,193 @@ __global__ __launch_bounds__(kTrainBlock, 1) void sg_mlp_backward_kernel(const S
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// The deformation field's decoder (examples/field.py:186-203): cat[x01(3), grid(32)] -> 32 -> 32 -> 1, ReLU, biases.
+// Same scheme; the forward chain is deform_kernel's (field_eval.hip).  dL/dout [n] -> dL/denc [n,32] (and, optionally,
+// the part of dL/dx01 that flows through the three x01 inputs of the first layer), weight and bias gradients.
+constexpr int kDfFwdMfma = 42, kDfBwdMfma = 42;
+
+struct DeformTrainArgs {
+    const float *enc, *x01, *d_out;
+    const float *w1, *b1, *w2, *b2, *wout;
+    int64_t n;
+    float *d_enc, *d_x01;
+    float *g_w1, *g_b1, *g_w2, *g_b2, *g_wout, *g_bout;
+};
+
+__device__ float df_fwd_weight(const DeformTrainArgs &a, int m, int lane)
+{
+    const int i = lane & 15, kq = lane >> 4;
+    if (m < 18) {
+        const int s = m >> 1, mt = m & 1, row = 16 * mt + i;
+        if (s < 8) return a.w1[row * 35 + 3 + 2 * (4 * (s >> 1) + kq) + (s & 1)];
+        return kq < 3 ? a.w1[row * 35 + kq] : a.b1[row];
+    }
+    if (m < 34) {
+        const int q = m - 18, s = q >> 1, mt = q & 1;
+        return a.w2[(16 * mt + i) * 32 + hidden_col(s, kq)];
+    }
+    return 0.0f;                              // the output layer is not recomputed
+}
+
+__device__ float df_bwd_weight(const DeformTrainArgs &a, int bm, int lane)
+{
+    const int i = lane & 15, kq = lane >> 4;
+    if (bm < 2) return kq == 0 ? a.wout[16 * bm + i] : 0.0f;                    // Wout^T, the one k-step that carries row 0
+    if (bm < 18) {                                                             // W2^T
+        const int q = bm - 2, s = q >> 1, mt = q & 1;
+        return a.w2[hidden_col(s, kq) * 32 + 16 * mt + i];
+    }
+    if (bm < 34) {                                                             // W1^T, the 32 grid columns
+        const int q = bm - 18, s = q >> 1, mt = q & 1;
+        return a.w1[hidden_col(s, kq) * 35 + 3 + 16 * mt + i];
+    }
+    const int s = bm - 34;                                                     // W1^T, the 3 x01 columns
+    return i < 3 ? a.w1[hidden_col(s, kq) * 35 + i] : 0.0f;
+}
+
+__global__ __launch_bounds__(kTrainBlock, 1) void deform_mlp_backward_kernel(const DeformTrainArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, p = lane & 15;
+    for (int e = tid; e < kDfFwdMfma * 64; e += kTrainBlock) lds[e] = df_fwd_weight(a, e >> 6, e & 63);
+    float *blds = lds + kDfFwdMfma * 64;
+    for (int e = tid; e < kDfBwdMfma * 64; e += kTrainBlock) blds[e] = df_bwd_weight(a, e >> 6, e & 63);
+    float *bias = blds + kDfBwdMfma * 64;
+    if (tid < 32) bias[tid] = a.b2[tid];
+    volatile float *scratch = bias + 32 + wave * (16 * 17);
+    __syncthreads();
+
+    const f32x4 zero = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const f32x4 ones_op = p == 0 ? (f32x4){1.f, 1.f, 1.f, 1.f} : zero;
+    f32x4 aWo[2] = {zero, zero}, abo = zero, aW2[2][2] = {{zero, zero}, {zero, zero}}, ab2[2] = {zero, zero};
+    f32x4 aW1f[2][2] = {{zero, zero}, {zero, zero}}, aW1x[2] = {zero, zero};
+
+    const int64_t n_groups = (a.n + 15) >> 4;
+    const int64_t wave_global = (int64_t)blockIdx.x * (kTrainBlock / 64) + wave;
+    const int64_t wave_stride = (int64_t)gridDim.x * (kTrainBlock / 64);
+    for (int64_t grp = wave_global; grp < n_groups; grp += wave_stride) {
+        const int64_t pt_raw = grp * 16 + p;
+        const bool valid = pt_raw < a.n;
+        const int64_t pt = valid ? pt_raw : a.n - 1;
+        int loff = lane;
+        asm volatile("" : "+v"(loff));
+        const float *wl = lds + loff;
+        const float *bl = blds + loff;
+
+        float in[9];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) in[s] = a.enc[pt * 32 + 2 * (4 * (s >> 1) + g) + (s & 1)];
+        in[8] = g < 3 ? a.x01[pt * 3 + g] : 1.0f;
+        f32x4 h1[2] = {zero, zero};
+#pragma unroll
+        for (int s = 0; s < 9; ++s)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) h1[mt] = mfma(wl[(2 * s + mt) * 64], in[s], h1[mt]);
+        f32x4 h2[2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { h1[mt][r] = fmaxf(h1[mt][r], 0.0f); h2[mt][r] = bias[16 * mt + 4 * g + r]; }
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) h2[mt] = mfma(wl[(18 + 2 * s + mt) * 64], h1[s >> 2][s & 3], h2[mt]);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) h2[mt][r] = fmaxf(h2[mt][r], 0.0f);
+
+        // ---- backward
+        const float v = (g == 0 && valid) ? a.d_out[pt] : 0.0f;       // row 0 of the 16-row output tile
+        f32x4 dz2[2], dz1[2] = {zero, zero}, de[2] = {zero, zero}, dxt = zero;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            dz2[mt] = mfma(bl[mt * 64], v, zero);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dz2[mt][r] = h2[mt][r] > 0.0f ? dz2[mt][r] : 0.0f;
+        }
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) dz1[mt] = mfma(bl[(2 + 2 * s + mt) * 64], dz2[s >> 2][s & 3], dz1[mt]);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dz1[mt][r] = h1[mt][r] > 0.0f ? dz1[mt][r] : 0.0f;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) de[mt] = mfma(bl[(18 + 2 * s + mt) * 64], dz1[s >> 2][s & 3], de[mt]);
+            dxt = mfma(bl[(34 + s) * 64], dz1[s >> 2][s & 3], dxt);
+        }
+        if (valid) {
+            *reinterpret_cast<f32x4 *>(a.d_enc + pt * 32 + 4 * g) = de[0];
+            *reinterpret_cast<f32x4 *>(a.d_enc + pt * 32 + 16 + 4 * g) = de[1];
+            if (a.d_x01 && g == 0) {
+                a.d_x01[pt * 3 + 0] = dxt[0];
+                a.d_x01[pt * 3 + 1] = dxt[1];
+                a.d_x01[pt * 3 + 2] = dxt[2];
+            }
+        }
+
+        // ---- weight / bias gradients
+        {
+            const f32x4 t3 = to_operand((f32x4){v, 0.f, 0.f, 0.f}, scratch, lane);
+            f32x4 th[2];
+            th[0] = to_operand(h2[0], scratch, lane);
+            th[1] = to_operand(h2[1], scratch, lane);
+            aWo[0] = outer_acc(t3, th[0], aWo[0]);
+            aWo[1] = outer_acc(t3, th[1], aWo[1]);
+            abo = outer_acc(t3, ones_op, abo);
+            th[0] = to_operand(h1[0], scratch, lane);
+            th[1] = to_operand(h1[1], scratch, lane);
+            f32x4 tin[3];
+            tin[0] = to_operand((f32x4){in[0], in[1], in[2], in[3]}, scratch, lane);
+            tin[1] = to_operand((f32x4){in[4], in[5], in[6], in[7]}, scratch, lane);
+            tin[2] = to_operand((f32x4){in[8], 0.f, 0.f, 0.f}, scratch, lane);
+#pragma unroll
+            for (int to = 0; to < 2; ++to) {
+                const f32x4 tz2 = to_operand(dz2[to], scratch, lane);
+                aW2[to][0] = outer_acc(tz2, th[0], aW2[to][0]);
+                aW2[to][1] = outer_acc(tz2, th[1], aW2[to][1]);
+                ab2[to] = outer_acc(tz2, ones_op, ab2[to]);
+                const f32x4 tz1 = to_operand(dz1[to], scratch, lane);
+                aW1f[to][0] = outer_acc(tz1, tin[0], aW1f[to][0]);
+                aW1f[to][1] = outer_acc(tz1, tin[1], aW1f[to][1]);
+                aW1x[to] = outer_acc(tz1, tin[2], aW1x[to]);
+            }
+        }
+    }
+
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = 4 * g + r;
+        if (row == 0) {
+            atomicAdd(a.g_wout + p, aWo[0][r]);
+            atomicAdd(a.g_wout + 16 + p, aWo[1][r]);
+            if (p == 0) atomicAdd(a.g_bout, abo[r]);
+        }
+#pragma unroll
+        for (int to = 0; to < 2; ++to) {
+            const int hrow = 16 * to + row;
+            atomicAdd(a.g_w2 + hrow * 32 + p, aW2[to][0][r]);
+            atomicAdd(a.g_w2 + hrow * 32 + 16 + p, aW2[to][1][r]);
+            if (p == 0) atomicAdd(a.g_b2 + hrow, ab2[to][r]);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int s = 4 * t + (p & 3);
+                atomicAdd(a.g_w1 + hrow * 35 + 3 + 2 * (4 * (s >> 1) + (p >> 2)) + (s & 1), aW1f[to][t][r]);
+            }
+            if ((p & 3) == 0) {
+                if (p < 12) atomicAdd(a.g_w1 + hrow * 35 + (p >> 2), aW1x[to][r]);
+                else atomicAdd(a.g_b1 + hrow, aW1x[to][r]);
+            }
+        }
+    }
+}
+
 // Backward of features_to_rgb (ngp.py:371-393,456-461): rgb = sigmoid(diffuse + sum_l c_l exp(|lambda_l| (a_l/|a_l| . d - 1))).
 // One lane per point; replaces ~20 elementwise torch kernels per lobe in the SG-fitting step (train_fit_sg.py:439-461).
 __global__ void sg_features_to_rgb_backward_kernel(const float *features, int64_t stride, const float *dirs,
@@ -783,6 +970,30 @@ extern "C" int qf_sg_mlp_backward(const float *enc, const uint8_t *selector, con
     const int64_t cap = (int64_t)qf_cu_count_cached();
     if (blocks > cap) blocks = cap;
     hipLaunchKernelGGL(sg_mlp_backward_kernel, dim3((unsigned)blocks), dim3(kTrainBlock), lds_bytes, qf_stream(stream), a);
+    QF_LAUNCH_CHECK();
+    return QF_OK;
+}
+
+extern "C" int qf_deform_mlp_backward(const float *enc, const float *x01, const float *d_out, const float *w1, const float *b1,
+                                      const float *w2, const float *b2, const float *wout, int64_t n, float *d_enc,
+                                      float *d_x01, float *g_w1, float *g_b1, float *g_w2, float *g_b2, float *g_wout,
+                                      float *g_bout, void *stream)
+{
+    if (n < 0) return QF_ERR_INVALID_ARGUMENT;
+    if (n == 0) return QF_OK;
+    if (!enc || !x01 || !d_out || !w1 || !b1 || !w2 || !b2 || !wout || !d_enc || !g_w1 || !g_b1 || !g_w2 || !g_b2 || !g_wout ||
+        !g_bout)
+        return QF_ERR_INVALID_ARGUMENT;
+    DeformTrainArgs a;
+    a.enc = enc; a.x01 = x01; a.d_out = d_out; a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2; a.wout = wout; a.n = n;
+    a.d_enc = d_enc; a.d_x01 = d_x01; a.g_w1 = g_w1; a.g_b1 = g_b1; a.g_w2 = g_w2; a.g_b2 = g_b2; a.g_wout = g_wout;
+    a.g_bout = g_bout;
+    const size_t lds_bytes = (size_t)((kDfFwdMfma + kDfBwdMfma) * 64 + 32 + (kTrainBlock / 64) * 16 * 17) * sizeof(float);
+    const int64_t n_groups = (n + 15) / 16;
+    int64_t blocks = qf_div_up(n_groups, kTrainBlock / 64);
+    const int64_t cap = (int64_t)qf_cu_count_cached() * 2;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(deform_mlp_backward_kernel, dim3((unsigned)blocks), dim3(kTrainBlock), lds_bytes, qf_stream(stream), a);
     QF_LAUNCH_CHECK();
     return QF_OK;
 }

@@ -33,6 +33,43 @@ class BasicDecoder(nn.Module):
         return self.lout(h)
 
 
+class _DeformTrainFn(torch.autograd.Function):
+    """Field.density with a fused backward (first order, parameter gradients only -- the input is data): forward = the
+    inference kernel, backward = grid encode + qf_deform_mlp_backward + qf_grid_encode_backward."""
+
+    @staticmethod
+    def forward(ctx, x, table, w1, b1, w2, b2, wout, bout, module):
+        x = _C.f32c(x.detach().reshape(-1, 3))
+        ctx.save_for_backward(x, table, w1, b1, w2, b2, wout, bout)
+        ctx.module = module
+        return module._density_fused(x, None)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, d_out):
+        x, table, w1, b1, w2, b2, wout, bout = ctx.saved_tensors
+        m = ctx.module
+        n = x.shape[0]
+        dev = x.device
+        lib = _C.lib()
+        table = _C.f32c(table.detach())
+        ws = [_C.f32c(t.detach()) for t in (w1, b1, w2, b2, wout)]
+        grads = [torch.zeros_like(t) for t in (w1, b1, w2, b2, wout, bout)]
+        g_table = torch.zeros_like(table)
+        if n:
+            x01 = _C.f32c((x - m.xyz_min) / (m.xyz_max - m.xyz_min))
+            desc = m.xyz_encoder.grid.desc
+            enc = torch.empty((n, 32), dtype=torch.float32, device=dev)
+            d_enc = torch.empty((n, 32), dtype=torch.float32, device=dev)
+            _C.check(lib.qf_grid_encode(desc, _C.ptr(table), _C.ptr(x01), n, _C.ptr(enc), _C.stream()), "qf_grid_encode")
+            _C.check(lib.qf_deform_mlp_backward(_C.ptr(enc), _C.ptr(x01), _C.ptr(_C.f32c(d_out.reshape(-1))),
+                                                *[_C.ptr(t) for t in ws], n, _C.ptr(d_enc), None,
+                                                *[_C.ptr(t) for t in grads], _C.stream()), "qf_deform_mlp_backward")
+            _C.check(lib.qf_grid_encode_backward(desc, _C.ptr(table), _C.ptr(x01), _C.ptr(d_enc), n, _C.ptr(g_table), None,
+                                                 _C.stream()), "qf_grid_encode_backward")
+        return (None, g_table, *grads, None)
+
+
 class Field(nn.Module):
     def __init__(self, scale, back_prop=0, precision=16, log2_T=19, L=16, max_res=512, output_dim=1, min_res=16,
                  hidden_size=32, num_features=2, nl="elu", bias=True, bias_last=True):
@@ -63,9 +100,20 @@ class Field(nn.Module):
         """[N,3] in [-scale, scale] -> [N,1].  field.py:186-203, one fused launch.  ``order`` (extension): int32
         processing permutation (``RayIntersector.coherent_order``), cache locality only."""
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            if self.fused_backward and not x.requires_grad:
+                d = self.decoder_field       # parameters train, the input is data: fused first-order backward
+                return _DeformTrainFn.apply(x, self.xyz_encoder.params, d.layers[0].weight, d.layers[0].bias,
+                                            d.layers[1].weight, d.layers[1].bias, d.lout.weight, d.lout.bias, self)
             x01 = (x.reshape(-1, 3) - self.xyz_min) / (self.xyz_max - self.xyz_min)
             h = self.xyz_encoder(x01 if self.back_prop else x01.detach())
             return self.decoder_field(torch.cat([x01, h], 1))
+        return self._density_fused(x, order)
+
+    #: Training route of ``density`` when only the parameters want gradients: True = fused HIP backward
+    #: (``_DeformTrainFn``); the input-gradient / second-order route always goes through the hash-grid autograd Function.
+    fused_backward = True
+
+    def _density_fused(self, x, order=None):
         x = _C.f32c(x.reshape(-1, 3))
         n = x.shape[0]
         out = torch.empty((n,), dtype=torch.float32, device=x.device)
