@@ -62,7 +62,8 @@ __device__ float fwd_weight(const TrainArgs &a, int m, int lane)
     return a.head_w[2048 + 4096 + i * 64 + hidden_col(m - 96, kq)];
 }
 
-// A operand of backward MFMA bm: rows = inputs of the layer, k = its outputs (see the plan in qf_hip.h)
+// A operand of backward MFMA bm (a layer's transposed weights): rows = the layer's inputs, k = its outputs, in the
+// register order the chained D layout delivers them
 __device__ float bwd_weight(const TrainArgs &a, int bm, int lane)
 {
     const int i = lane & 15, kq = lane >> 4;
