@@ -148,7 +148,7 @@ def cpu_baseline(mesh, field, cam_o, cam_d, crop=200):
                   f"brute-force intersection over {mesh.faces.shape[0]} triangles {t1 - t0:.1f} s (OpenMP C, "
                   f"{cores} threads) + torch-CPU field/compositing {t2 - t1:.2f} s "
                   f"({n_pts / max(t2 - t1, 1e-9):.0f} points/s)",
-    }, rgb, idx
+    }, rgb, idx, (np.asarray(sample[2]), np.asarray(sample[4]))
 
 
 def main():
@@ -319,8 +319,11 @@ def main():
     }
     if not args.no_cpu_baseline:
         log("cpu baseline (oracle on host cores)")
-        base, rgb_o, idx = cpu_baseline(mesh, field, rays[0][0].cpu(), rays[0][1].cpu())
+        base, rgb_o, idx, (ray_o, tri_o) = cpu_baseline(mesh, field, rays[0][0].cpu(), rays[0][1].cpu())
         rgb0 = stages.frame(rays[0][0], rays[0][1], cameras[0])[0].cpu()[idx]
+        crop = mi.sampling_raytrace_device(rays[0][1][idx.to(device)].contiguous(), rays[0][0][idx.to(device)].contiguous())
+        base["hit_ids_identical"] = bool(np.array_equal(crop[2].cpu().numpy(), ray_o)
+                                         and np.array_equal(crop[4].cpu().numpy(), tri_o))
         base["max_abs_err_vs_hip"] = float((rgb0 - rgb_o).abs().max())
         mse = float(((rgb0.double() - rgb_o.double()) ** 2).mean())
         base["psnr_hip_vs_oracle_db"] = float("inf") if mse == 0 else -10.0 * float(np.log10(mse))
