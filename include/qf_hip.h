@@ -312,6 +312,16 @@ typedef struct qf_camera {
 int qf_raster_intersect(const qf_bvh *bvh, const qf_camera *cam /* host */, const float *rays_o,
                         const float *rays_d, int64_t n_rays, int32_t max_hits, int32_t *hit_tri, float *hit_t,
                         int32_t *hit_count, int32_t *overflow, int32_t sort_lists, void *stream);
+/* The same pass for dense scenes, where most rays meet more than K = max_hits triangles (thin concentric shells):
+ * up to wide_hits >= max_hits candidates per ray are collected in the scratch lists wide_tri / wide_t
+ * ([wide_hits, n_rays], slot-major), then every ray's K nearest under (t, tri) -- the rule of qf_bvh_intersect -- go
+ * to hit_tri / hit_t [n_rays, max_hits] in arrival order (as with sort_lists = 0) and hit_count is clamped to K.
+ * Rays with more than wide_hits candidates keep their raw count (> K) for qf_bvh_repair_overflow; *overflow counts
+ * the candidates beyond wide_hits.                                                                           */
+int qf_raster_intersect_wide(const qf_bvh *bvh, const qf_camera *cam /* host */, const float *rays_o,
+                             const float *rays_d, int64_t n_rays, int32_t max_hits, int32_t wide_hits,
+                             int32_t *wide_tri, float *wide_t, int32_t *hit_tri, float *hit_t, int32_t *hit_count,
+                             int32_t *overflow, void *stream);
 /* The fall-back, per ray: after qf_raster_intersect with sort_lists = 0 (raw counts), re-traverses exactly the rays
  * with hit_count > max_hits through the BVH (exact K nearest; their lists and counts are overwritten, in the layout of
  * qf_bvh_intersect) and leaves every other ray alone.  No host round trip; a frame with a handful of overflowing

@@ -215,7 +215,8 @@ struct RasterCam {
 // vertices carry ~1e-4 px of rounding.  0.25 px leaves two orders of magnitude.
 constexpr float kRasterGuard = 0.25f;
 
-template <int kRasterLanes>
+// kWide: the lists are [slot][ray] (capacity max_hits = the wide capacity), for select_nearest_kernel's coalesced reads.
+template <int kRasterLanes, bool kWide>
 __global__ __launch_bounds__(256) void raster_kernel(const float4 *__restrict__ tris, int64_t n_tri, RasterCam cam,
                                                      const float *__restrict__ rays_o, const float *__restrict__ rays_d,
                                                      int max_hits, int32_t *__restrict__ hit_tri, float *__restrict__ hit_t,
@@ -300,12 +301,71 @@ __global__ __launch_bounds__(256) void raster_kernel(const float4 *__restrict__ 
         if (!mt_hit(a, b, c, ox, oy, oz, dx, dy, dz, &t)) continue;
         const int slot = atomicAdd(&hit_count[ray], 1);
         if (slot < max_hits) {
-            hit_t[ray * max_hits + slot] = t;
-            hit_tri[ray * max_hits + slot] = id;
+            const int64_t at = kWide ? (int64_t)slot * ((int64_t)cam.w * cam.h) + ray : ray * max_hits + slot;
+            hit_t[at] = t;
+            hit_tri[at] = id;
         } else {
             atomicAdd(overflow, 1);      // more than max_hits candidates: the caller re-runs the exact K-nearest BVH path
         }
     }
+}
+
+// Dense scenes (more than K candidates on most rays): the camera-coherent pass collects up to `wide` candidates per
+// ray in [slot][ray] lists, and this kernel keeps each ray's K nearest under (t, tri) -- the rule of
+// bvh_traverse_kernel -- in the ordinary [ray][K] lists (arrival order; qf_pack_samples sorts).  lane = ray, its K
+// running entries in a private LDS column.  Rays that lost candidates even at `wide` keep count > K and go to
+// qf_bvh_repair_overflow.
+constexpr int kSelectBlock = 128;
+__global__ __launch_bounds__(kSelectBlock) void select_nearest_kernel(int64_t n_rays, int wide, int max_hits,
+                                                                      const int32_t *__restrict__ wide_tri,
+                                                                      const float *__restrict__ wide_t,
+                                                                      int32_t *__restrict__ hit_tri, float *__restrict__ hit_t,
+                                                                      int32_t *__restrict__ hit_count)
+{
+    extern __shared__ float select_lds[];
+    float *lt = select_lds + threadIdx.x;                                                  // [max_hits][block]
+    int *li = reinterpret_cast<int *>(select_lds + (size_t)max_hits * kSelectBlock) + threadIdx.x;
+    const int64_t r = (int64_t)blockIdx.x * kSelectBlock + threadIdx.x;
+    if (r >= n_rays) return;
+    const int cnt = hit_count[r];
+    if (cnt > wide) return;
+    float *row_t = hit_t + r * max_hits;
+    int32_t *row_i = hit_tri + r * max_hits;
+    if (cnt <= max_hits) {
+        for (int i = 0; i < cnt; ++i) {
+            row_t[i] = wide_t[(int64_t)i * n_rays + r];
+            row_i[i] = wide_tri[(int64_t)i * n_rays + r];
+        }
+        return;
+    }
+    float worst_t = -INFINITY;
+    int worst_i = -1, worst_slot = 0;
+    for (int i = 0; i < max_hits; ++i) {
+        const float t = wide_t[(int64_t)i * n_rays + r];
+        const int id = wide_tri[(int64_t)i * n_rays + r];
+        lt[i * kSelectBlock] = t;
+        li[i * kSelectBlock] = id;
+        if (hit_less(worst_t, worst_i, t, id)) { worst_t = t; worst_i = id; worst_slot = i; }
+    }
+    for (int i = max_hits; i < cnt; ++i) {
+        const float t = wide_t[(int64_t)i * n_rays + r];
+        const int id = wide_tri[(int64_t)i * n_rays + r];
+        if (!hit_less(t, id, worst_t, worst_i)) continue;
+        lt[worst_slot * kSelectBlock] = t;
+        li[worst_slot * kSelectBlock] = id;
+        worst_t = -INFINITY;
+        worst_i = -1;
+        for (int s = 0; s < max_hits; ++s) {
+            const float ts = lt[s * kSelectBlock];
+            const int is = li[s * kSelectBlock];
+            if (hit_less(worst_t, worst_i, ts, is)) { worst_t = ts; worst_i = is; worst_slot = s; }
+        }
+    }
+    for (int i = 0; i < max_hits; ++i) {
+        row_t[i] = lt[i * kSelectBlock];
+        row_i[i] = li[i * kSelectBlock];
+    }
+    hit_count[r] = max_hits;
 }
 
 // In-place ascending (t, tri) sort of every ray's (unordered) list, padding and count clamp.
@@ -973,15 +1033,10 @@ extern "C" int qf_texture_shade_packed(const uint8_t *records, int32_t texture_s
     return QF_OK;
 }
 
-extern "C" int qf_raster_intersect(const qf_bvh *bvh, const qf_camera *cam, const float *rays_o, const float *rays_d,
-                                   int64_t n_rays, int32_t max_hits, int32_t *hit_tri, float *hit_t, int32_t *hit_count,
-                                   int32_t *overflow, int32_t sort_lists, void *stream)
+static int raster_launch(const qf_bvh *bvh, const qf_camera *cam, const float *rays_o, const float *rays_d, int64_t n_rays,
+                         int capacity, bool wide, int32_t *hit_tri, float *hit_t, int32_t *hit_count, int32_t *overflow,
+                         hipStream_t st)
 {
-    if (!bvh || !cam || n_rays < 0 || max_hits < 1 || max_hits > kMaxHits) return QF_ERR_INVALID_ARGUMENT;
-    if (cam->width < 1 || cam->height < 1 || (int64_t)cam->width * cam->height != n_rays) return QF_ERR_INVALID_ARGUMENT;
-    if (!(cam->fx > 0.0f) || !(cam->fy > 0.0f)) return QF_ERR_INVALID_ARGUMENT;
-    if (!rays_o || !rays_d || !hit_tri || !hit_t || !hit_count || !overflow) return QF_ERR_INVALID_ARGUMENT;
-    hipStream_t st = qf_stream(stream);
     QF_HIP_TRY(hipMemsetAsync(hit_count, 0, (size_t)n_rays * sizeof(int32_t), st));
     QF_HIP_TRY(hipMemsetAsync(overflow, 0, sizeof(int32_t), st));
     RasterCam rc;
@@ -1002,22 +1057,70 @@ extern "C" int qf_raster_intersect(const qf_bvh *bvh, const qf_camera *cam, cons
         const int64_t threads = bvh->n_tri * lanes;
         const int64_t blocks = qf_div_up(threads, 256);
         if (blocks > 0x7fffffff) return QF_ERR_UNSUPPORTED;
-#define QF_RASTER_LAUNCH(L)                                                                                           \
-    hipLaunchKernelGGL(raster_kernel<L>, dim3((unsigned)blocks), dim3(256), 0, st,                                   \
-                       reinterpret_cast<const float4 *>(bvh->d_tris), bvh->n_tri, rc, rays_o, rays_d, (int)max_hits, \
+#define QF_RASTER_LAUNCH(L, WIDE)                                                                                     \
+    hipLaunchKernelGGL((raster_kernel<L, WIDE>), dim3((unsigned)blocks), dim3(256), 0, st,                           \
+                       reinterpret_cast<const float4 *>(bvh->d_tris), bvh->n_tri, rc, rays_o, rays_d, capacity,      \
                        hit_tri, hit_t, hit_count, overflow)
-        switch (lanes) {
-        case 16: QF_RASTER_LAUNCH(16); break;
-        case 8: QF_RASTER_LAUNCH(8); break;
-        default: QF_RASTER_LAUNCH(4); break;
+        if (wide) {
+            switch (lanes) {
+            case 16: QF_RASTER_LAUNCH(16, true); break;
+            case 8: QF_RASTER_LAUNCH(8, true); break;
+            default: QF_RASTER_LAUNCH(4, true); break;
+            }
+        } else {
+            switch (lanes) {
+            case 16: QF_RASTER_LAUNCH(16, false); break;
+            case 8: QF_RASTER_LAUNCH(8, false); break;
+            default: QF_RASTER_LAUNCH(4, false); break;
+            }
         }
+#undef QF_RASTER_LAUNCH
         QF_LAUNCH_CHECK();
     }
+    return QF_OK;
+}
+
+static bool raster_args_ok(const qf_bvh *bvh, const qf_camera *cam, int64_t n_rays, int32_t max_hits)
+{
+    if (!bvh || !cam || n_rays < 0 || max_hits < 1 || max_hits > kMaxHits) return false;
+    if (cam->width < 1 || cam->height < 1 || (int64_t)cam->width * cam->height != n_rays) return false;
+    return cam->fx > 0.0f && cam->fy > 0.0f;
+}
+
+extern "C" int qf_raster_intersect(const qf_bvh *bvh, const qf_camera *cam, const float *rays_o, const float *rays_d,
+                                   int64_t n_rays, int32_t max_hits, int32_t *hit_tri, float *hit_t, int32_t *hit_count,
+                                   int32_t *overflow, int32_t sort_lists, void *stream)
+{
+    if (!raster_args_ok(bvh, cam, n_rays, max_hits)) return QF_ERR_INVALID_ARGUMENT;
+    if (!rays_o || !rays_d || !hit_tri || !hit_t || !hit_count || !overflow) return QF_ERR_INVALID_ARGUMENT;
+    hipStream_t st = qf_stream(stream);
+    const int rc = raster_launch(bvh, cam, rays_o, rays_d, n_rays, (int)max_hits, false, hit_tri, hit_t, hit_count, overflow, st);
+    if (rc != QF_OK) return rc;
     if (sort_lists) {
         hipLaunchKernelGGL(sort_hits_kernel, dim3(qf_grid_1d(n_rays, 256)), dim3(256), 0, st, n_rays, (int)max_hits,
                            hit_tri, hit_t, hit_count);
         QF_LAUNCH_CHECK();
     }
+    return QF_OK;
+}
+
+extern "C" int qf_raster_intersect_wide(const qf_bvh *bvh, const qf_camera *cam, const float *rays_o, const float *rays_d,
+                                        int64_t n_rays, int32_t max_hits, int32_t wide_hits, int32_t *wide_tri,
+                                        float *wide_t, int32_t *hit_tri, float *hit_t, int32_t *hit_count,
+                                        int32_t *overflow, void *stream)
+{
+    if (!raster_args_ok(bvh, cam, n_rays, max_hits)) return QF_ERR_INVALID_ARGUMENT;
+    if (wide_hits < max_hits || wide_hits > 4096) return QF_ERR_INVALID_ARGUMENT;
+    if (!rays_o || !rays_d || !wide_tri || !wide_t || !hit_tri || !hit_t || !hit_count || !overflow)
+        return QF_ERR_INVALID_ARGUMENT;
+    hipStream_t st = qf_stream(stream);
+    const int rc = raster_launch(bvh, cam, rays_o, rays_d, n_rays, (int)wide_hits, true, wide_tri, wide_t, hit_count, overflow, st);
+    if (rc != QF_OK) return rc;
+    if (n_rays == 0) return QF_OK;
+    const size_t lds = (size_t)max_hits * kSelectBlock * 2 * sizeof(float);       // <= 64 KB at K = 64
+    hipLaunchKernelGGL(select_nearest_kernel, dim3((unsigned)qf_div_up(n_rays, kSelectBlock)), dim3(kSelectBlock), lds, st,
+                       n_rays, (int)wide_hits, (int)max_hits, wide_tri, wide_t, hit_tri, hit_t, hit_count);
+    QF_LAUNCH_CHECK();
     return QF_OK;
 }
 

@@ -51,6 +51,8 @@ class RayIntersector:
         self.repaired_frames = 0         # frames on which some pixels overflowed K and were repaired through the BVH
         self._raster_streak = 0          # consecutive camera-coherent attempts that overflowed (see want_raster)
         self._raster_trying = False
+        self.raster_wide = 0             # > 0: the camera-coherent pass keeps this many candidates per ray (dense scenes)
+        self._wide_scratch = {}
         self._scratch = {}               # per-ray-count frame scratch, see _frame_scratch
         self.last_layout = None          # (inverse, xyz, dirs) of the most recent image-shaped pack, in the coherent order
         self._handle = ctypes.c_void_p()
@@ -106,6 +108,12 @@ class RayIntersector:
         self._raster_trying = False
         self._raster_streak += 1
         self._raster_backoff = min(self.RASTER_BACKOFF_MAX, 1 << min(self._raster_streak - 1, 30))
+
+    #: Dense scenes: when more than 5 % of a frame's candidates are beyond K, the following frames run the
+    #: camera-coherent pass with this many slots per ray (times K, at most RASTER_WIDE_MAX) and select the K nearest on
+    #: the device (qf_raster_intersect_wide) instead of leaving most of the image to the BVH.
+    RASTER_WIDE_FACTOR = 4
+    RASTER_WIDE_MAX = 128
 
     def _alloc_hits(self, n, k):
         return (torch.empty((n, k), dtype=torch.int32, device=self.device),
@@ -179,9 +187,22 @@ class RayIntersector:
         buf = self._frame_scratch(n)[0]
         hit_tri, hit_t, hit_count = self._alloc_hits(n, k)
         overflow = buf[n + 1:].view(torch.int32)[:1]           # low word of buf[n+1]; the high word stays zero
-        _C.check(_C.lib().qf_raster_intersect(self._handle, ctypes.byref(camera), _C.ptr(o), _C.ptr(d), n, k,
-                                              _C.ptr(hit_tri), _C.ptr(hit_t), _C.ptr(hit_count), _C.ptr(overflow),
-                                              0, _C.stream()), "qf_raster_intersect")
+        wide = max(int(self.raster_wide), 0)
+        if wide > k:
+            key = (n, wide, torch.cuda.current_stream().cuda_stream)
+            lists = self._wide_scratch.get(key)
+            if lists is None:
+                self._wide_scratch.clear()
+                lists = self._wide_scratch[key] = (torch.empty((wide, n), dtype=torch.int32, device=self.device),
+                                                   torch.empty((wide, n), dtype=torch.float32, device=self.device))
+            _C.check(_C.lib().qf_raster_intersect_wide(self._handle, ctypes.byref(camera), _C.ptr(o), _C.ptr(d), n, k, wide,
+                                                       _C.ptr(lists[0]), _C.ptr(lists[1]), _C.ptr(hit_tri), _C.ptr(hit_t),
+                                                       _C.ptr(hit_count), _C.ptr(overflow), _C.stream()),
+                     "qf_raster_intersect_wide")
+        else:
+            _C.check(_C.lib().qf_raster_intersect(self._handle, ctypes.byref(camera), _C.ptr(o), _C.ptr(d), n, k,
+                                                  _C.ptr(hit_tri), _C.ptr(hit_t), _C.ptr(hit_count), _C.ptr(overflow),
+                                                  0, _C.stream()), "qf_raster_intersect")
         # pixels that collected more than K candidates: exact K nearest through the BVH, those rays only, no host
         # round trip (afterwards every count is <= K)
         _C.check(_C.lib().qf_bvh_repair_overflow(self._handle, _C.ptr(o), _C.ptr(d), n, k, int(camera.width),
@@ -247,8 +268,12 @@ class RayIntersector:
         total, ovf = int(host[0]), int(host[1])
         if ovf:                                # already repaired on the device (qf_bvh_repair_overflow); policy only
             self.repaired_frames += 1
-            if ovf > 0.05 * o.shape[0]:        # most of the image overflows (dense shells): the camera-coherent pass is wasted
-                self.raster_overflowed()
+            if ovf > 0.05 * o.shape[0]:        # much of the image overflows (dense shells)
+                wide = min(self.RASTER_WIDE_FACTOR * k, self.RASTER_WIDE_MAX)
+                if self.raster_wide < wide and wide > k:
+                    self.raster_wide = wide    # from the next frame on: wide candidate lists + K-nearest selection
+                else:
+                    self.raster_overflowed()   # even the wide lists overflow: the camera-coherent pass is wasted
         self.last_layout = None
         if total == 0:
             return None, None

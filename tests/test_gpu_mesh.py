@@ -200,6 +200,7 @@ def test_raster_intersector_identical_to_bvh(device, w, h, max_hits):
     from quadraturefields_amd.mesh_utils import RayIntersector, make_camera
     mesh = _scene(3, 4)
     ri = RayIntersector(mesh, max_hits=max_hits)
+    ri.RASTER_WIDE_FACTOR = 1                                  # this test is about the plain pass and its BVH repair
     for seed in (0, 7):
         c2w = synthetic.orbit_cameras(1, seed=seed)[0]
         focal = synthetic.lego_focal(800) * w / 800.0
@@ -238,6 +239,40 @@ def test_raster_intersector_identical_to_bvh(device, w, h, max_hits):
     b = ri.hits(o, d, camera=make_camera(c2w, focal, w, h))
     for x, y in zip(a[:3], b[:3]):
         assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize("wide", [24, 7, 0])
+def test_wide_raster_selects_the_k_nearest_like_the_bvh(device, wide):
+    """Dense shells (most rays meet more than K triangles): qf_raster_intersect_wide keeps the K nearest of up to `wide`
+    candidates; rays beyond `wide` (wide = 7) are repaired through the BVH; wide = 0: the policy switches it on by itself
+    after the first heavily overflowing frame.  Packed samples identical to the BVH path every time."""
+    from quadraturefields_amd import synthetic
+    from quadraturefields_amd.mesh_utils import RayIntersector, make_camera
+    mesh = _scene(3, 8)
+    k, w, h = 5, 72, 56
+    ri = RayIntersector(mesh, max_hits=k)
+    ri.raster_wide = wide
+    brute = om.BruteForceIntersector(mesh.vertices, mesh.faces)
+    for seed in (1, 5, 9):
+        c2w = synthetic.orbit_cameras(1, seed=seed)[0]
+        focal = synthetic.lego_focal(800) * w / 800.0
+        o, d = synthetic.camera_rays(c2w, focal, w, h)
+        cam = make_camera(c2w, focal, w, h)
+        s1 = ri.sample_device(o, d, image_width=w)
+        ri._raster_backoff = 0
+        s2 = ri.sample_device(o, d, camera=cam)
+        for x, y in zip(s1, s2):
+            assert torch.equal(x, y)
+        counts = brute.hits(o.numpy(), d.numpy(), 64)[2]
+        assert (counts > k).mean() > 0.05 and counts.max() > 7          # the scene does what the test is about
+        tri_o, _, cnt_o = brute.hits(o.numpy(), d.numpy(), k)
+        keep = np.arange(k)[None, :] < cnt_o[:, None]
+        want = np.sort((np.arange(w * h)[:, None] * (1 << 20) + tri_o)[keep])
+        assert np.array_equal(np.sort(s2[2].cpu().numpy() * (1 << 20) + s2[4].cpu().numpy()), want)
+    if wide == 0:
+        assert ri.raster_wide == 4 * k and ri._raster_streak == 0       # switched on, never backed off to the BVH
+    if wide == 7:
+        assert ri._raster_streak > 0 or ri.repaired_frames > 0
 
 
 def test_coherent_order_is_the_tile_rank_pixel_permutation(device):

@@ -13,6 +13,7 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
+import numpy as np
 import torch
 
 import bench
@@ -62,6 +63,8 @@ def main():
         "triangles": int(mesh.faces.shape[0]), "rays_per_frame": n_rays, "rays_per_s": n_rays * args.steps / el,
         "ms_per_frame": el / args.steps * 1e3, "points_per_frame": pts / args.steps,
         "mean_hits_per_ray": pts / args.steps / n_rays, "stage_ms": ms,
+        "stage_ms_median": stages.stage_ms(np.median), "stage_ms_max": stages.stage_ms(np.max),
+        "raster_wide": int(mi.rayintersector.raster_wide),
         "field_points_per_s_in_kernel": pts / args.steps / (ms["field"] * 1e-3),
         "intersector": args.intersector, "bvh_fallback_frames": getattr(stages, "fallbacks", 0)}))
 
