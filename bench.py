@@ -317,7 +317,7 @@ def main():
             "avg_launch_ms": ms["field"],
         },
     }
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:      # rank 0 at N = 1 only
         log("cpu baseline (oracle on host cores)")
         base, rgb_o, idx, (ray_o, tri_o) = cpu_baseline(mesh, field, rays[0][0].cpu(), rays[0][1].cpu())
         rgb0 = stages.frame(rays[0][0], rays[0][1], cameras[0])[0].cpu()[idx]
