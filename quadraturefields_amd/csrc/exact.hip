@@ -315,7 +315,7 @@ __global__ __launch_bounds__(256) void raster_kernel(const float4 *__restrict__ 
 // bvh_traverse_kernel -- in the ordinary [ray][K] lists (arrival order; qf_pack_samples sorts).  lane = ray, its K
 // running entries in a private LDS column.  Rays that lost candidates even at `wide` keep count > K and go to
 // qf_bvh_repair_overflow.
-constexpr int kSelectBlock = 128;
+constexpr int kSelectBlock = 64;     // one wave: K = 64 needs 32 KB of LDS
 __global__ __launch_bounds__(kSelectBlock) void select_nearest_kernel(int64_t n_rays, int wide, int max_hits,
                                                                       const int32_t *__restrict__ wide_tri,
                                                                       const float *__restrict__ wide_t,
@@ -1117,7 +1117,7 @@ extern "C" int qf_raster_intersect_wide(const qf_bvh *bvh, const qf_camera *cam,
     const int rc = raster_launch(bvh, cam, rays_o, rays_d, n_rays, (int)wide_hits, true, wide_tri, wide_t, hit_count, overflow, st);
     if (rc != QF_OK) return rc;
     if (n_rays == 0) return QF_OK;
-    const size_t lds = (size_t)max_hits * kSelectBlock * 2 * sizeof(float);       // <= 64 KB at K = 64
+    const size_t lds = (size_t)max_hits * kSelectBlock * 2 * sizeof(float);       // <= 32 KB at K = 64
     hipLaunchKernelGGL(select_nearest_kernel, dim3((unsigned)qf_div_up(n_rays, kSelectBlock)), dim3(kSelectBlock), lds, st,
                        n_rays, (int)wide_hits, (int)max_hits, wide_tri, wide_t, hit_tri, hit_t, hit_count);
     QF_LAUNCH_CHECK();
