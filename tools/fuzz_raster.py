@@ -1,6 +1,8 @@
 """Fuzz of the camera-coherent intersector against the BVH traversal: random meshes (shell counts, subdivisions, scale),
 random cameras (orbit radius 0.05..8, focal 0.2x..8x, off-centre principal points, non-square images, tilted).
-Exits non-zero on the first mismatch.   python tools/fuzz_raster.py --cases 200"""
+Exits non-zero on the first mismatch.   python tools/fuzz_raster.py --cases 200
+--dense: K = 2..6 with wide candidate lists of K+1..16 slots (qf_raster_intersect_wide + K-nearest selection + per-ray
+BVH repair), compared as packed samples against the BVH path."""
 import argparse
 import os
 import sys
@@ -15,6 +17,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=200)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--dense", action="store_true")
     args = ap.parse_args()
     from quadraturefields_amd import _C, synthetic
     from quadraturefields_amd.mesh_utils import RayIntersector
@@ -47,6 +50,16 @@ def main():
         o = torch.empty((w * h, 3), device=dev)
         d = torch.empty((w * h, 3), device=dev)
         _C.check(_C.lib().qf_generate_rays(cam, 1, _C.ptr(o), _C.ptr(d), _C.stream()), "gen")
+        if args.dense:
+            k = int(rng.integers(2, 7))
+            ri.raster_wide, ri._raster_backoff = int(rng.integers(k + 1, 17)), 0
+            a = ri.sample_device(o, d, k, camera=cam)
+            b = ri.sample_device(o, d, k, image_width=w)
+            if (a is None) != (b is None) or (a is not None and not all(torch.equal(x, y) for x, y in zip(a, b))):
+                print(f"MISMATCH case {case}: mesh {key} image {w}x{h} focal {focal:.1f} K {k} wide {ri.raster_wide}")
+                sys.exit(1)
+            compared += 1
+            continue
         tri_r, t_r, cnt_r, ovf = ri._hits_raster(o, d, 25, cam)
         if int(ovf.item()):
             skipped += 1
