@@ -231,10 +231,12 @@ def main():
 
     # Device spin-up (untimed, before the W warm-up steps): the scene build leaves the GPU idle for seconds and its
     # clocks take tens of milliseconds of sustained work to come back -- longer than the whole default timed region.
-    t_spin = time.perf_counter()
-    while time.perf_counter() - t_spin < args.spin_up:
-        stages.frame(rays[0][0], rays[0][1], cameras[0])
+    t_spin, i_spin = time.perf_counter(), 0
+    while time.perf_counter() - t_spin < args.spin_up:      # cycling through the cameras, so that a profiler's
+        i = i_spin % n_frames                               # per-kernel averages see the timed region's frame mix
+        stages.frame(rays[i][0], rays[i][1], cameras[i])
         torch.cuda.synchronize()
+        i_spin += 1
     run(0, args.warmup, False)
     torch.cuda.synchronize()
     log(f"{args.warmup} warmup frames done")

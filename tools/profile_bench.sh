@@ -17,3 +17,8 @@ done
 python3 $R/tools/traffic_json.py $D > $D/field_traffic.json
 cat $D/field_traffic.json
 rm -rf $D/trace/*/*kernel_trace.csv
+# config 3 (dense shells, wide candidate lists): kernel stats only
+mkdir -p $D/config3
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $D/config3/trace -- python3 $R/tools/config3_bench.py --steps 10 --warmup 4 > $D/config3/bench.json 2> $D/config3/bench.err || echo "config3 pass failed"
+cp $(find $D/config3/trace -name "*kernel_stats.csv" | head -1) $D/config3/kernel_stats.csv
+rm -rf $D/config3/trace
