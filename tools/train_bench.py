@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--log2-t", type=int, default=19)
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--head", default="ngp", choices=["ngp", "sg"], help="ngp: SH head (finetune stage); sg: 6-lobe SG head")
+    ap.add_argument("--sorted", action="store_true", help="points in Morton order (spatially coherent batches)")
     args = ap.parse_args()
     from quadraturefields_amd import _C, synthetic
     from quadraturefields_amd import tinycudann as tcnn
@@ -48,6 +49,15 @@ def main():
     field = field.to(dev)
     g = torch.Generator(device="cpu").manual_seed(0)
     x = ((torch.rand(args.n, 3, generator=g) * 2 - 1) * 1.45).to(dev)
+    if args.sorted:
+        q = ((x + 1.5) / 3.0 * 1023).long().clamp(0, 1023)
+
+        def spread(v):
+            v = (v | (v << 16)) & 0x030000FF
+            v = (v | (v << 8)) & 0x0300F00F
+            v = (v | (v << 4)) & 0x030C30C3
+            return (v | (v << 2)) & 0x09249249
+        x = x[torch.argsort(spread(q[:, 0]) | (spread(q[:, 1]) << 1) | (spread(q[:, 2]) << 2))].contiguous()
     d = torch.nn.functional.normalize(torch.randn(args.n, 3, generator=g), dim=-1).to(dev)
     target = torch.rand(args.n, 3, generator=g).to(dev)
     opt = torch.optim.Adam(field.parameters(), lr=1e-3, eps=1e-15)
@@ -67,7 +77,7 @@ def main():
         with torch.no_grad():
             return field(x, d)
 
-    out = {"n": args.n, "log2_T": args.log2_t, "head": args.head}
+    out = {"n": args.n, "log2_T": args.log2_t, "head": args.head, "sorted": args.sorted}
     out["fused_forward_ms"] = _time(fwd_fused, args.iters)
     out["train_forward_ms"] = _time(fwd_train, args.iters)
     out["train_step_ms"] = _time(step, args.iters)
