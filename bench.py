@@ -2,11 +2,21 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-One step = one full 800x800 frame through the hot path on synthetic inputs already resident in HBM:
-BVH multi-hit traversal -> sample packing -> fused field evaluation (fp32 hash grid + MLPs) -> per-ray
-compositing.  N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL): every rank renders its own
-frame (weak scaling, no collective on the data path) and the finished tiles are exchanged with one
-all_gather_into_tensor per step.  Rank 0 prints ONE JSON line.
+One step = one full 800x800 frame per rank through the hot path on synthetic inputs already resident in HBM:
+ray/mesh intersection (camera-coherent pass, exact BVH traversal as its fallback) -> sample packing -> fused field
+evaluation (fp32 hash grid + MLPs) -> per-ray compositing.  N > 1 (launched by torch.distributed.run, one rank per
+GPU, RCCL):
+
+* ``value`` (weak scaling): the frames of an evaluation run are dealt to the ranks, one frame per rank per step, and
+  every finished frame is exchanged with one all_gather_into_tensor (every rank ends up with every frame);
+* ``sharded_frame`` (BASELINE configs[3]): ONE frame at a time, cut into cost-balanced row bands over the N ranks
+  (quadraturefields_amd/parallel.py), each band rendered through the same HIP kernels and the bands gathered with one
+  all_gather_into_tensor per frame; looped over eight seeded scenes.  Reported as latency (host waits for every frame)
+  and as pipelined throughput, next to the same loop's 1-rank figure when N = 1.
+
+At N = 1 rank 0 also appends ``configs``: BASELINE configs[2] (1080p, bf16, T = 2^21, dense shells) and configs[4]
+(baked SG textures 4096^2, L = 6), each with the roofline of its own dominant kernel measured with HIP events, and
+the ``cpu_baseline`` (the oracle on the host cores).  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -28,6 +38,7 @@ N_SHELLS, SUBDIV = 12, 6           # 12 x 81,920 = 983,040 triangles
 STEP = 5e-3
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 ALG_BYTES_PER_POINT = 16 * 8 * 2 * 4   # 16 levels x 8 corners x 2 features x 4 B
+PROFILE_ROUND = "r2"
 
 
 def log(msg):
@@ -35,15 +46,18 @@ def log(msg):
         print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
-def build_scene(device, seed=42):
+def build_scene(device, seed=42, n_shells=None, subdiv=None, log2_t=None):
     from quadraturefields_amd import synthetic
     from quadraturefields_amd.mesh_utils import MeshIntersection
     from quadraturefields_amd.radiance_fields.ngp import NGPRadianceField
-    mesh = synthetic.shell_mesh(n_shells=N_SHELLS, subdivisions=SUBDIV, seed=seed)
+    n_shells = N_SHELLS if n_shells is None else n_shells
+    subdiv = SUBDIV if subdiv is None else subdiv
+    log2_t = LOG2_T if log2_t is None else log2_t
+    mesh = synthetic.shell_mesh(n_shells=n_shells, subdivisions=subdiv, seed=seed)
     mi = MeshIntersection(mesh, simplify_mesh=False, scale=1.0, num_intersections=MAX_HITS, render_step_size=STEP,
                           device=device)
-    field = NGPRadianceField(aabb=[-1.5] * 3 + [1.5] * 3, log2_hashmap_size=LOG2_T)
-    field.load_state_dict(synthetic.seeded_ngp_state(LOG2_T, field.mlp_base.grid.n_rows, seed=seed), strict=False)
+    field = NGPRadianceField(aabb=[-1.5] * 3 + [1.5] * 3, log2_hashmap_size=log2_t)
+    field.load_state_dict(synthetic.seeded_ngp_state(log2_t, field.mlp_base.grid.n_rows, seed=seed), strict=False)
     return mesh, mi, field.to(device)
 
 
@@ -51,8 +65,9 @@ class Stages:
     """One frame, stage by stage, with a HIP event pair around each stage on the launch stream."""
     NAMES = ("traverse", "pack", "field", "composite")
 
-    def __init__(self, mi, field, coherent=True):
+    def __init__(self, mi, field, coherent=True, width=None):
         self.mi, self.field, self.coherent, self.order = mi, field, coherent, None
+        self.width = W if width is None else width
         self.ev = {k: [] for k in self.NAMES}
 
     def _timed(self, name, fn, record):
@@ -80,10 +95,10 @@ class Stages:
         if ri.want_raster(cam):
             hits = self._timed("traverse", lambda: ri._hits_raster_frame(o, d, MAX_HITS, cam), record)
         else:
-            hits = self._timed("traverse", lambda: ri._hits_bvh(o, d, MAX_HITS, W) + (None,), record)
+            hits = self._timed("traverse", lambda: ri._hits_bvh(o, d, MAX_HITS, self.width) + (None,), record)
         hit_tri, hit_t, hit_count, overflow = hits
-        pending = self._timed("pack", lambda: ri.pack_hits_begin(o, d, MAX_HITS, hit_tri, hit_t, hit_count, overflow, W,
-                                                                 lean=self.coherent), record)
+        pending = self._timed("pack", lambda: ri.pack_hits_begin(o, d, MAX_HITS, hit_tri, hit_t, hit_count, overflow,
+                                                                 self.width, lean=self.coherent), record)
         return pending, overflow is not None, record, o.shape[0]
 
     def finish(self, begun):
@@ -111,7 +126,7 @@ class Stages:
     def _pack(self, hits):
         """(tools/field_bench.py) hits = (hit_tri, hit_t, hit_count, overflow, o, d) -> packed samples; sets .order."""
         hit_tri, hit_t, hit_count, overflow, o, d = hits
-        data, order = self.mi.rayintersector.pack_hits(o, d, MAX_HITS, hit_tri, hit_t, hit_count, overflow, W)
+        data, order = self.mi.rayintersector.pack_hits(o, d, MAX_HITS, hit_tri, hit_t, hit_count, overflow, self.width)
         self.order = order if self.coherent else None
         return data
 
@@ -123,9 +138,10 @@ class Stages:
 
 
 def cpu_baseline(mesh, field, cam_o, cam_d, crop=200):
-    """The oracle (CPU restatement of the reference path) timed on this box's host cores on a bounded sample:
-    the centre crop x crop pixels of frame 0 through brute-force multi-hit intersection (OpenMP C), torch-CPU
-    field evaluation and compositing."""
+    """The oracle (CPU restatement of the reference path) timed on this box's host cores on a bounded sample: the
+    centre crop x crop pixels of frame 0 through multi-hit intersection on the oracle's host BVH (OpenMP C; the
+    reference walks Embree's BVH on the CPU, mesh_utils.py:350-354), torch-CPU field evaluation and compositing.
+    The intersection and the field + compositing legs are reported separately."""
     from oracle import meshpath as om
     from tests import helpers
     cores = om.host_cores()
@@ -134,9 +150,10 @@ def cpu_baseline(mesh, field, cam_o, cam_d, crop=200):
     idx = (torch.arange(y0, y0 + crop)[:, None] * W + torch.arange(x0, x0 + crop)[None, :]).reshape(-1)
     o, d = cam_o[idx].numpy(), cam_d[idx].numpy()
     wts = helpers.oracle_ngp_weights(field)
-    bf = om.BruteForceIntersector(mesh.vertices, mesh.faces)
+    tb = time.perf_counter()
+    bvh = om.BVHIntersector(mesh.vertices, mesh.faces, min_separation=float(_min_sep(mesh)))
     t0 = time.perf_counter()
-    sample = om.sampling_raytrace_numpy(bf, d, o, MAX_HITS)
+    sample = om.sampling_raytrace_numpy(bvh, d, o, MAX_HITS)
     t1 = time.perf_counter()
     data = om.to_loader_tensors(sample)
     rgb = om.render_image_finetune(wts, None, data, crop * crop)[0]
@@ -144,11 +161,180 @@ def cpu_baseline(mesh, field, cam_o, cam_d, crop=200):
     n_pts = data[0].shape[0]
     return {
         "value": crop * crop / (t2 - t0), "unit": "rays/s", "cores": cores, "kind": "port",
-        "sample": f"centre {crop}x{crop} crop of frame 0 ({crop * crop} rays, {n_pts} quadrature points): "
-                  f"brute-force intersection over {mesh.faces.shape[0]} triangles {t1 - t0:.1f} s (OpenMP C, "
-                  f"{cores} threads) + torch-CPU field/compositing {t2 - t1:.2f} s "
-                  f"({n_pts / max(t2 - t1, 1e-9):.0f} points/s)",
+        "intersection_rays_per_s": crop * crop / max(t1 - t0, 1e-9),
+        "field_composite_points_per_s": n_pts / max(t2 - t1, 1e-9),
+        "host_bvh_build_s": t0 - tb,
+        "sample": f"centre {crop}x{crop} crop of frame 0 ({crop * crop} rays, {n_pts} quadrature points): multi-hit "
+                  f"intersection on the oracle's host BVH over {mesh.faces.shape[0]} triangles {t1 - t0:.2f} s (OpenMP C, "
+                  f"{cores} threads; BVH build {t0 - tb:.1f} s, not counted) + torch-CPU field/compositing {t2 - t1:.2f} s",
     }, rgb, idx, (np.asarray(sample[2]), np.asarray(sample[4]))
+
+
+def _min_sep(mesh):
+    from quadraturefields_amd.mesh_utils import trimesh_ray_offset
+    return trimesh_ray_offset(mesh.vertices)
+
+
+def timed_field_events(stages, frames, warm):
+    """frames: list of (o, d, cam).  Runs them with HIP events around the field stage only; returns
+    (elapsed_s, points, mean field ms)."""
+    for f in frames[:warm]:
+        stages.frame(*f)
+    torch.cuda.synchronize()
+    stages.ev["field"] = []
+    t0 = time.perf_counter()
+    pts = 0
+    for f in frames[warm:]:
+        pts += stages.frame(*f, "field")[3]
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    return el, pts, stages.stage_ms()["field"]
+
+
+def config3_line(device, steps=5, warm=4):
+    """BASELINE configs[2]: 1920x1080, T = 2^21, ~3 M triangles of thin concentric shells (most object rays collect
+    more than K = 25 candidates), bf16 tables + MLPs with fp32 accumulate."""
+    from quadraturefields_amd import synthetic
+    from quadraturefields_amd.mesh_utils import make_camera
+    w, h, log2_t = 1920, 1080, 21
+    t0 = time.perf_counter()
+    mesh, mi, field = build_scene(device, n_shells=36, subdiv=6, log2_t=log2_t)
+    field.compute_dtype = "bf16"
+    log(f"config 3 scene: {mesh.faces.shape[0]} triangles, built in {time.perf_counter() - t0:.1f} s")
+    cams = synthetic.orbit_cameras(steps + warm, seed=42)
+    focal = synthetic.lego_focal(w)
+    frames = [synthetic.camera_rays(c, focal, w, h, device=device) + (make_camera(c, focal, w, h),) for c in cams]
+    stages = Stages(mi, field, width=w)
+    el, pts, field_ms = timed_field_events(stages, frames, warm)
+    for f in frames[:3]:
+        stages.frame(*f, True)
+    ms = stages.stage_ms(np.median)
+    ms["field"] = field_ms
+    ppl = pts / steps
+    achieved = ppl * 512 / (field_ms * 1e-3) / 1e9
+    return {
+        "workload": "configs[2]: 1920x1080, bf16 tables + MLPs (fp32 accumulate), T=2^21, dense thin shells, K=25",
+        "dtype": "bf16", "triangles": int(mesh.faces.shape[0]), "rays_per_frame": w * h,
+        "ms_per_frame": el / steps * 1e3, "rays_per_s": w * h * steps / el, "quadrature_points_per_frame": ppl,
+        "mean_hits_per_ray": ppl / (w * h), "stage_ms": ms, "raster_wide": int(mi.rayintersector.raster_wide),
+        "dominant_kernel": "field_kernel_bf16<NGP>",
+        "roofline": {"kernel": "field_kernel_bf16<NGP>", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "algorithmic_bytes_per_point": 512, "points_per_launch": ppl, "avg_launch_ms": field_ms},
+    }
+
+
+def config5_line(device, scene, steps=8, warm=3, texture_size=4096, lobes=6):
+    """BASELINE configs[4]: render from the baked SG textures (4096^2 uint8 texture set, L = 6) through
+    render_image_bake_texture_images_with_occgrid on the bench mesh and cameras."""
+    from quadraturefields_amd import synthetic
+    from quadraturefields_amd.mesh_utils import make_camera
+    from quadraturefields_amd.render import FrameRenderer
+    from quadraturefields_amd.texture_utils import FeatureCompression
+    mesh, mi, field = scene
+    tex = synthetic.random_textures(texture_size, lobes, seed=42)
+    comp = FeatureCompression.from_arrays(tex["alpha"], tex["diffuse"], tex["colors"], tex["lambdas"],
+                                          compression_type="sigmoid", lambda_thres=7.5, device=device)
+    del tex
+    uv = torch.from_numpy(synthetic.scaled_uv(mesh, texture_size)).to(device)
+    from quadraturefields_amd.radiance_fields.ngp import NGPRadianceFieldSGNew
+    sg = NGPRadianceFieldSGNew(aabb=[-1.5] * 3 + [1.5] * 3, use_viewdirs=False, num_g_lobes=lobes,
+                               log2_hashmap_size=14).to(device)          # only features_to_rgb's owner (B-17)
+    fr = FrameRenderer(mi, sg, render_step_size=STEP)
+    cams = synthetic.orbit_cameras(steps + warm, seed=42)
+    focal = synthetic.lego_focal(W)
+    frames = [synthetic.camera_rays(c, focal, W, H, device=device) + (make_camera(c, focal, W, H),) for c in cams]
+    events, shade = [], comp.shade
+
+    def timed_shade(indices, dirs, packed=True):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        out = shade(indices, dirs, packed)
+        b.record()
+        events.append((a, b, indices.shape[0]))
+        return out
+
+    comp.shade = timed_shade
+    for o, d, cam in frames[:warm]:
+        fr.render_baked(o, d, uv, comp, camera=cam)
+    torch.cuda.synchronize()
+    events.clear()
+    t0 = time.perf_counter()
+    pts = 0
+    for o, d, cam in frames[warm:]:
+        pts += fr.render_baked(o, d, uv, comp, camera=cam)[3]
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    shade_ms = float(np.mean([a.elapsed_time(b) for a, b, _ in events]))
+    ppl = pts / steps
+    alg = 1 + 3 + 6 * lobes                       # uint8 codes a sample decodes (SURVEY.md 8d: 40 B at L = 6)
+    achieved = ppl * alg / (shade_ms * 1e-3) / 1e9
+    return {
+        "workload": f"configs[4]: baked SG textures {texture_size}^2 uint8 x (2+2L) planes, L={lobes}, 800x800 frames, "
+                    "render_image_bake_texture_images_with_occgrid",
+        "dtype": "u8 codes -> f32", "rays_per_frame": W * H, "ms_per_frame": el / steps * 1e3,
+        "rays_per_s": W * H * steps / el, "quadrature_points_per_frame": ppl,
+        "dominant_kernel": "texture_shade_packed_kernel",
+        "roofline": {"kernel": "texture_shade_packed_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "algorithmic_bytes_per_point": alg, "fetched_bytes_per_point": 64 + 16 + 12,
+                     "points_per_launch": ppl, "avg_launch_ms": shade_ms,
+                     "note": "one 64-B texel record + 16-B texel index + 12-B direction per sample; the gather of "
+                             "isolated 64-B sectors out of a 1.07 GB record array is request-bound, not byte-bound"},
+    }
+
+
+def sharded_frames(device, rank, world, scene0, n_scenes, frames_per_scene, backend):
+    """BASELINE configs[3]: every frame cut into row bands over the ranks, gathered with one collective; eight seeded
+    scenes.  Returns the dict for the JSON line (identical on every rank up to timing; rank 0's is printed)."""
+    from quadraturefields_amd import parallel, synthetic
+    from quadraturefields_amd.render import FrameRenderer
+    scenes = [scene0] + [build_scene(device, seed=42 + s) for s in range(1, n_scenes)]
+    log(f"sharded_frame: {len(scenes)} scenes ready")
+    cams = synthetic.orbit_cameras(frames_per_scene, seed=7)
+    focal = synthetic.lego_focal(W)
+    rays = [synthetic.camera_rays(c, focal, W, H, device=device) for c in cams]
+    shards = [parallel.ShardedFrameRenderer(FrameRenderer(mi, field, render_step_size=STEP), rank, world)
+              for _, mi, field in scenes]
+
+    def loop(sync_each):
+        for sr in shards:
+            for i in range(frames_per_scene):
+                frame = sr.render(rays[i][0], rays[i][1], cams[i], focal, W, H)
+                if sync_each:
+                    torch.cuda.synchronize()
+        return frame
+
+    def timed(sync_each):
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        loop(sync_each)
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            el = float(t[0])
+        return el
+
+    loop(True)                      # warm-up: allocations, band profiles, RCCL channels
+    n = len(shards) * frames_per_scene
+    lat = timed(True)
+    thr = timed(False)
+    cuts = shards[0].last_cuts
+    return {
+        "workload": f"configs[3]: {len(scenes)} seeded scenes x {frames_per_scene} frames, each {W}x{H} frame cut into "
+                    f"{world} cost-balanced row band(s), one all_gather_into_tensor of the bands per frame",
+        "scenes": len(scenes), "frames": n, "ranks": world, "scaling": "strong",
+        "latency_ms_per_frame": lat / n * 1e3, "ms_per_frame_pipelined": thr / n * 1e3,
+        "rays_per_s": W * H * n / thr, "rays_per_s_latency_mode": W * H * n / lat,
+        "gather": "none (1 rank)" if world == 1 else "all_gather_into_tensor, 20 B/ray, bands padded to the tallest",
+        "band_rows": [cuts[r + 1] - cuts[r] for r in range(world)],
+    }
 
 
 def main():
@@ -157,18 +343,16 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the configs[2] / configs[4] lines (N = 1)")
+    ap.add_argument("--scenes", type=int, default=8, help="seeded scenes of the sharded_frame loop (0 = skip it)")
+    ap.add_argument("--sharded-frames", type=int, default=4, help="frames per scene in the sharded_frame loop")
     ap.add_argument("--spin-up", type=float, default=1.0,
                     help="seconds of untimed frames before the warm-up steps, to bring the GPU clocks up")
     ap.add_argument("--up-sample", type=int, default=1, choices=[1, 2],
                     help="render at up_sample x 800 per side as the reference's eval does with up_sample 2 "
                          "(train_finetune.py:620-627); the headline configuration is 1")
-    ap.add_argument("--pipeline", type=int, default=1, choices=[1, 2, 3],
-                    help="frames in flight (one HIP stream each); 1 = strictly one frame after the other.  Measured: "
-                         "2 or 3 frames in flight are 4-5 %% SLOWER (the fabric-bound field kernels of two frames "
-                         "overlap each other and the small kernels gain nothing), so the default stays 1")
-    ap.add_argument("--gather", action="store_true",
-                    help="N > 1: all_gather every finished frame (rgb, alpha, depth) to all ranks.  Off by default: the "
-                         "frames are independent units dealt to the ranks, the path has no exchange step")
+    ap.add_argument("--no-gather", action="store_true",
+                    help="N > 1: do not all_gather the finished frames of the frame-parallel loop")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for N > 1 (nccl = RCCL).  gloo + --single-device rehearses the multi-rank "
                          "control flow on a one-GPU box (all ranks on cuda:0)")
@@ -190,8 +374,10 @@ def main():
     device = torch.device("cuda", local_rank)
 
     log("building scene (mesh, BVH, field)")
+    t_build = time.perf_counter()
     mesh, mi, field = build_scene(device)
-    log(f"scene ready: {mesh.faces.shape[0]} triangles, {mi.rayintersector.num_nodes} BVH nodes")
+    log(f"scene ready in {time.perf_counter() - t_build:.1f} s: {mesh.faces.shape[0]} triangles, "
+        f"{mi.rayintersector.num_nodes} BVH nodes")
     n_frames = args.steps + args.warmup
     cams = synthetic.orbit_cameras(n_frames * world, seed=42)
     focal = synthetic.lego_focal(W)
@@ -199,33 +385,18 @@ def main():
     rays = [synthetic.camera_rays(cams[i * world + rank], focal, W, H, device=device) for i in range(n_frames)]
     cameras = [None if args.intersector == "bvh" else make_camera(cams[i * world + rank], focal, W, H) for i in range(n_frames)]
     stages = Stages(mi, field)
-
-    # --pipeline N keeps N frames in flight: frame i's intersection / pack kernels are enqueued on one stream before
-    # the host waits for frame i-1's sample count and launches its field + compositing kernels on another.
-    streams = [torch.cuda.Stream(device=device) for _ in range(max(1, args.pipeline))]
-    gather = args.gather and world > 1
-    gather_bufs = {s: torch.empty((world * W * H, 5), dtype=torch.float32, device=device) for s in streams} if gather else {}
-
-    def complete(begun, s):
-        with torch.cuda.stream(s):
-            rgb, alpha, depth, n_pts = stages.finish(begun)
-            if gather:
-                torch.distributed.all_gather_into_tensor(gather_bufs[s], torch.cat([rgb, alpha, depth], dim=1))
-        return rgb, n_pts
+    gather = world > 1 and not args.no_gather
+    staged = gather and args.backend == "gloo"          # rehearsal: gloo moves host memory
+    gather_buf = torch.empty((world * W * H, 5), dtype=torch.float32, device="cpu" if staged else device) if gather else None
 
     def run(first, last, record):
-        """Frames [first, last) with len(streams) of them in flight; returns (last rgb, total points)."""
-        inflight, pts, rgb = [], 0, None
+        """Frames [first, last), one after the other; returns (last rgb, total points)."""
+        pts, rgb = 0, None
         for i in range(first, last):
-            s = streams[i % len(streams)]
-            with torch.cuda.stream(s):
-                begun = stages.begin(rays[i][0], rays[i][1], cameras[i], record)
-            inflight.append((begun, s))
-            if len(inflight) == len(streams):
-                rgb, n_pts = complete(*inflight.pop(0))
-                pts += n_pts
-        while inflight:
-            rgb, n_pts = complete(*inflight.pop(0))
+            rgb, alpha, depth, n_pts = stages.frame(rays[i][0], rays[i][1], cameras[i], record)
+            if gather:
+                mine = torch.cat([rgb, alpha, depth], dim=1)
+                torch.distributed.all_gather_into_tensor(gather_buf, mine.cpu() if staged else mine)
             pts += n_pts
         return rgb, pts
 
@@ -260,6 +431,10 @@ def main():
     else:
         pts_total = float(pts)
 
+    sharded = None
+    if args.scenes > 0:             # every rank takes part
+        sharded = sharded_frames(device, rank, world, (mesh, mi, field), args.scenes, args.sharded_frames, args.backend)
+
     if rank != 0:
         parallel.shutdown()
         return
@@ -270,21 +445,35 @@ def main():
     stages.ev["field"] = []
     ms = stages.stage_ms(np.median)
     ms["field"] = field_ms
+    # the general intersector (exact BVH traversal of the same frames; the camera-coherent pass is the default above)
+    ri = mi.rayintersector
+    ev = []
+    for i in range(min(6, n_frames)):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        ri._hits_bvh(rays[i][0], rays[i][1], MAX_HITS, W)
+        b.record()
+        ev.append((a, b))
+    torch.cuda.synchronize()
+    bvh_ms = float(np.median([a.elapsed_time(b) for a, b in ev[1:]]))
     # HBM-side bytes of the dominant kernel come from PMC counters (separate rocprofv3 --pmc passes over this same
-    # command, see profiles/r1/README.md); bench.py cannot sample them itself, so the committed measurement is scaled
-    # to this run's points per launch.
+    # command, see profiles/<round>/README.md); bench.py cannot sample them itself, so the committed measurement is
+    # scaled to this run's points per launch.
     traffic = traffic_src = None
-    tpath = os.path.join(ROOT, "profiles", "r1", "field_traffic.json")
-    if os.path.exists(tpath):
-        tj = json.load(open(tpath))
-        traffic_src = "profiles/r1/field_traffic.json (FETCH_SIZE + WRITE_SIZE, bytes per point x points per launch)"
-        traffic = (tj["fetch_bytes_per_launch"] + tj["write_bytes_per_launch"]) / tj["points_per_launch"]
+    for rnd in (PROFILE_ROUND, "r1"):
+        tpath = os.path.join(ROOT, "profiles", rnd, "field_traffic.json")
+        if os.path.exists(tpath):
+            tj = json.load(open(tpath))
+            traffic_src = f"profiles/{rnd}/field_traffic.json (FETCH_SIZE + WRITE_SIZE, bytes per point x points per launch)"
+            traffic = (tj["fetch_bytes_per_launch"] + tj["write_bytes_per_launch"]) / tj["points_per_launch"]
+            break
     rays_total = W * H * args.steps * world
     pts_per_launch = pts / args.steps
     field_s = (ms["field"] or 0.0) * 1e-3
     achieved = pts_per_launch * ALG_BYTES_PER_POINT / field_s / 1e9 if field_s > 0 else 0.0
     result = {
-        "metric": f"rays/sec at {W}x{H} Lego (mesh-quadrature render: BVH traversal + hash-grid/MLP field + compositing)",
+        "metric": f"rays/sec at {W}x{H} Lego (mesh-quadrature render: ray/mesh intersection + hash-grid/MLP field + "
+                  "compositing)",
         "value": rays_total / elapsed,
         "unit": "rays/s",
         "n_gpus": world,
@@ -296,20 +485,25 @@ def main():
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
+        "spin_up_s": args.spin_up,
         "config": {
             "workload": f"Lego {W}x{H} (configs[1]), 1xMI355X per frame, fp32 hash-grid + tiny-MLP HIP kernels",
             "rays_per_frame": W * H, "max_hits": MAX_HITS, "triangles": int(mesh.faces.shape[0]),
             "log2_hashmap_size": LOG2_T, "render_step_size": STEP, "up_sample": args.up_sample,
-            "intersector": args.intersector, "bvh_fallback_frames": getattr(stages, "fallbacks", 0),
+            "intersector": ("camera-coherent pass (exact BVH traversal for overflowing rays)" if args.intersector == "raster"
+                            else "BVH traversal"),
+            "min_hit_separation": float(mi.rayintersector.min_separation),
+            "bvh_fallback_frames": getattr(stages, "fallbacks", 0),
             "overflow_repaired_frames": mi.rayintersector.repaired_frames,
-            "frames_in_flight": len(streams),
             "parallelism": f"{world} rank(s), the frames dealt round-robin to the ranks, one frame per rank per step"
-                           + (", all_gather of the finished frames" if gather else ", no data-path collective"),
+                           + (", all_gather_into_tensor of the finished frames" if gather else ", no data-path collective"),
         },
         "quadrature_points_per_frame": pts_per_launch,
         "field_evals_per_s": pts_total / elapsed,
         "field_evals_per_s_in_kernel": pts_per_launch / field_s if field_s > 0 else None,
         "stage_ms": ms,
+        "intersect_ms": {"camera_coherent": ms["traverse"] if args.intersector == "raster" else None,
+                         "bvh_traversal": bvh_ms},
         "roofline": {
             "kernel": "field_kernel<NGP> (hash-grid gather + MLPs)", "bound": "hbm", "achieved": achieved,
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
@@ -319,13 +513,28 @@ def main():
             "avg_launch_ms": ms["field"],
         },
     }
+    if sharded is not None:
+        result["sharded_frame"] = sharded
+    if world == 1 and not args.no_configs and args.up_sample == 1:
+        log("configs[4] (baked textures)")
+        cfg5 = config5_line(device, (mesh, mi, field))
+        torch.cuda.empty_cache()
+        log("configs[2] (1080p bf16 dense shells)")
+        cfg3 = config3_line(device)
+        torch.cuda.empty_cache()
+        result["configs"] = [cfg3, cfg5]
     if not args.no_cpu_baseline and world == 1:      # rank 0 at N = 1 only
         log("cpu baseline (oracle on host cores)")
         base, rgb_o, idx, (ray_o, tri_o) = cpu_baseline(mesh, field, rays[0][0].cpu(), rays[0][1].cpu())
         rgb0 = stages.frame(rays[0][0], rays[0][1], cameras[0])[0].cpu()[idx]
-        crop = mi.sampling_raytrace_device(rays[0][1][idx.to(device)].contiguous(), rays[0][0][idx.to(device)].contiguous())
-        base["hit_ids_identical"] = bool(np.array_equal(crop[2].cpu().numpy(), ray_o)
-                                         and np.array_equal(crop[4].cpu().numpy(), tri_o))
+        # ids of the path that was timed: the samples of the full frame, restricted to the crop's rays
+        full = mi.rayintersector.sample_device(rays[0][0], rays[0][1], MAX_HITS, W, cameras[0])
+        remap = torch.full((W * H,), -1, dtype=torch.int64, device=device)
+        remap[idx.to(device)] = torch.arange(idx.shape[0], device=device)
+        local = remap[full[2]]
+        keep = local >= 0
+        base["hit_ids_identical"] = bool(np.array_equal(local[keep].cpu().numpy(), ray_o)
+                                         and np.array_equal(full[4][keep].cpu().numpy(), tri_o))
         base["max_abs_err_vs_hip"] = float((rgb0 - rgb_o).abs().max())
         mse = float(((rgb0.double() - rgb_o.double()) ** 2).mean())
         base["psnr_hip_vs_oracle_db"] = float("inf") if mse == 0 else -10.0 * float(np.log10(mse))

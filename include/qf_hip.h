@@ -213,7 +213,9 @@ int qf_sum_reduce(const float *feats /* [n,c] */, int32_t c, const int64_t *seg_
  * bg_mode: 0 white, 1 black, 2 "random" (uses bkgd[3]); the double-alpha quirk is reproduced.
  * sample_index: NULL, or int32 [n]: sample i's colour and density are rgb_s[sample_index[i]] / sigma[sample_index[i]]
  * (they were produced in the field kernel's processing order, see qf_coherent_layout); depth, deltas, index_ray and
- * the weights output stay indexed by i.                                                         */
+ * the weights output stay indexed by i.
+ * A sample whose ray id lies outside [0, n_rays) contributes to no pixel (its weight is still written); n > 0
+ * with n_rays == 0 is QF_ERR_INVALID_ARGUMENT (the reference raises IndexError there).               */
 #define QF_BG_WHITE 0
 #define QF_BG_BLACK 1
 #define QF_BG_CUSTOM 2
@@ -229,10 +231,11 @@ int qf_derive_properties(const float *rgb_s /* [n,3] */, const float *sigma /* [
 
 /* Backward of qf_derive_properties (training side: the loss of examples/train_finetune.py:489-533 back-propagates
  * through utils.py:139-186).  g_rgb [n_rays,3], g_alpha / g_depth [n_rays] or NULL -> grad_rgb_s [n,3],
- * grad_sigma [n], grad_depth [n] or NULL.  Same inputs as the forward; one thread per ray.       */
+ * grad_sigma [n], grad_depth [n] or NULL.  Same inputs as the forward; one thread per ray.  Samples whose ray id
+ * is outside [0, n_rays) get zero gradients (the forward skips them too).                        */
 int qf_derive_properties_backward(const float *rgb_s, const float *sigma, const float *depth,
                                   const float *deltas /* [n] or NULL */, float delta_const,
-                                  const int64_t *index_ray, int64_t n, int32_t bg_mode,
+                                  const int64_t *index_ray, int64_t n, int64_t n_rays, int32_t bg_mode,
                                   const float *bkgd /* [3] or NULL */, const float *g_rgb,
                                   const float *g_alpha, const float *g_depth, float *grad_rgb_s,
                                   float *grad_sigma, float *grad_depth, void *stream);
@@ -267,32 +270,62 @@ int qf_render_from_density(const float *t_starts, const float *t_ends, const flo
 typedef struct qf_bvh qf_bvh; /* opaque; owns device memory */
 
 /* tri_verts: HOST pointer, [n_tri][3][3] fp32 (the layout of mesh.vertices[mesh.faces]).
- * Builds a SAH BVH on the host and uploads it.                                                */
+ * Builds a binned-SAH binary tree on the host, collapses it into the 8-wide tree the device traverses
+ * (one 256-byte node = 8 child boxes, one leaf = up to 8 triangles) and uploads it.
+ * n_tri < 2^28.                                                                                */
 int qf_bvh_create(const float *tri_verts /* host */, int64_t n_tri, qf_bvh **out);
 /* Same, with the level (1..32) below which the builder stops taking SAH splits and halves the index range
  * (qf_bvh_create uses 32).  Any value gives a valid tree and identical hits; small values trade traversal speed for
  * a shallower tree -- used by the tests to exercise the depth bound.                            */
 int qf_bvh_create_ex(const float *tri_verts /* host */, int64_t n_tri, int32_t sah_depth, qf_bvh **out);
-/* Same topology, new vertex positions (Intersector.update_vertices / train_finetune.py:716-718). */
+/* Same topology, new vertex positions (Intersector.update_vertices / train_finetune.py:716-718), HOST vertices.
+ * Waits for the device (hipDeviceSynchronize) before the upload, so no traversal still reads the old tree.   */
 int qf_bvh_refit(qf_bvh *bvh, const float *tri_verts /* host */, int64_t n_tri);
+/* The same refit with DEVICE vertices, stream-ordered, no host round trip: d_tri_verts [n_tri][3][3] fp32 in the
+ * ORIGINAL triangle order (vertices[faces] of the training loop, train_finetune.py:708-718).  One launch permutes
+ * them into leaf order, then one launch per tree level recomputes the child boxes bottom-up.  The box inflation of
+ * the build is reused (x1.25), valid while the mesh extent stays within 25 % of the build's.             */
+int qf_bvh_refit_device(qf_bvh *bvh, const float *d_tri_verts /* device */, int64_t n_tri, void *stream);
 void qf_bvh_destroy(qf_bvh *bvh);
 int64_t qf_bvh_num_triangles(const qf_bvh *bvh);
-int64_t qf_bvh_num_nodes(const qf_bvh *bvh);
-/* Depth of the deepest inner node (root = 1).  The builder guarantees <= 64, the size of the traversal stack, for
- * any input: below level 32 it halves the index range instead of taking the SAH split.          */
+int64_t qf_bvh_num_nodes(const qf_bvh *bvh);        /* binary build tree */
+int64_t qf_bvh_num_wide_nodes(const qf_bvh *bvh);   /* the 8-wide tree that is traversed */
+/* Depth of the deepest inner node of the binary tree (root = 1).  The builder guarantees <= 64 for any input: below
+ * level 32 it halves the index range instead of taking the SAH split.                            */
 int32_t qf_bvh_max_depth(const qf_bvh *bvh);
-/* Host copies for inspection/tests: nodes as 16 floats each, leaf triangle ids. */
+/* Exact bound of the wide traversal's per-ray stack for this tree (entries); the LDS stack is sized by it. */
+int32_t qf_bvh_max_stack(const qf_bvh *bvh);
+/* Host copies for inspection/tests: binary nodes as 16 floats each, wide nodes as 64 floats each (csrc/bvh.h),
+ * leaf triangle ids.                                                                              */
 int qf_bvh_copy_nodes(const qf_bvh *bvh, float *nodes_host, int64_t capacity_nodes);
+int qf_bvh_copy_wide_nodes(const qf_bvh *bvh, float *nodes_host, int64_t capacity_nodes);
 int qf_bvh_copy_tri_ids(const qf_bvh *bvh, int32_t *ids_host, int64_t capacity);
 
-/* Up to max_hits nearest hits per ray, ascending by (t, triangle id).
+/* The reference's multi-hit rule (trimesh 3.23.5 ray_pyembree.RayMeshIntersector.intersects_id, called at
+ * mesh_utils.py:350-354): after every hit the ray is re-originated `min_separation` past it and
+ * the next closest-hit query starts there, so hits closer than that to the previously returned one -- and the second
+ * copy of a duplicated face -- are never returned.  min_separation > 0 turns the rule on for every intersection
+ * call on this handle (qf_bvh_intersect, qf_bvh_repair_overflow, qf_raster_intersect with sort_lists,
+ * qf_filter_hits): with a ray's hits ascending in (t, tri), the first is kept and each later one iff
+ * t > t_last_kept + min_separation (fp32), up to max_hits kept hits.  <= 0 (the default of a new handle): every hit
+ * counts.  trimesh's value is clip(1e-4 * 100 / mesh.scale, 1e-8, inf) with mesh.scale = the bounding-box diagonal
+ * (restated from memory: parity unpinned).                                                          */
+int qf_bvh_set_min_separation(qf_bvh *bvh, float min_separation);
+float qf_bvh_min_separation(const qf_bvh *bvh);
+
+/* Up to max_hits nearest hits per ray (under the handle's min_separation rule), ascending by (t, triangle id).
  * rays_o, rays_d [n_rays,3]; hit_tri/hit_t [n_rays,max_hits] (unused slots -1 / +inf);
  * hit_count [n_rays].  image_width > 0: rays are a row-major image of that width and are
- * traversed in 8x8 pixel tiles (speed only; results identical).
+ * traversed in 8x4 pixel tiles (speed only; results identical).
  * Also the shape of Intersector.find_intersections (int[R*max_hits], -1 padded).             */
 int qf_bvh_intersect(const qf_bvh *bvh, const float *rays_o, const float *rays_d, int64_t n_rays,
                      int32_t max_hits, int32_t image_width, int32_t *hit_tri, float *hit_t,
                      int32_t *hit_count, void *stream);
+/* Applies the handle's min_separation rule to per-ray lists in ANY order that hold ALL hits of their ray
+ * (hit_count <= max_hits; the lists of qf_raster_intersect after qf_bvh_repair_overflow): sorts each list ascending,
+ * drops the hits the rule skips, pads, updates hit_count.  No launch when the rule is off.          */
+int qf_filter_hits(const qf_bvh *bvh, int64_t n_rays, int32_t max_hits, int32_t *hit_tri, float *hit_t,
+                   int32_t *hit_count, void *stream);
 
 /* Camera-coherent variant for rays that are the row-major pixel grid of ONE pinhole camera in the reference's
  * convention (nerf_synthetic.py:341-358): camera_dir = ((x - cx + 0.5)/fx, -(y - cy + 0.5)/fy, -1),

@@ -51,14 +51,37 @@ def _lib():
     global _LIB
     if _LIB is None:
         path = os.path.join(_HERE, "_build", "libqf_oracle.so")
-        if not os.path.exists(path):
+        src = os.path.join(_HERE, "intersect_ref.c")
+        if not os.path.exists(path) or (os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(path)):
             build()
         _LIB = ctypes.CDLL(path)
         _LIB.qf_oracle_multihit.restype = ctypes.c_int
         _LIB.qf_oracle_multihit.argtypes = [
             ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
-            ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+            ctypes.c_int, ctypes.c_float, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        _LIB.qf_oracle_bvh_build.restype = ctypes.c_void_p
+        _LIB.qf_oracle_bvh_build.argtypes = [ctypes.c_void_p, ctypes.c_int64]
+        _LIB.qf_oracle_bvh_free.restype = None
+        _LIB.qf_oracle_bvh_free.argtypes = [ctypes.c_void_p]
+        _LIB.qf_oracle_bvh_multihit.restype = ctypes.c_int
+        _LIB.qf_oracle_bvh_multihit.argtypes = [
+            ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float,
+            ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
     return _LIB
+
+
+def trimesh_ray_offset(vertices) -> float:
+    """trimesh 3.23.5 ``ray_pyembree.RayMeshIntersector.intersects_id``: after every hit the ray restarts
+    ``clip(_ray_offset_factor * _scale, _ray_offset_floor, inf)`` past it, ``_ray_offset_factor = 1e-4``,
+    ``_ray_offset_floor = 1e-8``, ``_scale = 100 / mesh.scale`` (scale_to_box), ``mesh.scale`` = length of the
+    bounding-box diagonal (restated from memory: PARITY UNPINNED)."""
+    v = np.asarray(vertices, dtype=np.float64).reshape(-1, 3)
+    if v.shape[0] == 0:
+        return 1e-8
+    scale = float(np.sqrt(((v.max(axis=0) - v.min(axis=0)) ** 2).sum()))
+    if not scale > 0:
+        return 1e-8
+    return float(np.clip(1e-4 * (100.0 / scale), 1e-8, np.inf))
 
 
 # ------------------------------------------------------------------ ray generation
@@ -81,12 +104,22 @@ def generate_rays(c2w: torch.Tensor, focal: float, width: int, height: int, open
 
 # --------------------------------------------------------------------- intersector
 class BruteForceIntersector:
-    """Duck-types the trimesh intersector used at mesh_utils.py:350-354."""
+    """Duck-types the trimesh intersector used at mesh_utils.py:350-354.  ``min_separation``: trimesh's re-origin
+    distance -- ``"trimesh"`` (default: ``trimesh_ray_offset(vertices)``), a distance, or 0 / None for every hit."""
 
-    def __init__(self, vertices: np.ndarray, faces: np.ndarray):
+    def __init__(self, vertices: np.ndarray, faces: np.ndarray, min_separation="trimesh"):
         self.vertices = np.ascontiguousarray(vertices, dtype=np.float64)
         self.faces = np.ascontiguousarray(faces, dtype=np.int64)
         self.tri = np.ascontiguousarray(self.vertices.astype(np.float32)[self.faces].reshape(-1, 9))
+        if isinstance(min_separation, str):
+            assert min_separation == "trimesh"
+            min_separation = trimesh_ray_offset(self.vertices)
+        self.min_separation = max(float(min_separation or 0.0), 0.0)
+
+    def _run(self, o, d, n, max_hits, n_threads, tri, t, cnt):
+        return _lib().qf_oracle_multihit(
+            self.tri.ctypes.data, self.tri.shape[0], o.ctypes.data, d.ctypes.data, n, int(max_hits),
+            float(self.min_separation), int(n_threads or host_cores()), tri.ctypes.data, t.ctypes.data, cnt.ctypes.data)
 
     def hits(self, origins, vectors, max_hits, n_threads=None):
         """-> (tri [R,K] int32 (-1 pad), t [R,K] fp32 (+inf pad), count [R] int32)."""
@@ -96,11 +129,9 @@ class BruteForceIntersector:
         tri = np.empty((n, max_hits), dtype=np.int32)
         t = np.empty((n, max_hits), dtype=np.float32)
         cnt = np.empty(n, dtype=np.int32)
-        rc = _lib().qf_oracle_multihit(
-            self.tri.ctypes.data, self.tri.shape[0], o.ctypes.data, d.ctypes.data, n,
-            int(max_hits), int(n_threads or host_cores()), tri.ctypes.data, t.ctypes.data, cnt.ctypes.data)
+        rc = self._run(o, d, n, max_hits, n_threads, tri, t, cnt)
         if rc != 0:
-            raise RuntimeError("qf_oracle_multihit failed: %d" % rc)
+            raise RuntimeError("oracle multihit failed: %d" % rc)
         return tri, t, cnt
 
     def intersects_id(self, origins, vectors, multiple_hits=True, return_locations=True, max_hits=10):
@@ -121,6 +152,30 @@ class BruteForceIntersector:
         if not out_t:
             return np.zeros(0, np.int64), np.zeros(0, np.int64), np.zeros((0, 3), np.float64)
         return np.concatenate(out_t), np.concatenate(out_r), np.concatenate(out_p)
+
+
+class BVHIntersector(BruteForceIntersector):
+    """The same answer as the brute force (tested), through the oracle's host BVH walk (intersect_ref.c): what the
+    reference's CPU path does with Embree, and the intersection leg of bench.py's cpu_baseline."""
+
+    def __init__(self, vertices, faces, min_separation="trimesh"):
+        super().__init__(vertices, faces, min_separation)
+        self._bvh = _lib().qf_oracle_bvh_build(self.tri.ctypes.data, self.tri.shape[0])
+        if not self._bvh:
+            raise RuntimeError("qf_oracle_bvh_build failed")
+
+    def __del__(self):
+        if getattr(self, "_bvh", None):
+            try:
+                _lib().qf_oracle_bvh_free(self._bvh)
+            except Exception:           # interpreter shutdown
+                pass
+            self._bvh = None
+
+    def _run(self, o, d, n, max_hits, n_threads, tri, t, cnt):
+        return _lib().qf_oracle_bvh_multihit(
+            self._bvh, o.ctypes.data, d.ctypes.data, n, int(max_hits), float(self.min_separation),
+            int(n_threads or host_cores()), tri.ctypes.data, t.ctypes.data, cnt.ctypes.data)
 
 
 def sampling_raytrace_numpy(intersector, vectors: np.ndarray, origins: np.ndarray, max_hits: int):

@@ -72,7 +72,7 @@ _SIGNATURES = {
     "qf_exponential_integration": (c_int, [_P, c_int32, _P, _P, c_int64, c_int64, c_int32, _P, _P, _P]),
     "qf_sum_reduce": (c_int, [_P, c_int32, _P, c_int64, c_int64, _P, _P]),
     "qf_derive_properties": (c_int, [_P, _P, _P, _P, c_float, _P, c_int64, c_int64, c_int32, _P, _P, _P, _P, _P, _P, _P]),
-    "qf_derive_properties_backward": (c_int, [_P, _P, _P, _P, c_float, _P, c_int64, c_int32, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "qf_derive_properties_backward": (c_int, [_P, _P, _P, _P, c_float, _P, c_int64, c_int64, c_int32, _P, _P, _P, _P, _P, _P, _P, _P]),
     "qf_pack_info": (c_int, [_P, c_int64, c_int64, _P, _P]),
     "qf_exclusive_scan": (c_int, [_P, _P, c_int64, c_int64, c_int32, _P, _P]),
     "qf_accumulate_along_rays": (c_int, [_P, _P, c_int32, _P, c_int64, c_int64, _P, _P]),
@@ -80,6 +80,13 @@ _SIGNATURES = {
     "qf_bvh_create": (c_int, [_P, c_int64, POINTER(c_void_p)]),
     "qf_bvh_create_ex": (c_int, [_P, c_int64, c_int32, POINTER(c_void_p)]),
     "qf_bvh_refit": (c_int, [_P, _P, c_int64]),
+    "qf_bvh_refit_device": (c_int, [_P, _P, c_int64, _P]),
+    "qf_bvh_num_wide_nodes": (c_int64, [_P]),
+    "qf_bvh_max_stack": (c_int32, [_P]),
+    "qf_bvh_copy_wide_nodes": (c_int, [_P, _P, c_int64]),
+    "qf_bvh_set_min_separation": (c_int, [_P, c_float]),
+    "qf_bvh_min_separation": (c_float, [_P]),
+    "qf_filter_hits": (c_int, [_P, c_int64, c_int32, _P, _P, _P, _P]),
     "qf_bvh_destroy": (None, [_P]),
     "qf_bvh_num_triangles": (c_int64, [_P]),
     "qf_bvh_num_nodes": (c_int64, [_P]),

@@ -1,4 +1,5 @@
-// Host-side BVH construction (binned SAH, binary, children's boxes stored in the parent) + upload.
+// Host-side BVH construction: binned-SAH binary tree (children's boxes stored in the parent), collapsed into the
+// 8-wide tree the device traverses (bvh.h), upload, and refits (host vertices or device vertices).
 //
 // Replaces the acceleration-structure build hidden in trimesh.ray.ray_pyembree.RayMeshIntersector
 // (examples/mesh_utils.py:223) and the OptiX `Intersector(vertices, max_hits, device)` constructor /
@@ -153,10 +154,12 @@ int upload(qf_bvh *bvh, const float *tri_verts)
         o[4] = v[3]; o[5] = v[4]; o[6] = v[5]; o[7] = 0.f;
         o[8] = v[6]; o[9] = v[7]; o[10] = v[8]; o[11] = 0.f;
     }
-    if (!bvh->d_nodes) QF_HIP_TRY(hipMalloc((void **)&bvh->d_nodes, std::max<size_t>(bvh->h_nodes.size(), 16) * sizeof(float)));
+    // the caller may have kernels in flight on non-blocking streams that read the old tree: wait for them
+    QF_HIP_TRY(hipDeviceSynchronize());
+    if (!bvh->d_nodes8) QF_HIP_TRY(hipMalloc((void **)&bvh->d_nodes8, std::max<size_t>(bvh->h_nodes8.size(), 64) * sizeof(float)));
     if (!bvh->d_tris) QF_HIP_TRY(hipMalloc((void **)&bvh->d_tris, std::max<size_t>(tris.size(), 12) * sizeof(float)));
-    if (!bvh->h_nodes.empty())
-        QF_HIP_TRY(hipMemcpy(bvh->d_nodes, bvh->h_nodes.data(), bvh->h_nodes.size() * sizeof(float), hipMemcpyHostToDevice));
+    if (!bvh->h_nodes8.empty())
+        QF_HIP_TRY(hipMemcpy(bvh->d_nodes8, bvh->h_nodes8.data(), bvh->h_nodes8.size() * sizeof(float), hipMemcpyHostToDevice));
     if (!tris.empty()) QF_HIP_TRY(hipMemcpy(bvh->d_tris, tris.data(), tris.size() * sizeof(float), hipMemcpyHostToDevice));
     return QF_OK;
 }
@@ -174,7 +177,7 @@ void build_host(qf_bvh *bvh, const float *tri_verts, int64_t n_tri, int sah_dept
         boxes[(size_t)i] = tri_box(tri_verts + 9 * i);
         for (int k = 0; k < 3; ++k) cent[3 * (size_t)i + k] = 0.5f * (boxes[(size_t)i].lo[k] + boxes[(size_t)i].hi[k]);
     }
-    const float eps = scene_eps(tri_verts, n_tri);
+    const float eps = bvh->eps = scene_eps(tri_verts, n_tri);
     std::vector<int32_t> &ids = bvh->h_tri_ids;
     std::vector<float> &nodes = bvh->h_nodes;
     nodes.reserve((size_t)n_tri * 8);
@@ -221,7 +224,7 @@ void build_host(qf_bvh *bvh, const float *tri_verts, int64_t n_tri, int sah_dept
 // New vertex positions, same topology: recompute boxes bottom-up (children have larger indices).
 void refit_host(qf_bvh *bvh, const float *tri_verts)
 {
-    const float eps = scene_eps(tri_verts, bvh->n_tri);
+    const float eps = bvh->eps = scene_eps(tri_verts, bvh->n_tri);
     std::vector<float> &nodes = bvh->h_nodes;
     for (int64_t n = bvh->n_nodes - 1; n >= 0; --n) {
         float *node = &nodes[(size_t)n * 16];
@@ -248,6 +251,207 @@ void refit_host(qf_bvh *bvh, const float *tri_verts)
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The 8-wide tree (bvh.h).  Built from the binary tree: a wide node starts from a binary node's two children and keeps
+// replacing the largest-area child that still holds more than QF_BVH8_LEAF_MAX triangles by its own two children until
+// it has 8; a child subtree of at most 8 triangles becomes ONE leaf (its triangles are contiguous in leaf order).
+
+struct Ref { float lo[3], hi[3]; int32_t child, count; };   // binary encoding: child >= 0 inner, < 0 leaf ~first
+
+inline Ref bin_ref(const float *node, int side)
+{
+    Ref r;
+    for (int k = 0; k < 3; ++k) { r.lo[k] = node[6 * side + k]; r.hi[k] = node[6 * side + 3 + k]; }
+    r.child = as_int(node[12 + side]);
+    r.count = as_int(node[14 + side]);
+    return r;
+}
+
+inline float ref_area(const Ref &r)
+{
+    const float dx = r.hi[0] - r.lo[0], dy = r.hi[1] - r.lo[1], dz = r.hi[2] - r.lo[2];
+    if (!(dx >= 0.f) || !(dy >= 0.f) || !(dz >= 0.f)) return 0.f;
+    return dx * dy + dy * dz + dz * dx;
+}
+
+inline int32_t leaf_token(int32_t first, int32_t count) { return ~((first << 3) | ((count - 1) & 7)); }
+
+void set_empty8(float *c)
+{
+    const float inf = std::numeric_limits<float>::infinity();
+    c[0] = c[1] = c[2] = inf;
+    c[3] = c[4] = c[5] = -inf;
+    c[6] = as_float(QF_BVH8_EMPTY);
+    c[7] = 0.f;
+}
+
+int collapse8(qf_bvh *bvh)
+{
+    bvh->h_nodes8.clear();
+    bvh->level_start8.clear();
+    bvh->n_nodes8 = 0;
+    bvh->max_stack8 = 1;
+    if (bvh->n_tri == 0) return QF_OK;
+    const std::vector<float> &bn = bvh->h_nodes;
+    const int64_t nb = bvh->n_nodes;
+    // triangle range of every binary inner node (children have larger indices than their parent)
+    std::vector<int32_t> first((size_t)nb), total((size_t)nb);
+    for (int64_t n = nb - 1; n >= 0; --n) {
+        int32_t f = 0x7fffffff, t = 0;
+        for (int side = 0; side < 2; ++side) {
+            const int32_t c = as_int(bn[(size_t)n * 16 + 12 + side]), k = as_int(bn[(size_t)n * 16 + 14 + side]);
+            if (c < 0) { if (k > 0) { f = std::min(f, ~c); t += k; } }
+            else { f = std::min(f, first[(size_t)c]); t += total[(size_t)c]; }
+        }
+        first[(size_t)n] = f;
+        total[(size_t)n] = t;
+    }
+    std::vector<float> &wn = bvh->h_nodes8;
+    std::vector<int32_t> queue;          // binary node behind each wide node, in breadth-first order
+    queue.push_back(0);
+    bvh->level_start8.push_back(0);
+    size_t head = 0;
+    while (head < queue.size()) {
+        const size_t level_end = queue.size();
+        for (; head < level_end; ++head) {
+            const int32_t b = queue[head];
+            Ref refs[8];
+            int n_ref = 0;
+            refs[n_ref++] = bin_ref(&bn[(size_t)b * 16], 0);
+            refs[n_ref++] = bin_ref(&bn[(size_t)b * 16], 1);
+            while (n_ref < 8) {
+                int best = -1;
+                float best_area = -1.f;
+                for (int i = 0; i < n_ref; ++i) {
+                    if (refs[i].child < 0 || total[(size_t)refs[i].child] <= QF_BVH8_LEAF_MAX) continue;
+                    const float a = ref_area(refs[i]);
+                    if (a > best_area) { best_area = a; best = i; }
+                }
+                if (best < 0) break;
+                const int32_t c = refs[best].child;
+                refs[best] = bin_ref(&bn[(size_t)c * 16], 0);
+                refs[n_ref++] = bin_ref(&bn[(size_t)c * 16], 1);
+            }
+            const size_t at = wn.size();
+            wn.resize(at + 64);
+            int slot = 0;
+            for (int i = 0; i < n_ref; ++i) {
+                const Ref &r = refs[i];
+                int32_t token;
+                if (r.child < 0) {
+                    if (r.count <= 0) continue;                          // the empty sibling of a tiny mesh's root
+                    token = leaf_token(~r.child, r.count);
+                } else if (total[(size_t)r.child] <= QF_BVH8_LEAF_MAX) {
+                    token = leaf_token(first[(size_t)r.child], total[(size_t)r.child]);
+                } else {
+                    token = (int32_t)queue.size();
+                    queue.push_back(r.child);
+                }
+                float *c = &wn[at + 8 * (size_t)slot++];
+                for (int k = 0; k < 3; ++k) { c[k] = r.lo[k]; c[3 + k] = r.hi[k]; }
+                c[6] = as_float(token);
+                c[7] = 0.f;
+            }
+            for (; slot < 8; ++slot) set_empty8(&wn[at + 8 * (size_t)slot]);
+        }
+        bvh->level_start8.push_back((int32_t)level_end);     // = start of the next level, or the node count at the end
+    }
+    bvh->n_nodes8 = (int64_t)queue.size();
+    // exact stack bound: need(n) = max(h, h - 1 + max over inner children need(c)), h = children of n
+    std::vector<int32_t> need((size_t)bvh->n_nodes8, 0);
+    for (int64_t n = bvh->n_nodes8 - 1; n >= 0; --n) {
+        int h = 0, deepest = 0;
+        for (int j = 0; j < 8; ++j) {
+            const int32_t tok = as_int(wn[(size_t)n * 64 + 8 * j + 6]);
+            if (tok == QF_BVH8_EMPTY) continue;
+            ++h;
+            if (tok >= 0) deepest = std::max(deepest, need[(size_t)tok]);
+        }
+        need[(size_t)n] = std::max(h, h - 1 + deepest);
+    }
+    bvh->max_stack8 = std::max(1, need[0]) + 1;
+    return bvh->max_stack8 <= QF_BVH8_MAX_STACK ? QF_OK : QF_ERR_UNSUPPORTED;
+}
+
+// New vertex positions: every wide child box again from its triangles (leaf order), bottom-up level by level.
+void refit8_host(qf_bvh *bvh, const float *tri_verts)
+{
+    std::vector<float> &wn = bvh->h_nodes8;
+    const float eps = bvh->eps;
+    for (int64_t n = bvh->n_nodes8 - 1; n >= 0; --n) {       // children have larger indices (breadth-first order)
+        for (int j = 0; j < 8; ++j) {
+            float *c = &wn[(size_t)n * 64 + 8 * (size_t)j];
+            const int32_t tok = as_int(c[6]);
+            if (tok == QF_BVH8_EMPTY) continue;
+            Box b;
+            b.reset();
+            if (tok < 0) {
+                const int32_t packed = ~tok, first = packed >> 3, cnt = (packed & 7) + 1;
+                for (int32_t k = 0; k < cnt; ++k) b.grow(tri_box(tri_verts + 9 * (size_t)bvh->h_tri_ids[(size_t)(first + k)]));
+                for (int k = 0; k < 3; ++k) { c[k] = b.lo[k] - eps; c[3 + k] = b.hi[k] + eps; }
+            } else {
+                const float *ch = &wn[(size_t)tok * 64];
+                for (int q = 0; q < 8; ++q) {
+                    if (as_int(ch[8 * q + 6]) == QF_BVH8_EMPTY) continue;
+                    Box cb;
+                    for (int k = 0; k < 3; ++k) { cb.lo[k] = ch[8 * q + k]; cb.hi[k] = ch[8 * q + 3 + k]; }
+                    b.grow(cb);
+                }
+                for (int k = 0; k < 3; ++k) { c[k] = b.lo[k]; c[3 + k] = b.hi[k]; }
+            }
+        }
+    }
+}
+
+// ---- device-side refit (training: the vertices live on the device, train_finetune.py:708-718) -------------------------
+__global__ void refit_tris_kernel(float4 *tris, const float *verts, int64_t n_tri)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_tri; i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 a = tris[i * 3];
+        const int64_t id = __float_as_int(a.w);
+        const float *v = verts + id * 9;
+        tris[i * 3 + 0] = make_float4(v[0], v[1], v[2], a.w);
+        tris[i * 3 + 1] = make_float4(v[3], v[4], v[5], 0.f);
+        tris[i * 3 + 2] = make_float4(v[6], v[7], v[8], 0.f);
+    }
+}
+
+// one thread per (node, child) of the level [node0, node1)
+__global__ void refit_level_kernel(float *nodes, const float4 *tris, int node0, int node1, float eps)
+{
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t n = node0 + (gid >> 3);
+    const int j = (int)(gid & 7);
+    if (n >= node1) return;
+    float *c = nodes + n * 64 + 8 * j;
+    const int tok = __float_as_int(c[6]);
+    if (tok == QF_BVH8_EMPTY) return;
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    if (tok < 0) {
+        const int packed = ~tok, first = packed >> 3, cnt = (packed & 7) + 1;
+        for (int k = 0; k < cnt; ++k) {
+#pragma unroll
+            for (int v = 0; v < 3; ++v) {
+                const float4 p = tris[(int64_t)(first + k) * 3 + v];
+                lo[0] = fminf(lo[0], p.x); lo[1] = fminf(lo[1], p.y); lo[2] = fminf(lo[2], p.z);
+                hi[0] = fmaxf(hi[0], p.x); hi[1] = fmaxf(hi[1], p.y); hi[2] = fmaxf(hi[2], p.z);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { lo[k] -= eps; hi[k] += eps; }
+    } else {
+        const float *ch = nodes + (int64_t)tok * 64;
+        for (int q = 0; q < 8; ++q) {
+            if (__float_as_int(ch[8 * q + 6]) == QF_BVH8_EMPTY) continue;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { lo[k] = fminf(lo[k], ch[8 * q + k]); hi[k] = fmaxf(hi[k], ch[8 * q + 3 + k]); }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { c[k] = lo[k]; c[3 + k] = hi[k]; }
+}
+
 }  // namespace
 
 extern "C" int qf_bvh_create(const float *tri_verts, int64_t n_tri, qf_bvh **out)
@@ -257,32 +461,67 @@ extern "C" int qf_bvh_create(const float *tri_verts, int64_t n_tri, qf_bvh **out
 
 extern "C" int qf_bvh_create_ex(const float *tri_verts, int64_t n_tri, int32_t sah_depth, qf_bvh **out)
 {
-    if (!out || n_tri < 0 || n_tri > 0x3fffffff || (n_tri > 0 && !tri_verts)) return QF_ERR_INVALID_ARGUMENT;
+    if (!out || n_tri < 0 || n_tri >= (1 << 28) || (n_tri > 0 && !tri_verts)) return QF_ERR_INVALID_ARGUMENT;
     if (sah_depth < 1 || sah_depth > QF_BVH_SAH_DEPTH) return QF_ERR_INVALID_ARGUMENT;
     qf_bvh *bvh = new (std::nothrow) qf_bvh();
     if (!bvh) return QF_ERR_INVALID_ARGUMENT;
     build_host(bvh, tri_verts, n_tri, sah_depth);
     if (bvh->max_depth > QF_BVH_MAX_DEPTH) { qf_bvh_destroy(bvh); return QF_ERR_UNSUPPORTED; }   // cannot happen, see bvh.h
-    int rc = upload(bvh, tri_verts);
+    int rc = collapse8(bvh);
+    if (rc == QF_OK) rc = upload(bvh, tri_verts);
     if (rc != QF_OK) { qf_bvh_destroy(bvh); return rc; }
     *out = bvh;
     return QF_OK;
 }
 
 extern "C" int32_t qf_bvh_max_depth(const qf_bvh *bvh) { return bvh ? bvh->max_depth : -1; }
+extern "C" int32_t qf_bvh_max_stack(const qf_bvh *bvh) { return bvh ? bvh->max_stack8 : -1; }
+extern "C" int64_t qf_bvh_num_wide_nodes(const qf_bvh *bvh) { return bvh ? bvh->n_nodes8 : -1; }
+
+extern "C" int qf_bvh_set_min_separation(qf_bvh *bvh, float min_separation)
+{
+    if (!bvh || min_separation != min_separation) return QF_ERR_INVALID_ARGUMENT;
+    bvh->min_sep = min_separation > 0.f ? min_separation : 0.f;
+    return QF_OK;
+}
+
+extern "C" float qf_bvh_min_separation(const qf_bvh *bvh) { return bvh ? bvh->min_sep : -1.f; }
 
 extern "C" int qf_bvh_refit(qf_bvh *bvh, const float *tri_verts, int64_t n_tri)
 {
     if (!bvh || n_tri != bvh->n_tri || (n_tri > 0 && !tri_verts)) return QF_ERR_INVALID_ARGUMENT;
     if (n_tri == 0) return QF_OK;
     refit_host(bvh, tri_verts);
-    return upload(bvh, tri_verts);
+    refit8_host(bvh, tri_verts);
+    return upload(bvh, tri_verts);      // waits for the device first: no traversal may still be reading the old tree
+}
+
+extern "C" int qf_bvh_refit_device(qf_bvh *bvh, const float *d_tri_verts, int64_t n_tri, void *stream)
+{
+    if (!bvh || n_tri != bvh->n_tri || (n_tri > 0 && !d_tri_verts)) return QF_ERR_INVALID_ARGUMENT;
+    if (n_tri == 0) return QF_OK;
+    hipStream_t st = qf_stream(stream);
+    hipLaunchKernelGGL(refit_tris_kernel, dim3(qf_grid_1d(n_tri, 256)), dim3(256), 0, st,
+                       reinterpret_cast<float4 *>(bvh->d_tris), d_tri_verts, n_tri);
+    QF_LAUNCH_CHECK();
+    const int levels = (int)bvh->level_start8.size() - 1;
+    for (int l = levels - 1; l >= 0; --l) {
+        const int n0 = bvh->level_start8[(size_t)l], n1 = bvh->level_start8[(size_t)l + 1];
+        if (n1 <= n0) continue;
+        const int64_t threads = (int64_t)(n1 - n0) * 8;
+        hipLaunchKernelGGL(refit_level_kernel, dim3((unsigned)qf_div_up(threads, 256)), dim3(256), 0, st, bvh->d_nodes8,
+                           reinterpret_cast<const float4 *>(bvh->d_tris), n0, n1, bvh->eps * 1.25f);
+        QF_LAUNCH_CHECK();
+    }
+    // eps was sized from the extent at build / host-refit time; 1.25x covers the bounded vertex motion of training.
+    // The host mirrors (h_nodes, h_nodes8) are NOT updated: inspection copies show the build state.
+    return QF_OK;
 }
 
 extern "C" void qf_bvh_destroy(qf_bvh *bvh)
 {
     if (!bvh) return;
-    if (bvh->d_nodes) (void)hipFree(bvh->d_nodes);
+    if (bvh->d_nodes8) (void)hipFree(bvh->d_nodes8);
     if (bvh->d_tris) (void)hipFree(bvh->d_tris);
     delete bvh;
 }
@@ -301,5 +540,12 @@ extern "C" int qf_bvh_copy_tri_ids(const qf_bvh *bvh, int32_t *ids_host, int64_t
 {
     if (!bvh || !ids_host || capacity < bvh->n_tri) return QF_ERR_INVALID_ARGUMENT;
     std::memcpy(ids_host, bvh->h_tri_ids.data(), (size_t)bvh->n_tri * sizeof(int32_t));
+    return QF_OK;
+}
+
+extern "C" int qf_bvh_copy_wide_nodes(const qf_bvh *bvh, float *nodes_host, int64_t capacity_nodes)
+{
+    if (!bvh || !nodes_host || capacity_nodes < bvh->n_nodes8) return QF_ERR_INVALID_ARGUMENT;
+    std::memcpy(nodes_host, bvh->h_nodes8.data(), (size_t)bvh->n_nodes8 * 64 * sizeof(float));
     return QF_OK;
 }

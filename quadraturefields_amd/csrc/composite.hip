@@ -40,8 +40,8 @@ constexpr int DP_STAGE = DP_CHUNK + DP_HALO;
 
 __global__ __launch_bounds__(DP_THREADS) void derive_properties_kernel(
     const float *rgb_s, const float *sigma, const float *depth_s, const float *deltas, float delta_const,
-    const int64_t *index_ray, int64_t n, int bg_mode, const float *bkgd, const int32_t *sample_index, float *out_rgb,
-    float *out_alpha, float *out_depth, float *weights)
+    const int64_t *index_ray, int64_t n, int64_t n_rays, int bg_mode, const float *bkgd, const int32_t *sample_index,
+    float *out_rgb, float *out_alpha, float *out_depth, float *weights)
 {
     __shared__ float s_tau[DP_STAGE];
     __shared__ float s_alpha[DP_STAGE];              // 1 - exp(-tau), computed by all lanes before the serial part
@@ -131,11 +131,13 @@ __global__ __launch_bounds__(DP_THREADS) void derive_properties_kernel(
                 g = ca * cg + (1.0f - ca) * bkgd[1];
                 b = ca * cb + (1.0f - ca) * bkgd[2];
             }
-            out_rgb[ray * 3 + 0] = r;
-            out_rgb[ray * 3 + 1] = g;
-            out_rgb[ray * 3 + 2] = b;
-            out_alpha[ray] = ca;
-            out_depth[ray] = cd;
+            if (ray >= 0 && ray < n_rays) {         // a ray id outside the image never touches memory (weights are still written)
+                out_rgb[ray * 3 + 0] = r;
+                out_rgb[ray * 3 + 1] = g;
+                out_rgb[ray * 3 + 2] = b;
+                out_alpha[ray] = ca;
+                out_depth[ray] = cd;
+            }
         }
         __syncthreads();
         for (int k = threadIdx.x; k < staged; k += DP_THREADS)
@@ -319,11 +321,12 @@ extern "C" int qf_derive_properties(const float *rgb_s, const float *sigma, cons
                          out_alpha, out_depth);
     }
     if (n == 0) return QF_OK;
+    if (n_rays == 0) return QF_ERR_INVALID_ARGUMENT;             // samples without an image to composite them into
     if (!rgb_s || !sigma || !depth || !index_ray || !weights) return QF_ERR_INVALID_ARGUMENT;
     const int64_t n_chunks = (n + DP_CHUNK - 1) / DP_CHUNK;
     hipLaunchKernelGGL(derive_properties_kernel, dim3((unsigned)(n_chunks < 65536 ? n_chunks : 65536)), dim3(DP_THREADS), 0,
-                       qf_stream(stream), rgb_s, sigma, depth, deltas, delta_const, index_ray, n, (int)bg_mode, bkgd, sample_index,
-                       out_rgb, out_alpha, out_depth, weights);
+                       qf_stream(stream), rgb_s, sigma, depth, deltas, delta_const, index_ray, n, n_rays, (int)bg_mode, bkgd,
+                       sample_index, out_rgb, out_alpha, out_depth, weights);
     QF_LAUNCH_CHECK();
     return QF_OK;
 }
@@ -548,7 +551,7 @@ namespace {
 
 __global__ void derive_properties_backward_kernel(const float *rgb_s, const float *sigma, const float *depth_s,
                                                   const float *deltas, float delta_const, const int64_t *index_ray,
-                                                  int64_t n, int bg_mode, const float *bkgd, const float *g_rgb,
+                                                  int64_t n, int64_t n_rays, int bg_mode, const float *bkgd, const float *g_rgb,
                                                   const float *g_alpha, const float *g_depth, float *grad_rgb_s,
                                                   float *grad_sigma, float *grad_depth_s)
 {
@@ -567,13 +570,15 @@ __global__ void derive_properties_backward_kernel(const float *rgb_s, const floa
             cb += w * rgb_s[end * 3 + 2];
             ca += w;
         }
-        const float gr = g_rgb[ray * 3 + 0], gg = g_rgb[ray * 3 + 1], gb = g_rgb[ray * 3 + 2];
-        const float gD = g_depth ? g_depth[ray] : 0.0f;
+        const bool in_image = ray >= 0 && ray < n_rays;      // a ray id outside the image has no output: zero gradient
+        const float gr = in_image ? g_rgb[ray * 3 + 0] : 0.0f, gg = in_image ? g_rgb[ray * 3 + 1] : 0.0f;
+        const float gb = in_image ? g_rgb[ray * 3 + 2] : 0.0f;
+        const float gD = (g_depth && in_image) ? g_depth[ray] : 0.0f;
         const bool plain = bg_mode == QF_BG_NONE;
         const float b0 = bg_mode == QF_BG_WHITE ? 1.0f : (bg_mode == QF_BG_CUSTOM ? bkgd[0] : 0.0f);
         const float b1 = bg_mode == QF_BG_WHITE ? 1.0f : (bg_mode == QF_BG_CUSTOM ? bkgd[1] : 0.0f);
         const float b2 = bg_mode == QF_BG_WHITE ? 1.0f : (bg_mode == QF_BG_CUSTOM ? bkgd[2] : 0.0f);
-        const float gA = (g_alpha ? g_alpha[ray] : 0.0f) +
+        const float gA = ((g_alpha && in_image) ? g_alpha[ray] : 0.0f) +
                          (plain ? 0.0f : gr * (cr - b0) + gg * (cg - b1) + gb * (cb - b2));
         const float gCr = plain ? gr : ca * gr, gCg = plain ? gg : ca * gg, gCb = plain ? gb : ca * gb;
         // backward sweep: cum holds the total optical depth; peel samples off the far end
@@ -599,16 +604,17 @@ __global__ void derive_properties_backward_kernel(const float *rgb_s, const floa
 
 extern "C" int qf_derive_properties_backward(const float *rgb_s, const float *sigma, const float *depth,
                                              const float *deltas, float delta_const, const int64_t *index_ray,
-                                             int64_t n, int32_t bg_mode, const float *bkgd, const float *g_rgb,
+                                             int64_t n, int64_t n_rays, int32_t bg_mode, const float *bkgd, const float *g_rgb,
                                              const float *g_alpha, const float *g_depth, float *grad_rgb_s,
                                              float *grad_sigma, float *grad_depth, void *stream)
 {
-    if (n < 0 || bg_mode < 0 || bg_mode > 3 || (bg_mode == QF_BG_CUSTOM && !bkgd)) return QF_ERR_INVALID_ARGUMENT;
+    if (n < 0 || n_rays < 0 || bg_mode < 0 || bg_mode > 3 || (bg_mode == QF_BG_CUSTOM && !bkgd)) return QF_ERR_INVALID_ARGUMENT;
     if (n == 0) return QF_OK;
+    if (n_rays == 0) return QF_ERR_INVALID_ARGUMENT;
     if (!rgb_s || !sigma || !depth || !index_ray || !g_rgb || !grad_rgb_s || !grad_sigma) return QF_ERR_INVALID_ARGUMENT;
     hipLaunchKernelGGL(derive_properties_backward_kernel, dim3(qf_grid_1d(n, 256)), dim3(256), 0, qf_stream(stream),
-                       rgb_s, sigma, depth, deltas, delta_const, index_ray, n, (int)bg_mode, bkgd, g_rgb, g_alpha, g_depth,
-                       grad_rgb_s, grad_sigma, grad_depth);
+                       rgb_s, sigma, depth, deltas, delta_const, index_ray, n, n_rays, (int)bg_mode, bkgd, g_rgb, g_alpha,
+                       g_depth, grad_rgb_s, grad_sigma, grad_depth);
     QF_LAUNCH_CHECK();
     return QF_OK;
 }

@@ -17,7 +17,6 @@
 namespace {
 
 constexpr int kMaxHits = QF_BVH_MAX_HITS;
-constexpr int kStack = QF_BVH_MAX_DEPTH;   // one deferred sibling per level; the builder bounds the depth (bvh.h)
 
 // fp32 Moller-Trumbore, operation order shared verbatim (as a contract, not as code) with the oracle.
 __device__ __forceinline__ bool mt_hit(const float4 a, const float4 b, const float4 c, const float ox, const float oy,
@@ -52,147 +51,274 @@ __device__ __forceinline__ float safe_inv(float d)
     return 1.0f / d;
 }
 
-// Conservative slab test: boxes were inflated on the host; the exit distance is widened by 2 ulp-ish.
-__device__ __forceinline__ bool box_hit(const float lox, const float loy, const float loz, const float hix,
-                                        const float hiy, const float hiz, const float ox, const float oy, const float oz,
-                                        const float ix, const float iy, const float iz, const float t_limit, float *t_near)
-{
-    const float ax = (lox - ox) * ix, bx = (hix - ox) * ix;
-    const float ay = (loy - oy) * iy, by = (hiy - oy) * iy;
-    const float az = (loz - oz) * iz, bz = (hiz - oz) * iz;
-    const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
-    const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz)) * 1.0000005f;
-    *t_near = tn;
-    return tn <= tf && tn * 0.999999f <= t_limit;
-}
-
 // (t, tri) lexicographic "a sorts before b"
 __device__ __forceinline__ bool hit_less(float ta, int ia, float tb, int ib) { return ta < tb || (ta == tb && ia < ib); }
 
-__global__ __launch_bounds__(64) void bvh_traverse_kernel(const float4 *__restrict__ nodes, const float4 *__restrict__ tris,
-                                                          int root_is_valid, const float *__restrict__ rays_o,
-                                                          const float *__restrict__ rays_d, int64_t n_rays, int max_hits,
-                                                          int image_width, int image_height, int tiles_x,
-                                                          int32_t *__restrict__ hit_tri, float *__restrict__ hit_t,
-                                                          int32_t *__restrict__ hit_count, int only_overflowed)
+// A hit as one 64-bit key: t > 0, so its bit pattern orders like its value, and the triangle id breaks ties --
+// key order IS the (t, tri) order of the contract.
+__device__ __forceinline__ uint64_t hit_key(float t, int id) { return ((uint64_t)__float_as_uint(t) << 32) | (uint32_t)id; }
+__device__ __forceinline__ float key_t(uint64_t k) { return __uint_as_float((uint32_t)(k >> 32)); }
+__device__ __forceinline__ int key_id(uint64_t k) { return (int)(uint32_t)k; }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Wide-BVH multi-hit traversal: EIGHT LANES PER RAY.  A node of the 8-wide tree (bvh.h) is 8 children x 32 B; lane j of
+// a ray's octet loads child j (the octet reads the node's 256 contiguous bytes), tests its box, and the octet's hit
+// mask comes out of one ballot.  A leaf holds up to 8 triangles: lane j runs the exact test on triangle j.  So one
+// dependent step decides 8 boxes or 8 triangles (the binary one-ray-per-lane walk of round 1 needed ~3 dependent node
+// fetches for the same decision and kept a 64-entry stack per LANE in scratch), a wave carries 8 rays instead of 64 --
+// eight times the waves for the same batch, which is what a latency-bound walk over a 2^17-ray training batch lacks --
+// and the per-ray state (stack, K-list) lives in LDS, shared by the octet:
+//   * stack: tokens of the hit children not taken yet; the nearest hit child is taken next (DPP min over the octet);
+//     the capacity is the tree's exact bound, computed by the builder (qf_bvh::max_stack8);
+//   * K-list: 64-bit (t, tri) keys, unordered while there is room, then K-nearest replacement with the worst entry
+//     found by the octet together; t_limit = the worst entry's t prunes boxes;
+//   * at the end the octet rank-sorts the list (each lane ranks every 8th entry) and writes the row ascending.
+// min_sep > 0 adds the reference's multi-hit rule (trimesh 3.23.5 ray_pyembree.intersects_id, called at
+// examples/mesh_utils.py:350-354): after a kept hit at t_prev the ray is re-originated min_sep past it, so the next
+// kept hit is the first with t > t_prev + min_sep -- hits closer than that, and the second copy of a duplicated face,
+// are never returned.  The chain runs over the sorted list; when the K-list was full and the chain kept fewer than K
+// the traversal runs again for the hits beyond the page (lower bound = the page's last key), until K are kept or a
+// page comes back not full.
+constexpr int kOctRays = 32;                    // rays per workgroup: 256 threads = 4 waves x 8 octets
+constexpr int kTravThreads = kOctRays * 8;
+constexpr int kDone = (int)0x80000000;          // == QF_BVH8_EMPTY; no leaf token takes this value (n_tri < 2^28)
+constexpr int kMaxPages = 4096;
+
+#define QF_DPP_QUAD_1032 0xB1
+#define QF_DPP_QUAD_2301 0x4E
+#define QF_DPP_HALF_MIRROR 0x141
+
+__device__ __forceinline__ unsigned oct_min_u32(unsigned v)
 {
-    // one wave = one 8x8 pixel tile (or 64 consecutive rays); serving fewer rays per wave is slower (8x4: +10 %,
-    // 4x4: +48 %): the traversal is bound by instruction issue, not by the latency of one wave's path
-    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, QF_DPP_QUAD_1032, 0xf, 0xf, true));
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, QF_DPP_QUAD_2301, 0xf, 0xf, true));
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, QF_DPP_HALF_MIRROR, 0xf, 0xf, true));
+    return v;
+}
+__device__ __forceinline__ unsigned oct_max_u32(unsigned v)
+{
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, QF_DPP_QUAD_1032, 0xf, 0xf, true));
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, QF_DPP_QUAD_2301, 0xf, 0xf, true));
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, QF_DPP_HALF_MIRROR, 0xf, 0xf, true));
+    return v;
+}
+template <int kCtrl>
+__device__ __forceinline__ uint64_t dpp_u64(uint64_t v)
+{
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)v, kCtrl, 0xf, 0xf, true);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(v >> 32), kCtrl, 0xf, 0xf, true);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t oct_max_u64(uint64_t v)
+{
+    uint64_t o = dpp_u64<QF_DPP_QUAD_1032>(v); v = o > v ? o : v;
+    o = dpp_u64<QF_DPP_QUAD_2301>(v); v = o > v ? o : v;
+    o = dpp_u64<QF_DPP_HALF_MIRROR>(v); v = o > v ? o : v;
+    return v;
+}
+// value of lane `src` (0..7) of this octet
+__device__ __forceinline__ int oct_bcast(int v, int oct_base, int src)
+{
+    return __builtin_amdgcn_ds_bpermute((oct_base + src) << 2, v);
+}
+// LDS written by one lane of the octet is read by the others: same wave, LDS operations complete in order; this only
+// keeps the compiler from moving them across each other
+__device__ __forceinline__ void oct_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+struct OctList {
+    uint64_t *keys;      // [K] in LDS
+    int K, j;
+    int count;           // entries in keys (octet-uniform)
+    uint64_t worst;      // valid when count == K: the largest key, at worst_slot
+    int worst_slot;
+
+    __device__ __forceinline__ void find_worst()
+    {
+        uint64_t m = 0;
+        int slot = 0;
+        for (int i = j; i < K; i += 8) {
+            const uint64_t k = keys[i];
+            if (k >= m) { m = k; slot = i; }
+        }
+        worst = oct_max_u64(m);
+        worst_slot = (int)oct_max_u32(m == worst ? (unsigned)slot : 0u);     // keys are unique: one lane holds it
+    }
+};
+
+__global__ __launch_bounds__(kTravThreads) void bvh8_traverse_kernel(
+    const float4 *__restrict__ nodes, const float4 *__restrict__ tris, int root_is_valid, const float *__restrict__ rays_o,
+    const float *__restrict__ rays_d, int64_t n_rays, int max_hits, int image_width, int image_height, int tiles_x,
+    int n_blocks, int blocks_per_xcd, int stack_cap, float min_sep, int32_t *__restrict__ hit_tri,
+    float *__restrict__ hit_t, int32_t *__restrict__ hit_count, int only_overflowed)
+{
+    extern __shared__ uint64_t trav_lds[];
+    const int K = max_hits;
+    const int tid = threadIdx.x, j = tid & 7, q = tid >> 3;
+    const int oct_base = (tid & 63) & 56;               // first lane of this octet within its wave
+    // XCD-aware block order: hardware deals workgroups round-robin to the 8 XCDs (private L2 each); XCD x walks the
+    // x-th CONTIGUOUS eighth of the blocks, i.e. one band of the image / one slice of the batch, so its L2 only has to
+    // hold that band's part of the tree
+    const int block = (int)(blockIdx.x & 7) * blocks_per_xcd + (int)(blockIdx.x >> 3);
+    if (block >= n_blocks) return;
     int64_t ray;
-    if (image_width > 0) {
-        const int64_t tile = tid >> 6;
-        const int in = (int)(tid & 63);
-        const int px = (int)(tile % tiles_x) * 8 + (in & 7);
-        const int py = (int)(tile / tiles_x) * 8 + (in >> 3);
+    if (image_width > 0) {          // workgroup = 8x4 pixels, wave = 4x2 pixels
+        const int w = q >> 3, r = q & 7;
+        const int px = (block % tiles_x) * 8 + (w & 1) * 4 + (r & 3);
+        const int py = (block / tiles_x) * 4 + (w >> 1) * 2 + (r >> 2);
         if (px >= image_width || py >= image_height) return;
         ray = (int64_t)py * image_width + px;
     } else {
-        ray = tid;
+        ray = (int64_t)block * kOctRays + q;
     }
     if (ray >= n_rays) return;
     // repair pass after the camera-coherent intersector: only the rays whose candidate list overflowed are traversed
-    if (only_overflowed && hit_count[ray] <= max_hits) return;
+    if (only_overflowed && hit_count[ray] <= K) return;
+
+    uint64_t *keys = trav_lds + (size_t)q * K;
+    uint64_t *sorted = trav_lds + (size_t)kOctRays * K + (size_t)q * K;          // only when min_sep > 0
+    int *stack = reinterpret_cast<int *>(trav_lds + (size_t)kOctRays * K * (min_sep > 0.0f ? 2 : 1)) + (size_t)q * stack_cap;
 
     const float ox = rays_o[ray * 3], oy = rays_o[ray * 3 + 1], oz = rays_o[ray * 3 + 2];
     const float dx = rays_d[ray * 3], dy = rays_d[ray * 3 + 1], dz = rays_d[ray * 3 + 2];
     const float ix = safe_inv(dx), iy = safe_inv(dy), iz = safe_inv(dz);
-    float *my_t = hit_t + ray * max_hits;
-    int32_t *my_tri = hit_tri + ray * max_hits;
+    const float nx = -(ox * ix), ny = -(oy * iy), nz = -(oz * iz);
+    float *my_t = hit_t + ray * K;
+    int32_t *my_tri = hit_tri + ray * K;
 
-    int count = 0;
-    float worst_t = INFINITY;      // valid once the list is full: its lexicographically largest entry
-    int worst_tri = 0x7fffffff, worst_slot = -1;
-    float t_limit = INFINITY;
+    OctList list;
+    list.keys = keys; list.K = K; list.j = j;
+    int kept = 0;                    // hits written so far (min_sep chain)
+    float last_t = 0.0f;             // t of the last kept hit
+    uint64_t lo_key = 0;             // page lower bound: only keys > lo_key are collected
+    float t_lo = 0.0f, t_accept = 0.0f;      // box pruning below the page / hits the chain would drop anyway
 
-    // "while-while" traversal: the inner loop walks inner nodes only, so the lanes of a wave stay together in it; a
-    // lane that reaches a leaf parks there until the others have one too (or are done), and the triangle tests then
-    // run for all of them at once.  Leaves travel through `cur` and the stack as negative tokens
-    // ~(first * 8 + count - 1) (count <= QF_BVH_LEAF_MAX = 4 <= 8; first < 2^28, checked on the host).
-    constexpr int kDone = (int)0x80000000;
-    int stack[kStack];
-    int sp = 0;
-    int cur = root_is_valid ? 0 : kDone;
-    while (cur != kDone) {
-        while (cur >= 0) {
-            const float4 n0 = nodes[cur * 4 + 0];   // c0.lo.xyz, c0.hi.x
-            const float4 n1 = nodes[cur * 4 + 1];   // c0.hi.yz, c1.lo.xy
-            const float4 n2 = nodes[cur * 4 + 2];   // c1.lo.z, c1.hi.xyz
-            const float4 n3 = nodes[cur * 4 + 3];   // child0, child1, count0, count1 (int bits)
-            float tn0, tn1;
-            const bool h0 = box_hit(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, ox, oy, oz, ix, iy, iz, t_limit, &tn0);
-            const bool h1 = box_hit(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, ox, oy, oz, ix, iy, iz, t_limit, &tn1);
-            const int c0 = __float_as_int(n3.x), c1 = __float_as_int(n3.y);
-            const int k0 = __float_as_int(n3.z), k1 = __float_as_int(n3.w);
-            // tokens: inner child = its index; leaf = ~(first * 8 + count - 1); an empty leaf never passes box_hit
-            const int tok0 = c0 >= 0 ? c0 : ~(((~c0) << 3) | ((k0 - 1) & 7));
-            const int tok1 = c1 >= 0 ? c1 : ~(((~c1) << 3) | ((k1 - 1) & 7));
-            const bool v0 = h0 && (c0 >= 0 || k0 > 0), v1 = h1 && (c1 >= 0 || k1 > 0);
-            if (v0 && v1) {
-                const bool first0 = tn0 <= tn1;
-                cur = first0 ? tok0 : tok1;
-                if (sp < kStack) stack[sp++] = first0 ? tok1 : tok0;
-            } else if (v0) {
-                cur = tok0;
-            } else if (v1) {
-                cur = tok1;
-            } else {
-                cur = sp > 0 ? stack[--sp] : kDone;
-            }
-        }
-        if (cur == kDone) break;
-        {
-            const int packed = ~cur;
-            const int first = packed >> 3, cnt = (packed & 7) + 1;
-            for (int k = 0; k < cnt; ++k) {
-                const float4 a = tris[(first + k) * 3 + 0];
-                const float4 b = tris[(first + k) * 3 + 1];
-                const float4 c = tris[(first + k) * 3 + 2];
-                float t;
-                if (!mt_hit(a, b, c, ox, oy, oz, dx, dy, dz, &t)) continue;
-                const int id = __float_as_int(a.w);
-                if (count < max_hits) {
-                    my_t[count] = t;
-                    my_tri[count] = id;
-                    ++count;
-                    if (count == max_hits) worst_slot = -1;   // recompute below
-                } else if (hit_less(t, id, worst_t, worst_tri)) {
-                    my_t[worst_slot] = t;
-                    my_tri[worst_slot] = id;
-                    worst_slot = -1;
-                } else {
+    for (int page = 0; page < kMaxPages; ++page) {
+        list.count = 0;
+        list.worst = ~0ull;
+        list.worst_slot = 0;
+        float t_limit = INFINITY;
+        int sp = 0;
+        int cur = root_is_valid ? 0 : kDone;
+        while (cur != kDone) {
+            while (cur >= 0) {
+                const float4 *np = nodes + (size_t)cur * 16 + j * 2;
+                const float4 a = np[0];                 // lo.xyz, hi.x
+                const float4 b = np[1];                 // hi.yz, token, 0
+                const float ax = __builtin_fmaf(a.x, ix, nx), bx = __builtin_fmaf(a.w, ix, nx);
+                const float ay = __builtin_fmaf(a.y, iy, ny), by = __builtin_fmaf(b.x, iy, ny);
+                const float az = __builtin_fmaf(a.z, iz, nz), bz = __builtin_fmaf(b.y, iz, nz);
+                const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
+                const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz)) * 1.0000005f;
+                const int tok = __float_as_int(b.z);
+                // conservative: the boxes were inflated on the host, the exit distance is widened, NaN counts as a hit
+                const bool hit = tok != kDone && !(tn > tf) && !(tn * 0.999999f > t_limit) && !(tf < t_lo);
+                const unsigned m8 = (unsigned)(__ballot(hit) >> oct_base) & 0xffu;
+                if (m8 == 0) {
+                    cur = kDone;
+                    if (sp > 0) cur = stack[--sp];
                     continue;
                 }
-                if (count == max_hits && worst_slot < 0) {
-                    worst_t = -INFINITY;
-                    worst_tri = -1;
-                    for (int s = 0; s < max_hits; ++s) {
-                        const float ts = my_t[s];
-                        const int is = my_tri[s];
-                        if (hit_less(worst_t, worst_tri, ts, is)) { worst_t = ts; worst_tri = is; worst_slot = s; }
+                const int n = __popc(m8);
+                const unsigned key = hit ? ((__float_as_uint(tn) & ~7u) | (unsigned)j) : 0xffffffffu;
+                const int nearest = (int)(oct_min_u32(key) & 7u);
+                if (hit && j != nearest) {
+                    const unsigned others = m8 & ~(1u << nearest);
+                    stack[sp + __popc(others & ((1u << j) - 1u))] = tok;
+                }
+                sp += n - 1;
+                cur = oct_bcast(tok, oct_base, nearest);
+                oct_lds_sync();
+            }
+            if (cur == kDone) break;
+            {
+                const int packed = ~cur;
+                const int first = packed >> 3, cnt = (packed & 7) + 1;
+                bool h = false;
+                uint64_t key = 0;
+                if (j < cnt) {
+                    const float4 a = tris[(size_t)(first + j) * 3 + 0];
+                    const float4 b = tris[(size_t)(first + j) * 3 + 1];
+                    const float4 c = tris[(size_t)(first + j) * 3 + 2];
+                    float t;
+                    if (mt_hit(a, b, c, ox, oy, oz, dx, dy, dz, &t)) {
+                        key = hit_key(t, __float_as_int(a.w));
+                        h = key > lo_key && t > t_accept && key < list.worst;
                     }
-                    t_limit = worst_t;
+                }
+                const unsigned m8 = (unsigned)(__ballot(h) >> oct_base) & 0xffu;
+                if (m8) {
+                    const int n = __popc(m8);
+                    if (list.count + n <= K) {
+                        if (h) keys[list.count + __popc(m8 & ((1u << j) - 1u))] = key;
+                        list.count += n;
+                        oct_lds_sync();
+                        if (list.count == K) list.find_worst();
+                    } else {                                    // the list fills up or is full: one hit at a time
+                        for (unsigned mm = m8; mm; mm &= mm - 1u) {
+                            const int src = __ffs(mm) - 1;
+                            const uint64_t k = ((uint64_t)(unsigned)oct_bcast((int)(unsigned)(key >> 32), oct_base, src) << 32) |
+                                               (unsigned)oct_bcast((int)(unsigned)key, oct_base, src);
+                            if (list.count < K) {
+                                if (j == 0) keys[list.count] = k;
+                                ++list.count;
+                                oct_lds_sync();
+                                if (list.count == K) list.find_worst();
+                            } else if (k < list.worst) {
+                                if (j == 0) keys[list.worst_slot] = k;
+                                oct_lds_sync();
+                                list.find_worst();
+                            }
+                        }
+                    }
+                    if (list.count == K) t_limit = key_t(list.worst);
                 }
             }
+            cur = kDone;
+            if (sp > 0) cur = stack[--sp];
         }
-        cur = sp > 0 ? stack[--sp] : kDone;
-    }
 
-    // ascending (t, tri); pad the tail
-    for (int i = 1; i < count; ++i) {
-        const float t = my_t[i];
-        const int id = my_tri[i];
-        int j = i - 1;
-        while (j >= 0 && hit_less(t, id, my_t[j], my_tri[j])) {
-            my_t[j + 1] = my_t[j];
-            my_tri[j + 1] = my_tri[j];
-            --j;
+        // rank sort of the page: lane j ranks entries j, j+8, ... (keys are unique, so the ranks are a permutation)
+        const int count = list.count;
+        if (!(min_sep > 0.0f)) {
+            for (int e = j; e < count; e += 8) {
+                const uint64_t k = keys[e];
+                int rank = 0;
+                for (int i = 0; i < count; ++i) rank += keys[i] < k ? 1 : 0;
+                my_t[rank] = key_t(k);
+                my_tri[rank] = key_id(k);
+            }
+            kept = count;
+            break;
         }
-        my_t[j + 1] = t;
-        my_tri[j + 1] = id;
+        for (int e = j; e < count; e += 8) {
+            const uint64_t k = keys[e];
+            int rank = 0;
+            for (int i = 0; i < count; ++i) rank += keys[i] < k ? 1 : 0;
+            sorted[rank] = k;
+        }
+        oct_lds_sync();
+        // the re-origin chain, front to back (octet-uniform; lane 0 writes)
+        for (int i = 0; i < count && kept < K; ++i) {
+            const uint64_t k = sorted[i];
+            const float t = key_t(k);
+            if (kept == 0 || t > last_t + min_sep) {
+                if (j == 0) { my_t[kept] = t; my_tri[kept] = key_id(k); }
+                ++kept;
+                last_t = t;
+            }
+        }
+        if (count < K || kept >= K) break;          // every hit of the ray has been seen, or K are kept
+        lo_key = sorted[K - 1];
+        t_lo = key_t(lo_key) * 0.999999f;
+        t_accept = last_t + min_sep;                // anything closer is dropped by the chain whatever follows
+        oct_lds_sync();
     }
-    for (int i = count; i < max_hits; ++i) { my_t[i] = INFINITY; my_tri[i] = -1; }
-    hit_count[ray] = count;
+    for (int i = kept + j; i < K; i += 8) { my_t[i] = INFINITY; my_tri[i] = -1; }
+    if (j == 0) hit_count[ray] = kept;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -316,7 +442,7 @@ __global__ __launch_bounds__(256) void raster_kernel(const float4 *__restrict__ 
 // running entries in a private LDS column.  Rays that lost candidates even at `wide` keep count > K and go to
 // qf_bvh_repair_overflow.
 constexpr int kSelectBlock = 64;     // one wave: K = 64 needs 32 KB of LDS
-__global__ __launch_bounds__(kSelectBlock) void select_nearest_kernel(int64_t n_rays, int wide, int max_hits,
+__global__ __launch_bounds__(kSelectBlock) void select_nearest_kernel(int64_t n_rays, int wide, int max_hits, float min_sep,
                                                                       const int32_t *__restrict__ wide_tri,
                                                                       const float *__restrict__ wide_t,
                                                                       int32_t *__restrict__ hit_tri, float *__restrict__ hit_t,
@@ -361,6 +487,30 @@ __global__ __launch_bounds__(kSelectBlock) void select_nearest_kernel(int64_t n_
             if (hit_less(worst_t, worst_i, ts, is)) { worst_t = ts; worst_i = is; worst_slot = s; }
         }
     }
+    if (min_sep > 0.0f) {
+        // The re-origin rule (bvh8_traverse_kernel) runs over a ray's hits in ascending order; with more than K
+        // candidates the K nearest only decide it if the chain keeps all of them.  Sort the column, run the chain; if
+        // it drops anything the ray goes to the paged BVH traversal (count > K marks it for qf_bvh_repair_overflow).
+        for (int i = 1; i < max_hits; ++i) {
+            const float t = lt[i * kSelectBlock];
+            const int id = li[i * kSelectBlock];
+            int j = i - 1;
+            while (j >= 0 && hit_less(t, id, lt[j * kSelectBlock], li[j * kSelectBlock])) {
+                lt[(j + 1) * kSelectBlock] = lt[j * kSelectBlock];
+                li[(j + 1) * kSelectBlock] = li[j * kSelectBlock];
+                --j;
+            }
+            lt[(j + 1) * kSelectBlock] = t;
+            li[(j + 1) * kSelectBlock] = id;
+        }
+        float last_t = lt[0];
+        bool dropped = false;
+        for (int i = 1; i < max_hits; ++i) {
+            const float t = lt[i * kSelectBlock];
+            if (t > last_t + min_sep) last_t = t; else dropped = true;
+        }
+        if (dropped) return;                 // hit_count[r] stays > K
+    }
     for (int i = 0; i < max_hits; ++i) {
         row_t[i] = lt[i * kSelectBlock];
         row_i[i] = li[i * kSelectBlock];
@@ -368,27 +518,58 @@ __global__ __launch_bounds__(kSelectBlock) void select_nearest_kernel(int64_t n_
     hit_count[r] = max_hits;
 }
 
-// In-place ascending (t, tri) sort of every ray's (unordered) list, padding and count clamp.
-__global__ void sort_hits_kernel(int64_t n_rays, int max_hits, int32_t *hit_tri, float *hit_t, int32_t *hit_count)
+// In-place ascending (t, tri) sort of every ray's (unordered) list, the re-origin rule (min_sep > 0: keep a hit iff it
+// is the first or lies more than min_sep behind the last kept one -- see bvh8_traverse_kernel), padding and count
+// clamp.  Exact for rays whose list holds ALL their hits (count <= K); the camera-coherent path sends every other ray
+// through the BVH repair first.  A workgroup stages 128 rays' rows in LDS (coalesced both ways), lane = ray.
+constexpr int kFilterRays = 128;
+__global__ __launch_bounds__(kFilterRays) void filter_hits_kernel(int64_t n_rays, int max_hits, float min_sep,
+                                                                  int32_t *__restrict__ hit_tri, float *__restrict__ hit_t,
+                                                                  int32_t *__restrict__ hit_count)
 {
-    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_rays; r += (int64_t)gridDim.x * blockDim.x) {
-        int cnt = hit_count[r];
-        if (cnt > max_hits) { cnt = max_hits; hit_count[r] = cnt; }
-        float *my_t = hit_t + r * max_hits;
-        int32_t *my_tri = hit_tri + r * max_hits;
+    extern __shared__ __attribute__((aligned(16))) unsigned char filter_smem[];
+    const int K = max_hits, Kp = max_hits | 1;
+    float *s_t = reinterpret_cast<float *>(filter_smem);
+    int32_t *s_tri = reinterpret_cast<int32_t *>(s_t + kFilterRays * Kp);
+    const int tid = threadIdx.x;
+    const int64_t ray0 = (int64_t)blockIdx.x * kFilterRays;
+    const int nr = (int)((n_rays - ray0) < kFilterRays ? (n_rays - ray0) : kFilterRays);
+    for (int i = tid; i < nr * K; i += kFilterRays) {
+        const int r = i / K, k = i - r * K;
+        s_t[r * Kp + k] = hit_t[ray0 * K + i];
+        s_tri[r * Kp + k] = hit_tri[ray0 * K + i];
+    }
+    __syncthreads();
+    if (tid < nr) {
+        int cnt = hit_count[ray0 + tid];
+        if (cnt > K) cnt = K;
+        float *row_t = s_t + tid * Kp;
+        int32_t *row_i = s_tri + tid * Kp;
         for (int i = 1; i < cnt; ++i) {
-            const float t = my_t[i];
-            const int id = my_tri[i];
+            const float t = row_t[i];
+            const int id = row_i[i];
             int j = i - 1;
-            while (j >= 0 && hit_less(t, id, my_t[j], my_tri[j])) {
-                my_t[j + 1] = my_t[j];
-                my_tri[j + 1] = my_tri[j];
-                --j;
-            }
-            my_t[j + 1] = t;
-            my_tri[j + 1] = id;
+            while (j >= 0 && hit_less(t, id, row_t[j], row_i[j])) { row_t[j + 1] = row_t[j]; row_i[j + 1] = row_i[j]; --j; }
+            row_t[j + 1] = t;
+            row_i[j + 1] = id;
         }
-        for (int i = cnt; i < max_hits; ++i) { my_t[i] = INFINITY; my_tri[i] = -1; }
+        if (min_sep > 0.0f && cnt > 1) {
+            int kept = 1;
+            float last_t = row_t[0];
+            for (int i = 1; i < cnt; ++i) {
+                const float t = row_t[i];
+                if (t > last_t + min_sep) { row_t[kept] = t; row_i[kept] = row_i[i]; ++kept; last_t = t; }
+            }
+            cnt = kept;
+        }
+        for (int i = cnt; i < K; ++i) { row_t[i] = INFINITY; row_i[i] = -1; }
+        hit_count[ray0 + tid] = cnt;
+    }
+    __syncthreads();
+    for (int i = tid; i < nr * K; i += kFilterRays) {
+        const int r = i / K, k = i - r * K;
+        hit_t[ray0 * K + i] = s_t[r * Kp + k];
+        hit_tri[ray0 * K + i] = s_tri[r * Kp + k];
     }
 }
 
@@ -893,21 +1074,51 @@ static int bvh_launch(const qf_bvh *bvh, const float *rays_o, const float *rays_
     if (n_rays == 0) return QF_OK;
     if (!rays_o || !rays_d || !hit_tri || !hit_t || !hit_count) return QF_ERR_INVALID_ARGUMENT;
     int height = 0, tiles_x = 0;
-    int64_t threads = n_rays;
+    int64_t n_blocks = qf_div_up(n_rays, kOctRays);
     if (image_width > 0) {
         if (n_rays % image_width) return QF_ERR_INVALID_ARGUMENT;
         height = (int)(n_rays / image_width);
         tiles_x = (image_width + 7) / 8;
-        threads = (int64_t)tiles_x * ((height + 7) / 8) * 64;
+        n_blocks = (int64_t)tiles_x * ((height + 3) / 4);
     }
-    const int64_t blocks = qf_div_up(threads, 64);
-    if (blocks > 0x7fffffff) return QF_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(bvh_traverse_kernel, dim3((unsigned)blocks), dim3(64), 0, qf_stream(stream),
-                       reinterpret_cast<const float4 *>(bvh->d_nodes), reinterpret_cast<const float4 *>(bvh->d_tris),
+    const int64_t per_xcd = qf_div_up(n_blocks, 8);
+    if (per_xcd * 8 > 0x7fffffff) return QF_ERR_UNSUPPORTED;
+    const bool sep = bvh->min_sep > 0.0f;
+    const int stack_cap = (bvh->max_stack8 < 2 ? 2 : bvh->max_stack8) | 1;       // odd row stride
+    const size_t lds = (size_t)kOctRays * ((size_t)max_hits * 8 * (sep ? 2 : 1) + (size_t)stack_cap * 4);
+    if (lds > 160 * 1024) return QF_ERR_UNSUPPORTED;
+    if (lds > 48 * 1024)
+        QF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(bvh8_traverse_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(bvh8_traverse_kernel, dim3((unsigned)(per_xcd * 8)), dim3(kTravThreads), lds, qf_stream(stream),
+                       reinterpret_cast<const float4 *>(bvh->d_nodes8), reinterpret_cast<const float4 *>(bvh->d_tris),
                        bvh->n_tri > 0 ? 1 : 0, rays_o, rays_d, n_rays, (int)max_hits, (int)image_width, height, tiles_x,
-                       hit_tri, hit_t, hit_count, only_overflowed);
+                       (int)n_blocks, (int)per_xcd, stack_cap, sep ? bvh->min_sep : 0.0f, hit_tri, hit_t, hit_count,
+                       only_overflowed);
     QF_LAUNCH_CHECK();
     return QF_OK;
+}
+
+static int filter_launch(int64_t n_rays, int32_t max_hits, float min_sep, int32_t *hit_tri, float *hit_t,
+                         int32_t *hit_count, hipStream_t st)
+{
+    const int Kp = max_hits | 1;
+    const size_t lds = (size_t)kFilterRays * Kp * 8;
+    const int64_t blocks = qf_div_up(n_rays, kFilterRays);
+    if (blocks > 0x7fffffff) return QF_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(filter_hits_kernel, dim3((unsigned)blocks), dim3(kFilterRays), lds, st, n_rays, (int)max_hits, min_sep,
+                       hit_tri, hit_t, hit_count);
+    QF_LAUNCH_CHECK();
+    return QF_OK;
+}
+
+extern "C" int qf_filter_hits(const qf_bvh *bvh, int64_t n_rays, int32_t max_hits, int32_t *hit_tri, float *hit_t,
+                              int32_t *hit_count, void *stream)
+{
+    if (!bvh || n_rays < 0 || max_hits < 1 || max_hits > kMaxHits) return QF_ERR_INVALID_ARGUMENT;
+    if (n_rays == 0 || !(bvh->min_sep > 0.0f)) return QF_OK;       // rule off: the lists stay as they are
+    if (!hit_tri || !hit_t || !hit_count) return QF_ERR_INVALID_ARGUMENT;
+    return filter_launch(n_rays, max_hits, bvh->min_sep, hit_tri, hit_t, hit_count, qf_stream(stream));
 }
 
 extern "C" int qf_bvh_intersect(const qf_bvh *bvh, const float *rays_o, const float *rays_d, int64_t n_rays,
@@ -1096,11 +1307,7 @@ extern "C" int qf_raster_intersect(const qf_bvh *bvh, const qf_camera *cam, cons
     hipStream_t st = qf_stream(stream);
     const int rc = raster_launch(bvh, cam, rays_o, rays_d, n_rays, (int)max_hits, false, hit_tri, hit_t, hit_count, overflow, st);
     if (rc != QF_OK) return rc;
-    if (sort_lists) {
-        hipLaunchKernelGGL(sort_hits_kernel, dim3(qf_grid_1d(n_rays, 256)), dim3(256), 0, st, n_rays, (int)max_hits,
-                           hit_tri, hit_t, hit_count);
-        QF_LAUNCH_CHECK();
-    }
+    if (sort_lists && n_rays > 0) return filter_launch(n_rays, max_hits, bvh->min_sep, hit_tri, hit_t, hit_count, st);
     return QF_OK;
 }
 
@@ -1119,7 +1326,7 @@ extern "C" int qf_raster_intersect_wide(const qf_bvh *bvh, const qf_camera *cam,
     if (n_rays == 0) return QF_OK;
     const size_t lds = (size_t)max_hits * kSelectBlock * 2 * sizeof(float);       // <= 32 KB at K = 64
     hipLaunchKernelGGL(select_nearest_kernel, dim3((unsigned)qf_div_up(n_rays, kSelectBlock)), dim3(kSelectBlock), lds, st,
-                       n_rays, (int)wide_hits, (int)max_hits, wide_tri, wide_t, hit_tri, hit_t, hit_count);
+                       n_rays, (int)wide_hits, (int)max_hits, bvh->min_sep, wide_tri, wide_t, hit_tri, hit_t, hit_count);
     QF_LAUNCH_CHECK();
     return QF_OK;
 }

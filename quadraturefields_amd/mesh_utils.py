@@ -36,16 +36,54 @@ def make_camera(c2w, focal: float, width: int, height: int) -> _C.Camera:
     return cam
 
 
+def _on_device(fn):
+    """Run a method with the intersector's device current: its kernels launch on that device's stream (a caller whose
+    current device is another GPU would otherwise launch on the wrong one with this device's pointers)."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(self, *args, **kwargs):
+        with torch.cuda.device(self.device):
+            return fn(self, *args, **kwargs)
+    return wrapped
+
+
+def trimesh_ray_offset(vertices) -> float:
+    """The distance trimesh 3.23.5 re-originates a ray past each hit in ``RayMeshIntersector.intersects_id``
+    (``ray_pyembree.py``: ``clip(_ray_offset_factor * self._scale, _ray_offset_floor, inf)`` with
+    ``_ray_offset_factor = 1e-4``, ``_ray_offset_floor = 1e-8`` and ``_scale = 100 / mesh.scale``, ``mesh.scale`` = the
+    length of the bounding-box diagonal).  Hits closer than this to the previously returned hit are skipped by the
+    reference.  Restated from memory -- trimesh is not in the container: parity unpinned."""
+    v = np.asarray(vertices, dtype=np.float64).reshape(-1, 3)
+    if v.shape[0] == 0:
+        return 1e-8
+    diag = float(np.sqrt(((v.max(axis=0) - v.min(axis=0)) ** 2).sum()))
+    if not diag > 0:
+        return 1e-8
+    return float(np.clip(1e-4 * (100.0 / diag), 1e-8, np.inf))
+
+
 class RayIntersector:
     """Multi-hit ray/mesh intersector.  Duck-types trimesh's ``RayMeshIntersector`` and the reference's OptiX
-    adapter (``intersects_id``, ``update_intersector``; mesh_utils.py:75-109)."""
+    adapter (``intersects_id``, ``update_intersector``; mesh_utils.py:75-109).
 
-    def __init__(self, mesh: TriMesh, max_hits: int = 10, device="cuda:0", sah_depth: int = 32):
+    ``min_separation``: the reference's multi-hit rule (``qf_bvh_set_min_separation``): ``"trimesh"`` (default) =
+    ``trimesh_ray_offset(mesh.vertices)``, a float = that distance, ``0`` / ``None`` = every hit counts."""
+
+    def __init__(self, mesh: TriMesh, max_hits: int = 10, device="cuda:0", sah_depth: int = 32,
+                 min_separation="trimesh"):
         if max_hits < 1 or max_hits > _C.QF_BVH_MAX_HITS:
             raise ValueError(f"max_hits must be in 1..{_C.QF_BVH_MAX_HITS}")
         self.mesh = mesh
         self.max_hits = int(max_hits)
         self.device = torch.device(device)
+        if min_separation is None:
+            min_separation = 0.0
+        elif isinstance(min_separation, str):
+            if min_separation != "trimesh":
+                raise ValueError("min_separation: 'trimesh', a distance, 0 or None")
+            min_separation = trimesh_ray_offset(mesh.vertices)
+        self.min_separation = max(float(min_separation), 0.0)
         self.last_order = None           # coherent processing order of the most recent image-shaped sample_device()
         self._raster_backoff = 0         # frames left to skip the camera-coherent intersector after an overflow
         self.repaired_frames = 0         # frames on which some pixels overflowed K and were repaired through the BVH
@@ -60,6 +98,7 @@ class RayIntersector:
         with torch.cuda.device(self.device):
             _C.check(_C.lib().qf_bvh_create_ex(tri.ctypes.data_as(ctypes.c_void_p), tri.shape[0], int(sah_depth),
                                                ctypes.byref(self._handle)), "qf_bvh_create_ex")
+            _C.check(_C.lib().qf_bvh_set_min_separation(self._handle, self.min_separation), "qf_bvh_set_min_separation")
 
     def __del__(self):
         h = getattr(self, "_handle", None)
@@ -78,15 +117,42 @@ class RayIntersector:
     def max_depth(self) -> int:
         return int(_C.lib().qf_bvh_max_depth(self._handle))
 
+    @property
+    def num_wide_nodes(self) -> int:
+        return int(_C.lib().qf_bvh_num_wide_nodes(self._handle))
+
+    @property
+    def max_stack(self) -> int:
+        return int(_C.lib().qf_bvh_max_stack(self._handle))
+
+    def set_min_separation(self, min_separation: float) -> None:
+        self.min_separation = max(float(min_separation or 0.0), 0.0)
+        _C.check(_C.lib().qf_bvh_set_min_separation(self._handle, self.min_separation), "qf_bvh_set_min_separation")
+
     def update_intersector(self, vertices) -> None:
         """New vertex positions, same faces (Intersector.update_vertices; train_finetune.py:716-718).
-        ``vertices``: [V,3] vertex array, or the flattened [F*9] triangle soup the OptiX module took."""
-        v = np.asarray(vertices, dtype=np.float32)
-        if v.size == self.mesh.faces.shape[0] * 9 and v.shape != tuple(self.mesh.vertices.shape):
+        ``vertices``: [V,3] vertex array, or the flattened [F*9] triangle soup the OptiX module took.  A tensor on this
+        intersector's device is refitted ON the device, stream-ordered (``qf_bvh_refit_device``: no D2H / host refit /
+        H2D round trip in the training loop); host arrays take the host refit."""
+        n_tri = self.mesh.faces.shape[0]
+        if isinstance(vertices, torch.Tensor) and vertices.is_cuda:
+            v = vertices.detach().to(device=self.device, dtype=torch.float32)
+            if v.numel() == n_tri * 9 and tuple(v.shape) != tuple(self.mesh.vertices.shape):
+                tri = v.reshape(-1, 9).contiguous()
+            else:
+                if getattr(self, "_faces_dev", None) is None:
+                    self._faces_dev = torch.from_numpy(np.ascontiguousarray(self.mesh.faces, dtype=np.int64)).to(self.device)
+                tri = v.reshape(-1, 3)[self._faces_dev].reshape(-1, 9).contiguous()
+            with torch.cuda.device(self.device):
+                _C.check(_C.lib().qf_bvh_refit_device(self._handle, _C.ptr(tri), n_tri, _C.stream()), "qf_bvh_refit_device")
+            return
+        v = np.asarray(vertices.detach().cpu() if isinstance(vertices, torch.Tensor) else vertices, dtype=np.float32)
+        if v.size == n_tri * 9 and v.shape != tuple(self.mesh.vertices.shape):
             tri = np.ascontiguousarray(v.reshape(-1, 9))
         else:
             tri = np.ascontiguousarray(v.reshape(-1, 3)[self.mesh.faces].reshape(-1, 9))
-        _C.check(_C.lib().qf_bvh_refit(self._handle, tri.ctypes.data_as(ctypes.c_void_p), tri.shape[0]), "qf_bvh_refit")
+        with torch.cuda.device(self.device):
+            _C.check(_C.lib().qf_bvh_refit(self._handle, tri.ctypes.data_as(ctypes.c_void_p), tri.shape[0]), "qf_bvh_refit")
 
     #: After a frame on which some pixel collected more than K candidates (the camera-coherent pass is then wasted and
     #: the BVH answers) the next frames go straight to the BVH: 1 frame after an isolated overflow, doubling while the
@@ -120,6 +186,7 @@ class RayIntersector:
                 torch.empty((n, k), dtype=torch.float32, device=self.device),
                 torch.empty((n,), dtype=torch.int32, device=self.device))
 
+    @_on_device
     def _hits_bvh(self, o, d, k, image_width):
         n = o.shape[0]
         hit_tri, hit_t, hit_count = self._alloc_hits(n, k)
@@ -128,6 +195,7 @@ class RayIntersector:
                  "qf_bvh_intersect")
         return hit_tri, hit_t, hit_count
 
+    @_on_device
     def _hits_raster(self, o, d, k, camera, sort_lists=True):
         """Camera-coherent path; returns the lists plus the device overflow counter (unchecked).
         sort_lists=False leaves the lists in arrival order for qf_pack_samples (which sorts while packing)."""
@@ -139,6 +207,7 @@ class RayIntersector:
                                               1 if sort_lists else 0, _C.stream()), "qf_raster_intersect")
         return hit_tri, hit_t, hit_count, overflow
 
+    @_on_device
     def hits(self, origins, vectors, max_hits: Optional[int] = None, image_width: int = 0, camera=None):
         """Device result: (hit_tri [R,K] int32 (-1 pad), hit_t [R,K] fp32 (+inf pad), hit_count [R] int32, o, d),
         each ray's hits ascending in (t, triangle id).  ``camera`` (see ``make_camera``) selects the
@@ -181,6 +250,7 @@ class RayIntersector:
                 self._scratch.pop(next(iter(self._scratch)))
         return s
 
+    @_on_device
     def _hits_raster_frame(self, o, d, k, camera):
         """Camera-coherent pass whose overflow counter lives next to the frame's sample total (one readback)."""
         n = o.shape[0]
@@ -208,6 +278,9 @@ class RayIntersector:
         _C.check(_C.lib().qf_bvh_repair_overflow(self._handle, _C.ptr(o), _C.ptr(d), n, k, int(camera.width),
                                                  _C.ptr(hit_tri), _C.ptr(hit_t), _C.ptr(hit_count), _C.stream()),
                  "qf_bvh_repair_overflow")
+        if self.min_separation > 0:     # the reference's re-origin rule on the (now complete) lists; no launch when off
+            _C.check(_C.lib().qf_filter_hits(self._handle, n, k, _C.ptr(hit_tri), _C.ptr(hit_t), _C.ptr(hit_count),
+                                             _C.stream()), "qf_filter_hits")
         return hit_tri, hit_t, hit_count, overflow
 
     def pack_hits(self, o, d, k, hit_tri, hit_t, hit_count, overflow, width, lean=False, layout=True):
@@ -222,6 +295,7 @@ class RayIntersector:
         that keep several frames in flight on different streams."""
         return self.pack_hits_end(self.pack_hits_begin(o, d, k, hit_tri, hit_t, hit_count, overflow, width, lean, layout))
 
+    @_on_device
     def pack_hits_begin(self, o, d, k, hit_tri, hit_t, hit_count, overflow, width, lean=False, layout=True):
         """Enqueue scan, readback, pack and ordering on the current stream; no host wait.  ``lean`` (image-shaped
         batches only): skip the ray-major xyz / dirs / origins arrays -- a caller that only renders reads the copies
@@ -261,6 +335,7 @@ class RayIntersector:
         return (o, d, k, width, (lean, want_layout), host, ev, [xyz, dirs, index_ray, depth, index_tri, org], order, layout,
                 (hit_tri, hit_t, hit_count))          # the lists stay referenced until the kernels reading them ran
 
+    @_on_device
     def pack_hits_end(self, pending):
         """Wait for the 16-byte readback of ``pack_hits_begin`` and slice the results (same stream as ``begin``)."""
         o, d, k, width, lean, host, ev, arrays, order, layout, _lists = pending
@@ -281,6 +356,7 @@ class RayIntersector:
             self.last_layout = tuple(t[:total] for t in layout)
         return [None if t is None else t[:total] for t in arrays], (order[:total] if order is not None else None)
 
+    @_on_device
     def sample_device(self, origins, vectors, max_hits: Optional[int] = None, image_width: int = 0, camera=None,
                       lean: bool = False, layout: bool = True):
         """Packed, sorted samples on the device: [xyzs, dirs, index_ray, ts, index_tri, origins] -- the six
@@ -303,6 +379,7 @@ class RayIntersector:
                                                layout)
         return data
 
+    @_on_device
     def coherent_layout(self, hit_count, ray_offset, total: int, width: int):
         """``coherent_order`` and its inverse map (``inverse[sample] = position``).  Given the inverse,
         ``qf_pack_samples`` also writes ``xyz[order]`` / ``dirs[order]``, so ``field(xyz_c, dirs_c)`` reads and writes
@@ -320,6 +397,7 @@ class RayIntersector:
                                              _C.ptr(order), _C.ptr(inverse), _C.stream()), "qf_coherent_layout")
         return order, inverse
 
+    @_on_device
     def coherent_order(self, hit_count: torch.Tensor, ray_offset: torch.Tensor, total: int, width: int) -> torch.Tensor:
         """int32 permutation of the ``total`` packed samples of a row-major ``width``-wide image, ordered
         (8x8 tile, hit rank, pixel).  Handing it to ``radiance_field(points, dirs, order=...)`` makes the points of
@@ -384,7 +462,7 @@ class MeshIntersection:
     ``TriMesh``.  ``optix`` is accepted and ignored: there is one intersector, the gfx950 BVH."""
 
     def __init__(self, mesh_path, simplify_mesh=True, scale=1.0, num_repeat=16, optix=False, voxel_size=512,
-                 num_intersections=20, render_step_size=0.005, device="cuda:0"):
+                 num_intersections=20, render_step_size=0.005, device="cuda:0", min_hit_separation="trimesh"):
         if isinstance(mesh_path, TriMesh):
             self.mesh = TriMesh(mesh_path.vertices.copy(), mesh_path.faces.copy(), mesh_path.visual.uv)
         else:
@@ -398,7 +476,10 @@ class MeshIntersection:
         self.device = torch.device(device)
         self.mesh.vertices *= scale
         self.vertices = torch.from_numpy(self.mesh.vertices.astype(np.float32)).to(self.device)
-        self.rayintersector = RayIntersector(self.mesh, max_hits=self.num_intersections, device=device)
+        # min_hit_separation: the re-origin distance of the reference's trimesh intersector (default), a distance in
+        # world units, or 0 / None to count every hit (``RayIntersector``)
+        self.rayintersector = RayIntersector(self.mesh, max_hits=self.num_intersections, device=device,
+                                             min_separation=min_hit_separation)
 
     def find_deltas(self, boundary, depth):
         """Constant step for every sample (mesh_utils.py:225-231; B-4)."""

@@ -1,19 +1,173 @@
 """Ray-batch sharding across the GPUs of one node (one process per GPU, torch.distributed; backend "nccl" is
-RCCL on ROCm, "gloo" in CPU tests).
+RCCL on ROCm, "gloo" in CPU tests and in the single-device rehearsal).
 
-The reference is single-GPU; this is new.  Rays are independent, so a frame is cut
-into 8x8-pixel tiles dealt round-robin to ranks (object and background tiles balance), every rank holds a
-replica of mesh/BVH + tables + weights, renders its tiles with no collective on the data path, and the
-finished tiles (rgb3 + alpha1 + depth1 = 20 B/ray) are exchanged with ONE all_gather_into_tensor per frame.
-At 800x800 that is 12.8 MB in total, 1.6 MB per rank on 8 ranks: latency-, not bandwidth-bound on xGMI.
+The reference is single-GPU (``examples/train_finetune.py:218`` pins ``cuda:0``); this is
+new.  Rays are independent, every rank holds a replica of mesh/BVH + tables + weights, and ONE frame is cut into
+contiguous ROW BANDS, one per rank:
+
+* a band ``[y0, y1)`` of a pinhole frame is itself the full pixel grid of a pinhole camera -- the same camera with
+  the principal point moved up by ``y0`` rows (``band_camera``) -- so the camera-coherent intersector, the 8x8-tile
+  processing order and the streamed field path (the whole of the single-GPU speed) apply to a band unchanged, and a
+  band's rays are a contiguous slice of the frame's ray arrays;
+* every per-ray result depends on that ray alone (hits, samples, field values, the compositing sum in rank order),
+  so the bands' pixels are bit-identical to the 1-rank frame whatever the cuts are (tested on the GPU);
+* the cuts are multiples of 8 rows (tile rows stay tile rows) and are balanced by a per-row cost profile taken from
+  the gathered alpha of an earlier frame (object rows cost ~25x background rows).  The profile is applied with a
+  fixed lag, so every rank cuts every frame identically without a collective;
+* the finished bands (rgb3 + alpha1 + depth1 = 20 B/ray) are exchanged with ONE ``all_gather_into_tensor`` per frame
+  of the bands padded to the tallest one.  At 800x800 that is 12.8 MB in total: latency-, not bandwidth-bound on xGMI.
+
+The 8x8-tile round-robin sharding of round 1 (``shard_tiles`` ...) is kept for arbitrary (non-pinhole) ray sets.
 """
-from typing import Tuple
+from typing import List, Optional, Sequence, Tuple
 
+import numpy as np
 import torch
 import torch.distributed as dist
 
 TILE = 8
+BAND_ALIGN = 8
+#: relative cost of a row: COST_RAY per pixel + COST_OBJECT per pixel that hit the object (alpha > 0).  From the
+#: single-GPU stage times: ~10 quadrature points x 0.39 ns of field + compositing per object ray, ~0.15 ns of
+#: pack / compositing set-up per ray.
+COST_RAY, COST_OBJECT = 0.15, 3.9
 
+
+# ----------------------------------------------------------------------------------------------------------
+# row bands (pinhole frames)
+
+def band_cuts(height: int, world_size: int, row_cost: Optional[Sequence[float]] = None,
+              align: int = BAND_ALIGN) -> List[int]:
+    """``world_size + 1`` ascending row boundaries (multiples of ``align`` except the last = ``height``): rank r
+    renders rows ``[cuts[r], cuts[r+1])``.  ``row_cost`` [height]: relative cost per row (None = uniform); the cuts
+    equalise the cost per rank.  Every rank gets at least one block of rows while there are blocks left."""
+    n_blocks = (height + align - 1) // align
+    if row_cost is None:
+        cost = np.ones(n_blocks, dtype=np.float64)
+    else:
+        rc = np.asarray(row_cost, dtype=np.float64).reshape(-1)
+        if rc.shape[0] != height:
+            raise ValueError("row_cost must have one entry per row")
+        pad = n_blocks * align - height
+        cost = np.pad(np.maximum(rc, 0.0), (0, pad)).reshape(n_blocks, align).sum(axis=1)
+    cost = cost + 1e-9 * max(float(cost.sum()), 1.0) / n_blocks + 1e-30      # strictly increasing prefix
+    prefix = np.concatenate([[0.0], np.cumsum(cost)])
+    cuts_b = [0]
+    for r in range(1, world_size):
+        target = prefix[-1] * r / world_size
+        b = int(np.searchsorted(prefix, target, side="left"))
+        if b > 0 and target - prefix[b - 1] < prefix[b] - target:
+            b -= 1                                                          # the nearer block boundary
+        if n_blocks >= world_size:          # at least one block for every rank before and after this cut
+            b = min(max(b, cuts_b[-1] + 1), n_blocks - (world_size - r))
+        else:                               # fewer blocks than ranks: the last ranks get empty bands
+            b = min(max(b, cuts_b[-1]), n_blocks)
+        cuts_b.append(int(b))
+    cuts_b.append(n_blocks)
+    return [min(b * align, height) for b in cuts_b]
+
+
+def band_camera(c2w, focal: float, width: int, height: int, y0: int, y1: int):
+    """The pinhole camera whose full pixel grid is rows ``[y0, y1)`` of the ``width x height`` frame of
+    ``mesh_utils.make_camera(c2w, focal, width, height)``: same pose and focal length, principal point moved up by
+    ``y0`` rows.  The camera only bounds the intersector's search (it never enters the hit arithmetic), so the band's
+    hits are those of the frame's rays."""
+    from .mesh_utils import make_camera
+    cam = make_camera(c2w, focal, width, height)
+    cam.cy = height / 2.0 - float(y0)
+    cam.height = int(y1 - y0)
+    return cam
+
+
+def gather_bands(local: torch.Tensor, cuts: Sequence[int], width: int, rank: int, world_size: int) -> torch.Tensor:
+    """local [rows_r * width, C] (this rank's band, row-major) -> the full frame [H * width, C] on every rank with
+    one ``all_gather_into_tensor`` of the bands padded to the tallest band."""
+    rows = [cuts[r + 1] - cuts[r] for r in range(world_size)]
+    if local.shape[0] != rows[rank] * width:
+        raise ValueError(f"rank {rank}: band has {local.shape[0]} rays, expected {rows[rank] * width}")
+    if world_size == 1:
+        return local
+    c = local.shape[1]
+    cap = max(rows) * width
+    send = local if local.shape[0] == cap else torch.cat(
+        [local, torch.zeros((cap - local.shape[0], c), dtype=local.dtype, device=local.device)])
+    staged = local.is_cuda and dist.get_backend() == "gloo"     # rehearsal on one GPU: gloo moves host memory
+    if staged:
+        send = send.cpu()
+    buf = torch.empty((world_size * cap, c), dtype=send.dtype, device=send.device)
+    dist.all_gather_into_tensor(buf, send.contiguous())
+    buf = buf.view(world_size, cap, c)
+    frame = torch.cat([buf[r, :rows[r] * width] for r in range(world_size)], dim=0)
+    return frame.to(local.device) if staged else frame
+
+
+class ShardedFrameRenderer:
+    """One frame per call, split into row bands over the ranks of the default process group and gathered on every
+    rank: ``render(origins, viewdirs, c2w, focal, width, height) -> [H*W, 5]`` (rgb, alpha, depth).
+
+    ``renderer`` is a ``render.FrameRenderer`` (this rank's replica of the scene).  ``origins`` / ``viewdirs`` are the
+    frame's full row-major ray arrays (every rank generates or holds them; a band is a zero-copy slice).  The band
+    cuts follow the cost profile of the frame rendered ``PROFILE_LAG`` calls earlier -- by then its 3 KB host copy
+    has long arrived, and because the lag is fixed every rank uses the same profile for the same frame."""
+
+    PROFILE_LAG = 2
+
+    def __init__(self, renderer, rank: int = 0, world_size: int = 1, balance: bool = True):
+        self.renderer, self.rank, self.world = renderer, int(rank), int(world_size)
+        self.balance = bool(balance) and self.world > 1
+        self._profiles = []          # (pinned host row counts, event), oldest first
+        self.row_cost = None         # np [H] or None: the profile the next cuts are made from
+        self.last_cuts = None
+        self._ring = {}
+
+    def cuts_for(self, height: int) -> List[int]:
+        if self.row_cost is not None and self.row_cost.shape[0] != height:
+            self.row_cost = None
+        return band_cuts(height, self.world, self.row_cost)
+
+    def render_band(self, origins, viewdirs, c2w, focal, width: int, height: int, y0: int, y1: int) -> torch.Tensor:
+        """[(y1-y0)*W, 5] for rows [y0, y1) through the HIP path."""
+        if y1 <= y0:
+            return torch.empty((0, 5), dtype=torch.float32, device=origins.device)
+        cam = band_camera(c2w, focal, width, height, y0, y1)
+        o, d = origins[y0 * width:y1 * width], viewdirs[y0 * width:y1 * width]
+        rgb, alpha, depth, _ = self.renderer.render(o, d, camera=cam)
+        return torch.cat([rgb, alpha, depth], dim=1)
+
+    def render(self, origins, viewdirs, c2w, focal, width: int, height: int) -> torch.Tensor:
+        if origins.shape[0] != width * height:
+            raise ValueError("origins / viewdirs must be the frame's full row-major ray arrays")
+        cuts = self.last_cuts = self.cuts_for(height)
+        local = self.render_band(origins, viewdirs, c2w, focal, width, height, cuts[self.rank], cuts[self.rank + 1])
+        frame = gather_bands(local, cuts, width, self.rank, self.world)
+        if self.balance:
+            self._push_profile(frame, width, height)
+        return frame
+
+    def _push_profile(self, frame, width, height):
+        rows = (frame[:, 3] > 0).view(height, width).sum(dim=1, dtype=torch.float32)
+        if rows.is_cuda:
+            ring = self._ring.get(height)
+            if ring is None:      # PROFILE_LAG + 1 pinned buffers, reused round-robin (pinning per frame is slow)
+                ring = self._ring[height] = [[torch.empty((height,), dtype=torch.float32).pin_memory()
+                                              for _ in range(self.PROFILE_LAG + 1)], 0]
+            host = ring[0][ring[1] % len(ring[0])]
+            ring[1] += 1
+            host.copy_(rows, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+        else:
+            host, ev = rows.clone(), None
+        self._profiles.append((host, ev))
+        if len(self._profiles) >= self.PROFILE_LAG:       # deterministic: the same frame's profile on every rank
+            host, ev = self._profiles.pop(0)
+            if ev is not None:
+                ev.synchronize()
+            self.row_cost = COST_RAY * width + COST_OBJECT * host.numpy().astype(np.float64)
+
+
+# ----------------------------------------------------------------------------------------------------------
+# 8x8 tiles dealt round-robin (arbitrary ray sets; no camera-coherent fast path)
 
 def tile_layout(width: int, height: int) -> Tuple[int, int]:
     return (width + TILE - 1) // TILE, (height + TILE - 1) // TILE
@@ -42,7 +196,7 @@ def tile_ray_indices(tile_ids: torch.Tensor, width: int, height: int) -> torch.T
 
 def local_rays(origins: torch.Tensor, viewdirs: torch.Tensor, width: int, height: int, rank: int, world_size: int):
     """This rank's rays in tile order: (origins_local, viewdirs_local, ray_ids [n_local]); pad slots repeat ray 0
-    and are dropped again by ``scatter_tiles`` (their id is -1)."""
+    and are dropped again by ``gather_frame`` (their id is -1)."""
     ids = tile_ray_indices(shard_tiles(width, height, rank, world_size), width, height).reshape(-1)
     src = ids.clamp_min(0).to(origins.device)
     return origins[src].contiguous(), viewdirs[src].contiguous(), ids.to(origins.device)
@@ -65,6 +219,8 @@ def gather_frame(local: torch.Tensor, width: int, height: int, rank: int, world_
         frame[ids[keep]] = gathered[r][keep]
     return frame
 
+
+# ----------------------------------------------------------------------------------------------------------
 
 def init_from_env(backend: str = "nccl"):
     """(rank, local_rank, world_size) from the torchrun environment; initialises the process group if needed."""

@@ -195,6 +195,11 @@ class _FusedFieldBase(nn.Module):
             dirs = _C.f32c(dirs.reshape(-1, 3))
             if dirs.shape[0] != n:
                 raise ValueError(f"{tuple(xyz.shape)} v.s. {tuple(dirs.shape)}")
+        if order is not None:     # a stale permutation would index the points out of bounds inside the kernel
+            if order.dtype != torch.int32 or order.dim() != 1 or order.shape[0] != n or order.device != dev:
+                raise ValueError(f"order must be an int32 [{n}] permutation on {dev}, got {order.dtype} "
+                                 f"{tuple(order.shape)} on {order.device}")
+            order = order.contiguous()
         rgb = torch.empty((n, 3), dtype=torch.float32, device=dev) if want_rgb else None
         sigma = torch.empty((n,), dtype=torch.float32, device=dev) if want_sigma else None
         geo = torch.empty((n, 15), dtype=torch.float32, device=dev) if want_geo else None

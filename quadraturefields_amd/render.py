@@ -14,12 +14,18 @@ from .datasets.utils import Rays
 
 
 class FrameRenderer:
-    def __init__(self, mesh_intersect, radiance_field, field_net=None, render_step_size: float = 5e-3,
+    def __init__(self, mesh_intersect, radiance_field, field_net=None, render_step_size: Optional[float] = None,
                  bg_color: str = "white"):
         self.mesh_intersect = mesh_intersect
         self.radiance_field = radiance_field
         self.field_net = field_net
-        self.render_step_size = render_step_size
+        # The reference composites with MeshIntersection.render_step_size whatever the renderer's argument says
+        # (utils.py:574-585 goes through find_deltas), so there is ONE step size: the mesh intersector's.
+        step = float(mesh_intersect.render_step_size)
+        if render_step_size is not None and abs(float(render_step_size) - step) > 1e-12 * max(step, 1.0):
+            raise ValueError(f"render_step_size {render_step_size} differs from mesh_intersect.render_step_size {step}: "
+                             "the deformed and undeformed routes would composite differently")
+        self.render_step_size = step
         self.bg_color = bg_color
 
     @torch.no_grad()

@@ -74,7 +74,7 @@ class _DerivePropertiesFn(torch.autograd.Function):
             ctx.mark_non_differentiable(rgb, alpha, depth_out, weights)     # the indexed form is inference only
             return rgb, alpha, depth_out, weights
         ctx.save_for_backward(color, density, depths, deltas_t, index_ray, bk)
-        ctx.delta_c, ctx.mode = delta_c, mode
+        ctx.delta_c, ctx.mode, ctx.n_rays = delta_c, mode, N
         ctx.mark_non_differentiable(weights)
         return rgb, alpha, depth_out, weights
 
@@ -88,7 +88,7 @@ class _DerivePropertiesFn(torch.autograd.Function):
         if n:
             _C.check(_C.lib().qf_derive_properties_backward(
                 _C.ptr(color), _C.ptr(density), _C.ptr(depths), _C.ptr(deltas_t), ctx.delta_c, _C.ptr(index_ray), n,
-                ctx.mode, _C.ptr(bk), _C.ptr(_C.f32c(g_rgb)), _C.ptr(_C.f32c(g_alpha)), _C.ptr(_C.f32c(g_depth)),
+                ctx.n_rays, ctx.mode, _C.ptr(bk), _C.ptr(_C.f32c(g_rgb)), _C.ptr(_C.f32c(g_alpha)), _C.ptr(_C.f32c(g_depth)),
                 _C.ptr(g_color), _C.ptr(g_sigma), _C.ptr(g_t), _C.stream()), "qf_derive_properties_backward")
         return g_color, g_sigma, g_t, None, None, None, None, None, None, None
 
@@ -110,6 +110,10 @@ def derive_properties(color, density, depths, deltas, boundary, index_ray, rende
     density = _C.f32c(density.reshape(-1))
     depths = _C.f32c(depths.reshape(-1))
     index_ray = _C.i64c(index_ray.reshape(-1))
+    N = int(N)
+    if N <= 0 and depths.shape[0] > 0:
+        # the reference's default N=0 fails there too (index N-sized buffers by ray id: IndexError)
+        raise IndexError(f"derive_properties: {depths.shape[0]} samples but N={N} rays; pass the number of rays")
     deltas_t, delta_c = None, 0.0
     if isinstance(deltas, torch.Tensor):
         deltas_t = _C.f32c(deltas.detach().reshape(-1))

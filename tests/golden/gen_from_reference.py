@@ -229,7 +229,8 @@ def gen_sampling():
     for m in ("sampling_raytrace_numpy", "sampling_indexing", "find_deltas"):
         code = extract("mesh_utils.py", m, cls="MeshIntersection").replace("device=torch.device('cuda')", "device=torch.device('cpu')")
         run(code, ns)
-    self = types.SimpleNamespace(rayintersector=om.BruteForceIntersector(mesh.vertices, mesh.faces),
+    # min_separation=0: the fixture pins the reference's own sort / cast bodies; the intersector behind them is a stand-in
+    self = types.SimpleNamespace(rayintersector=om.BruteForceIntersector(mesh.vertices, mesh.faces, min_separation=0.0),
                                  num_intersections=25, render_step_size=0.005)
     for m in ("sampling_raytrace_numpy", "sampling_indexing", "find_deltas"):
         setattr(self, m, types.MethodType(ns[m], self))

@@ -103,7 +103,7 @@ def test_oracle_texture_vs_reference():
 
 def test_oracle_sampling_vs_reference():
     z = load("sampling_ref.npz")
-    bf = om.BruteForceIntersector(z["vertices"].numpy(), z["faces"].numpy())
+    bf = om.BruteForceIntersector(z["vertices"].numpy(), z["faces"].numpy(), min_separation=0.0)    # as the generator
     s = om.sampling_raytrace_numpy(bf, z["viewdirs"].numpy(), z["origins"].numpy(), 25)
     data = om.to_loader_tensors(s)
     for got, key in zip(data, ("xyzs", "dirs", "index_ray", "ts", "index_tri", "origins_s")):
@@ -199,7 +199,8 @@ def test_hip_sampling_vs_reference(device):
     from quadraturefields_amd.mesh_io import TriMesh
     from quadraturefields_amd.mesh_utils import MeshIntersection
     z = load("sampling_ref.npz")
-    mi = MeshIntersection(TriMesh(z["vertices"].numpy(), z["faces"].numpy()), simplify_mesh=False, scale=1.0, num_intersections=25)
+    mi = MeshIntersection(TriMesh(z["vertices"].numpy(), z["faces"].numpy()), simplify_mesh=False, scale=1.0,
+                          num_intersections=25, min_hit_separation=0.0)      # the fixture's stand-in intersector returns every hit
     data = mi.sampling_raytrace_device(z["viewdirs"], z["origins"])
     for got, key in zip(data, ("xyzs", "dirs", "index_ray", "ts", "index_tri", "origins_s")):
         assert torch.equal(got.cpu(), z[key]), key

@@ -200,3 +200,29 @@ def test_derive_properties_chunking_long_rays_and_sample_index(device):
                                    sample_index=dev(inv))
     for k in (0, 1, 3, 4):
         assert torch.equal(got2[k], got[k])
+
+
+def test_derive_properties_ray_ids_outside_the_image(device):
+    """N = 0 (the reference signature's default) with samples raises like the reference's index error instead of
+    writing through a NULL / too small buffer, and a ray id >= N contributes to no pixel (forward and backward)."""
+    from quadraturefields_amd import utils
+    g = torch.Generator().manual_seed(0)
+    n = 40
+    ridx = torch.sort(torch.randint(0, 6, (n,), generator=g)).values
+    col, sig, dep = torch.rand(n, 3, generator=g), torch.rand(n, generator=g) * 50, torch.rand(n, generator=g)
+    dev = lambda t: t.to(device)
+    with pytest.raises(IndexError):
+        utils.derive_properties(dev(col), dev(sig), dev(dep), 5e-3, None, dev(ridx), N=0)
+    rgb6, a6, _, d6, w6 = utils.derive_properties(dev(col), dev(sig), dev(dep), 5e-3, None, dev(ridx), N=6)
+    rgb4, a4, _, d4, w4 = utils.derive_properties(dev(col), dev(sig), dev(dep), 5e-3, None, dev(ridx), N=4)   # rays 4, 5 outside
+    torch.cuda.synchronize()
+    assert torch.equal(rgb4, rgb6[:4]) and torch.equal(a4, a6[:4]) and torch.equal(d4, d6[:4]) and torch.equal(w4, w6)
+    with torch.enable_grad():
+        c = dev(col).requires_grad_(True)
+        s = dev(sig).requires_grad_(True)
+        out = utils.derive_properties(c, s, dev(dep), 5e-3, None, dev(ridx), N=4)
+        (out[0].sum() + out[1].sum()).backward()
+    outside = dev(ridx) >= 4
+    assert torch.isfinite(c.grad).all() and torch.isfinite(s.grad).all()
+    assert float(c.grad[outside].abs().max()) == 0.0 and float(s.grad[outside].abs().max()) == 0.0
+    assert float(s.grad[~outside].abs().max()) > 0.0

@@ -101,7 +101,7 @@ def test_scale_and_refit(device):
     moved = mi.mesh.vertices + rng.normal(scale=0.02, size=mi.mesh.vertices.shape)
     mi.rayintersector.update_intersector(moved)
     tri, t, cnt, _, _ = mi.rayintersector.hits(o, d)
-    tri_o, t_o, cnt_o = om.BruteForceIntersector(moved, mi.mesh.faces).hits(o, d, 10)
+    tri_o, t_o, cnt_o = om.BruteForceIntersector(moved, mi.mesh.faces, mi.rayintersector.min_separation).hits(o, d, 10)
     assert np.array_equal(cnt.cpu().numpy(), cnt_o)
     assert np.array_equal(tri.cpu().numpy(), tri_o)
     assert np.array_equal(t.cpu().numpy(), t_o)
@@ -427,3 +427,181 @@ def test_bvh_depth_is_bounded_on_lopsided_input(device):
         assert np.array_equal(t.cpu().numpy(), t_o)
     assert depths[0] >= 25                                  # lopsided under SAH ...
     assert depths[1] <= 3 + 12                              # ... and at most sah_depth + ceil(log2(3000)) when halving
+
+
+# ----------------------------------------------------------------------------------------------------------
+# round 2: the 8-wide tree, the reference's multi-hit (re-origin) rule, device-side refit
+
+def test_wide_tree_structure(device):
+    """Every triangle sits in exactly one leaf of the 8-wide tree, every child box encloses its subtree's triangles,
+    children follow their parent (breadth-first order) and the stack bound covers the worst root-to-leaf path."""
+    from quadraturefields_amd import _C
+    from quadraturefields_amd.mesh_utils import RayIntersector
+    mesh = _scene(3, 3)
+    ri = RayIntersector(mesh, max_hits=4)
+    n8, n_tri = ri.num_wide_nodes, mesh.faces.shape[0]
+    nodes = np.zeros((n8, 8, 8), np.float32)
+    ids = np.zeros(n_tri, np.int32)
+    _C.check(_C.lib().qf_bvh_copy_wide_nodes(ri._handle, nodes.ctypes.data, n8))
+    _C.check(_C.lib().qf_bvh_copy_tri_ids(ri._handle, ids.ctypes.data, n_tri))
+    tok = nodes[:, :, 6].copy().view(np.int32)
+    tris = mesh.vertices.astype(np.float32)[mesh.faces]
+    seen = np.zeros(n_tri, bool)
+    empty = np.int32(-2 ** 31)
+
+    def walk(n, depth_sum):
+        lo_all, hi_all = np.full(3, np.inf, np.float32), np.full(3, -np.inf, np.float32)
+        h = int((tok[n] != empty).sum())
+        worst = h
+        for j in range(8):
+            t = tok[n, j]
+            if t == empty:
+                continue
+            lo, hi = nodes[n, j, 0:3], nodes[n, j, 3:6]
+            if t < 0:
+                packed = ~t
+                first, cnt = packed >> 3, (packed & 7) + 1
+                assert 1 <= cnt <= 8
+                for k in range(cnt):
+                    tid = ids[first + k]
+                    assert not seen[tid]
+                    seen[tid] = True
+                    assert (tris[tid] >= lo).all() and (tris[tid] <= hi).all()
+            else:
+                assert t > n
+                clo, chi, need = walk(int(t), depth_sum)
+                assert (clo >= lo).all() and (chi <= hi).all()
+                worst = max(worst, h - 1 + need)
+            lo_all, hi_all = np.minimum(lo_all, lo), np.maximum(hi_all, hi)
+        return lo_all, hi_all, worst
+
+    _, _, need = walk(0, 0)
+    assert seen.all()
+    assert ri.max_stack >= need + 1 and ri.max_stack <= 384
+    assert n8 < ri.num_nodes                                 # the collapse shrinks the node count
+
+
+def _doubled(mesh, gap):
+    """mesh + a copy of it scaled by (1 + gap): gap = 0 duplicates every face exactly."""
+    from quadraturefields_amd.mesh_io import TriMesh
+    v = np.concatenate([mesh.vertices, mesh.vertices * (1.0 + gap)])
+    f = np.concatenate([mesh.faces, mesh.faces + mesh.vertices.shape[0]])
+    return TriMesh(v, f)
+
+
+@pytest.mark.parametrize("gap", [0.0, 5e-5])
+@pytest.mark.parametrize("max_hits", [3, 25])
+def test_reorigin_rule_on_duplicated_and_near_coincident_shells(device, gap, max_hits):
+    """The reference's multi-hit rule (trimesh re-origin, mesh_utils.py:350-354; the reference's mesh is a
+    concatenation of two iso-surfaces loaded with process=False): with an exactly duplicated shell and with two shells
+    5e-5 apart the second copy of every crossing is never returned.  Ids, counts and distances bit-exact against the
+    oracle through every route: BVH traversal (with list pages: K = 3 fills at once), the camera-coherent pass with
+    its filter, the wide pass, and the packed samples; rule off = the round-1 behaviour (every hit)."""
+    from quadraturefields_amd import synthetic
+    from quadraturefields_amd.mesh_utils import RayIntersector, make_camera, trimesh_ray_offset
+    mesh = _doubled(_scene(3, 3), gap)
+    sep = trimesh_ray_offset(mesh.vertices)
+    assert sep == om.trimesh_ray_offset(mesh.vertices) and 1e-3 < sep < 1e-2
+    ri = RayIntersector(mesh, max_hits=max_hits)                       # default: the trimesh distance
+    assert abs(ri.min_separation - sep) < 1e-12
+    o, d = _rays(4000, seed=7)
+    o[:40] = 0.0
+    bf = om.BruteForceIntersector(mesh.vertices, mesh.faces)
+    tri_o, t_o, cnt_o = bf.hits(o, d, max_hits)
+    tri, t, cnt, _, _ = ri.hits(o, d)
+    assert np.array_equal(cnt.cpu().numpy(), cnt_o) and np.array_equal(tri.cpu().numpy(), tri_o)
+    assert np.array_equal(t.cpu().numpy(), t_o)
+    # the rule removed the second copies: with it off there are about twice as many hits
+    bf_all = om.BruteForceIntersector(mesh.vertices, mesh.faces, min_separation=0.0)
+    tri_a, t_a, cnt_a = bf_all.hits(o, d, 64)
+    tri_k, t_k, cnt_k = om.BruteForceIntersector(mesh.vertices, mesh.faces).hits(o, d, 64)
+    assert cnt_a.sum() >= 1.9 * cnt_k.sum() > 0
+    ri.set_min_separation(0.0)
+    tri0, t0, cnt0, _, _ = ri.hits(o, d)
+    assert np.array_equal(cnt0.cpu().numpy(), np.minimum(cnt_a, max_hits))
+    assert np.array_equal(tri0.cpu().numpy(), tri_a[:, :max_hits]) and np.array_equal(t0.cpu().numpy(), t_a[:, :max_hits])
+    ri.set_min_separation(sep)
+    # camera frames: the coherent pass + filter (and repair of overflowing pixels through the paged traversal)
+    w = h = 96
+    c2w = synthetic.orbit_cameras(1, seed=3)[0]
+    focal = synthetic.lego_focal(800) * w / 800.0
+    oc, dc = synthetic.camera_rays(c2w, focal, w, h)
+    want = om.to_loader_tensors(om.sampling_raytrace_numpy(bf, dc.numpy(), oc.numpy(), max_hits))
+    for wide in (0, 4 * max_hits):
+        ri._raster_backoff, ri.raster_wide = 0, wide
+        got = ri.sample_device(oc.to(device), dc.to(device), max_hits, camera=make_camera(c2w, focal, w, h))
+        for a, b in zip(got, want):
+            assert torch.equal(a.cpu(), b)
+    got = ri.sample_device(oc.to(device), dc.to(device), max_hits, image_width=w)          # BVH route
+    for a, b in zip(got, want):
+        assert torch.equal(a.cpu(), b)
+    # qf_raster_intersect with sort_lists (RayIntersector.hits with a camera)
+    ri._raster_backoff, ri.raster_wide = 0, 0
+    tri_c, t_c, cnt_c, _, _ = ri.hits(oc.to(device), dc.to(device), camera=make_camera(c2w, focal, w, h))
+    tri_b, t_b, cnt_b = bf.hits(oc.numpy(), dc.numpy(), max_hits)
+    assert np.array_equal(cnt_c.cpu().numpy(), cnt_b) and np.array_equal(tri_c.cpu().numpy(), tri_b)
+
+
+def test_reorigin_rule_pages_through_many_coincident_copies(device):
+    """Six exact copies of a shell mesh and K = 4: each crossing fills more than one page of the K-list before the
+    chain advances; the paged traversal still returns exactly the oracle's hits."""
+    from quadraturefields_amd.mesh_io import TriMesh
+    from quadraturefields_amd.mesh_utils import RayIntersector
+    base = _scene(2, 3)
+    nv = base.vertices.shape[0]
+    mesh = TriMesh(np.concatenate([base.vertices] * 6), np.concatenate([base.faces + i * nv for i in range(6)]))
+    o, d = _rays(1500, seed=11)
+    for k in (4, 9):
+        ri = RayIntersector(mesh, max_hits=k)
+        tri_o, t_o, cnt_o = om.BVHIntersector(mesh.vertices, mesh.faces).hits(o, d, k)
+        tri, t, cnt, _, _ = ri.hits(o, d)
+        assert np.array_equal(cnt.cpu().numpy(), cnt_o) and np.array_equal(tri.cpu().numpy(), tri_o)
+        assert np.array_equal(t.cpu().numpy(), t_o)
+        assert cnt_o.max() >= 4
+
+
+def test_oracle_bvh_walk_equals_bruteforce_here_too(device):
+    mesh = _scene(3, 4)
+    o, d = _rays(2000, seed=5)
+    for sep in (0.0, "trimesh", 0.05):
+        a = om.BruteForceIntersector(mesh.vertices, mesh.faces, sep).hits(o, d, 25)
+        b = om.BVHIntersector(mesh.vertices, mesh.faces, sep).hits(o, d, 25)
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y)
+
+
+def test_device_refit_equals_a_fresh_intersector(device):
+    """update_intersector with a DEVICE tensor (qf_bvh_refit_device: no host round trip) gives the hits of an
+    intersector built from the moved vertices, for [V,3] vertices and for the [F*9] triangle soup."""
+    from quadraturefields_amd.mesh_io import TriMesh
+    from quadraturefields_amd.mesh_utils import RayIntersector
+    mesh = _scene(3, 3)
+    rng = np.random.default_rng(2)
+    moved = mesh.vertices + rng.normal(size=mesh.vertices.shape) * 0.01
+    o, d = _rays(3000, seed=9)
+    fresh = RayIntersector(TriMesh(moved, mesh.faces), max_hits=25, min_separation=0.0)
+    want = fresh.hits(o, d)
+    ri = RayIntersector(mesh, max_hits=25, min_separation=0.0)
+    ri.update_intersector(torch.from_numpy(moved.astype(np.float32)).to(device))
+    for a, b in zip(ri.hits(o, d)[:3], want[:3]):
+        assert torch.equal(a, b)
+    ri2 = RayIntersector(mesh, max_hits=25, min_separation=0.0)
+    soup = torch.from_numpy(moved.astype(np.float32)[mesh.faces].reshape(-1)).to(device)
+    ri2.update_intersector(soup)
+    for a, b in zip(ri2.hits(o, d)[:3], want[:3]):
+        assert torch.equal(a, b)
+    # and back again through the host refit
+    ri.update_intersector(mesh.vertices)
+    orig = RayIntersector(mesh, max_hits=25, min_separation=0.0).hits(o, d)
+    for a, b in zip(ri.hits(o, d)[:3], orig[:3]):
+        assert torch.equal(a, b)
+    # camera-coherent pass reads the refitted triangles too
+    from quadraturefields_amd import synthetic
+    from quadraturefields_amd.mesh_utils import make_camera
+    ri.update_intersector(torch.from_numpy(moved.astype(np.float32)).to(device))
+    c2w = synthetic.orbit_cameras(1, seed=1)[0]
+    oc, dc = synthetic.camera_rays(c2w, synthetic.lego_focal(800) * 64 / 800.0, 64, 64)
+    a = ri.sample_device(oc.to(device), dc.to(device), 25, camera=make_camera(c2w, synthetic.lego_focal(800) * 64 / 800.0, 64, 64))
+    b = fresh.sample_device(oc.to(device), dc.to(device), 25, image_width=64)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)

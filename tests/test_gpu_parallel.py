@@ -1,0 +1,100 @@
+"""GPU: ONE frame sharded into row bands over 2 ranks (both on cuda:0, gloo process group -- the rehearsal of the
+N > 1 path on a one-GPU box), each band rendered through the HIP kernels (camera-coherent intersector, coherent
+layout, streamed field kernel, compositing) and gathered with one all_gather_into_tensor.  The gathered frame must
+be BIT-IDENTICAL to the 1-rank frame of the same scene: a band is the full pixel grid of a shifted pinhole camera and
+every per-ray result depends on that ray alone (quadraturefields_amd/parallel.py).  Also on the device: the BVH route
+of a band (no camera), ragged cuts, and the profile-driven rebalancing.
+"""
+import os
+import socket
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+W, H = 160, 128
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _build(device):
+    from quadraturefields_amd import synthetic
+    from quadraturefields_amd.mesh_utils import MeshIntersection
+    from quadraturefields_amd.radiance_fields.ngp import NGPRadianceField
+    from quadraturefields_amd.render import FrameRenderer
+    mesh = synthetic.shell_mesh(n_shells=4, subdivisions=4)
+    mi = MeshIntersection(mesh, simplify_mesh=False, scale=1.0, num_intersections=25, device=device)
+    field = NGPRadianceField(aabb=[-1.5] * 3 + [1.5] * 3, log2_hashmap_size=15)
+    field.load_state_dict(synthetic.seeded_ngp_state(15, field.mlp_base.grid.n_rows), strict=False)
+    cams = synthetic.orbit_cameras(4, seed=5)
+    focal = synthetic.lego_focal(800) * W / 800.0
+    return FrameRenderer(mi, field.to(device)), cams, focal
+
+
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+    from quadraturefields_amd import parallel, synthetic
+    from quadraturefields_amd.mesh_utils import make_camera
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK="0",
+                      WORLD_SIZE=str(world))
+    torch.set_grad_enabled(False)
+    parallel.init_from_env("gloo")
+    device = torch.device("cuda:0")
+    fr, cams, focal = _build(device)
+    sharded = parallel.ShardedFrameRenderer(fr, rank, world)
+    ok, cuts = [], []
+    for i in range(cams.shape[0]):
+        o, d = synthetic.camera_rays(cams[i], focal, W, H, device=device)
+        frame = sharded.render(o, d, cams[i], focal, W, H)
+        cuts.append(list(sharded.last_cuts))
+        rgb, alpha, depth, _ = fr.render(o, d, camera=make_camera(cams[i], focal, W, H))      # the 1-rank frame
+        ok.append(torch.equal(frame, torch.cat([rgb, alpha, depth], dim=1)))
+    torch.cuda.synchronize()
+    q.put((rank, ok, cuts, int((frame[:, 3] > 0).sum())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_band_frame_is_bit_identical_to_one_rank():
+    import torch.multiprocessing as mp
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted(q.get(timeout=600) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank, ok, cuts, n_obj in results:
+        assert all(ok), (rank, ok)
+        assert n_obj > 1000                                   # the frames are not empty
+    assert results[0][2] == results[1][2]                     # identical cuts on both ranks, every frame
+    assert results[0][2][0] == [0, H // 2, H]                 # uniform first, profile-driven from frame 2 on
+
+
+def test_bands_equal_the_frame_for_any_cuts_and_for_the_bvh_route(device):
+    """Single process: the union of bands with ragged cuts equals the whole frame, through the camera-coherent route
+    (band cameras) and through the BVH route (no camera: image_width only)."""
+    from quadraturefields_amd import parallel, synthetic
+    from quadraturefields_amd.mesh_utils import make_camera
+    fr, cams, focal = _build(device)
+    o, d = synthetic.camera_rays(cams[0], focal, W, H, device=device)
+    rgb, alpha, depth, n = fr.render(o, d, camera=make_camera(cams[0], focal, W, H))
+    whole = torch.cat([rgb, alpha, depth], dim=1)
+    assert n > 1000
+    sharded = parallel.ShardedFrameRenderer(fr, 0, 1)
+    for cuts in ([0, 8, 72, 120, H], [0, 64, H], [0, 40, 40, H]):
+        parts = [sharded.render_band(o, d, cams[0], focal, W, H, a, b) for a, b in zip(cuts[:-1], cuts[1:])]
+        assert torch.equal(torch.cat(parts), whole), cuts
+    parts = []
+    for a, b in ((0, 56), (56, H)):
+        r, al, de, _ = fr.render(o[a * W:b * W], d[a * W:b * W], image_width=W)             # BVH traversal
+        parts.append(torch.cat([r, al, de], dim=1))
+    assert torch.equal(torch.cat(parts), whole)

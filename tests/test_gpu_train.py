@@ -393,7 +393,7 @@ def test_finetune_loop_end_to_end(device):
     mi.rayintersector.update_intersector(finetune.vertices)
     o, d, _ = views[0]
     a = mi.rayintersector.hits(o, d, image_width=w)
-    fresh = RayIntersector(mi.mesh, max_hits=25)
+    fresh = RayIntersector(mi.mesh, max_hits=25, min_separation=mi.rayintersector.min_separation)
     b = fresh.hits(o, d, image_width=w)
     for x, y in zip(a[:3], b[:3]):
         assert torch.equal(x, y)

@@ -1,6 +1,8 @@
-"""CPU, gloo, world_size 2: tile sharding of a frame and the one-collective gather (the N > 1 path of bench.py).
-The render itself is replaced by a deterministic function of the ray (no GPU here); the sharding / gather logic is
-what is under test."""
+"""CPU, gloo, world_size 2: the host logic of quadraturefields_amd/parallel.py -- row-band sharding of ONE frame
+(cost-balanced cuts, band cameras, the padded one-collective gather, the fixed-lag profile that keeps the ranks'
+cuts identical) and the round-1 tile sharding for arbitrary ray sets.  The render itself is replaced by a
+deterministic function of the ray (no GPU here); the same band path with the HIP render on a real device is
+tests/test_gpu_parallel.py, and bench.py --gpus N times it (its "sharded_frame" object)."""
 import os
 import socket
 
@@ -71,3 +73,103 @@ def test_tile_layout_single_process():
     o, d = torch.rand(w * h, 3, generator=g), torch.rand(w * h, 3, generator=g)
     lo, ld, ids = parallel.local_rays(o, d, w, h, 0, 1)
     assert torch.equal(parallel.gather_frame(_fake_render(lo, ld), w, h, 0, 1), _fake_render(o, d))
+
+
+# ----------------------------------------------------------------------------------------------------------
+# row bands
+
+class _FakeRenderer:
+    """Stands in for render.FrameRenderer: a deterministic function of each ray, alpha > 0 on a disc of the frame."""
+
+    def __init__(self):
+        self.cameras = []
+
+    def render(self, o, d, camera=None):
+        self.cameras.append((camera.width, camera.height, camera.cy))
+        assert o.shape[0] == camera.width * camera.height
+        v = _fake_render(o, d)
+        alpha = ((o[:, :1] - 0.5) ** 2 + (o[:, 1:2] - 0.5) ** 2 < 0.09).float()
+        return v[:, :3], alpha, v[:, 4:5], 0
+
+
+def _frame_inputs(w, h):
+    ys, xs = torch.meshgrid(torch.arange(h), torch.arange(w), indexing="ij")
+    o = torch.stack([(xs.flatten() + 0.5) / w, (ys.flatten() + 0.5) / h, torch.zeros(w * h)], dim=1)
+    d = torch.rand(w * h, 3, generator=torch.Generator().manual_seed(3))
+    return o, d
+
+
+def _band_worker(rank, world, port, w, h, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank),
+                      WORLD_SIZE=str(world))
+    parallel.init_from_env("gloo")
+    o, d = _frame_inputs(w, h)
+    c2w = torch.eye(4)[:3]
+    ref = _FakeRenderer().render(o, d, camera=parallel.band_camera(c2w, 50.0, w, h, 0, h))
+    ref = torch.cat([ref[0], ref[1], ref[2]], dim=1)
+    sr = parallel.ShardedFrameRenderer(_FakeRenderer(), rank, world)
+    ok, cuts = True, []
+    for _ in range(4):                       # frames 0-1 use uniform cuts, 2-3 the profile of frames 0-1
+        frame = sr.render(o, d, c2w, 50.0, w, h)
+        ok = ok and torch.equal(frame, ref)
+        cuts.append(list(sr.last_cuts))
+    q.put((rank, ok, cuts))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("w,h", [(24, 64), (17, 43)])
+def test_two_rank_band_render_and_gather(w, h):
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_band_worker, args=(r, world, port, w, h, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted(q.get(timeout=90) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in results)
+    assert results[0][2] == results[1][2]                    # both ranks cut every frame identically
+    cuts = results[0][2]
+    assert cuts[0] == cuts[1] == parallel.band_cuts(h, 2)    # uniform until the lagged profile arrives
+    assert cuts[2][0] == 0 and cuts[2][-1] == h and cuts[2][1] % parallel.BAND_ALIGN == 0
+
+
+def test_band_cuts_properties():
+    import numpy as np
+    for h, world in [(800, 1), (800, 8), (1080, 8), (100, 3), (37, 2), (7, 2), (20, 8), (8, 8)]:
+        cuts = parallel.band_cuts(h, world)
+        assert len(cuts) == world + 1 and cuts[0] == 0 and cuts[-1] == h
+        assert all(a <= b for a, b in zip(cuts[:-1], cuts[1:]))
+        assert all(c % parallel.BAND_ALIGN == 0 for c in cuts if c < h)
+        n_blocks = -(-h // parallel.BAND_ALIGN)
+        if n_blocks >= world:
+            assert all(b > a for a, b in zip(cuts[:-1], cuts[1:]))       # nobody idles while there are blocks
+    # a profile that is heavy in the middle: bands there are shorter, costs come out nearly equal
+    rc = np.full(800, 0.15 * 800)
+    rc[230:570] += 3.9 * 600
+    cuts = parallel.band_cuts(800, 8, rc)
+    cost = [rc[a:b].sum() for a, b in zip(cuts[:-1], cuts[1:])]
+    assert max(cost) <= 1.15 * (sum(cost) / 8)
+    assert cuts[1] - cuts[0] > cuts[4] - cuts[3]
+    with pytest.raises(ValueError):
+        parallel.band_cuts(800, 2, rc[:10])
+
+
+def test_band_camera_is_the_frame_camera_shifted():
+    c2w = torch.eye(4)[:3]
+    full = parallel.band_camera(c2w, 1111.0, 800, 800, 0, 800)
+    band = parallel.band_camera(c2w, 1111.0, 800, 800, 304, 400)
+    assert (full.width, full.height, full.cy) == (800, 800, 400.0)
+    assert (band.width, band.height, band.cx) == (800, 96, 400.0)
+    assert band.cy == 400.0 - 304 and band.fx == full.fx == band.fy
+    assert list(band.c2w) == list(full.c2w)
+
+
+def test_gather_bands_single_rank_and_shape_check():
+    x = torch.arange(40.0).reshape(8, 5)
+    assert parallel.gather_bands(x, [0, 2], 4, 0, 1) is x
+    with pytest.raises(ValueError):
+        parallel.gather_bands(x, [0, 3], 4, 0, 1)
