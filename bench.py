@@ -137,7 +137,7 @@ class Stages:
         return {k: (float(reduce([a.elapsed_time(b) for a, b in v])) if v else None) for k, v in self.ev.items()}
 
 
-def cpu_baseline(mesh, field, cam_o, cam_d, crop=200):
+def cpu_baseline(mesh, field, cam_o, cam_d, crop=600):
     """The oracle (CPU restatement of the reference path) timed on this box's host cores on a bounded sample: the
     centre crop x crop pixels of frame 0 through multi-hit intersection on the oracle's host BVH (OpenMP C; the
     reference walks Embree's BVH on the CPU, mesh_utils.py:350-354), torch-CPU field evaluation and compositing.

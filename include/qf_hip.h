@@ -28,7 +28,7 @@ extern "C" {
 #define QF_ERR_UNSUPPORTED (-3)
 #define QF_ERR_NO_DEVICE (-4)
 
-#define QF_ABI_VERSION 1
+#define QF_ABI_VERSION 2
 #define QF_MAX_LEVELS 16
 #define QF_MAX_LOBES 8
 
@@ -356,12 +356,16 @@ int qf_raster_intersect_wide(const qf_bvh *bvh, const qf_camera *cam /* host */,
                              int32_t *wide_tri, float *wide_t, int32_t *hit_tri, float *hit_t, int32_t *hit_count,
                              int32_t *overflow, void *stream);
 /* The fall-back, per ray: after qf_raster_intersect with sort_lists = 0 (raw counts), re-traverses exactly the rays
- * with hit_count > max_hits through the BVH (exact K nearest; their lists and counts are overwritten, in the layout of
- * qf_bvh_intersect) and leaves every other ray alone.  No host round trip; a frame with a handful of overflowing
- * pixels costs a few microseconds instead of a whole-image traversal.                            */
+ * with hit_count > max_hits through the BVH (exact K nearest under the handle's min_separation rule; their lists and
+ * counts are overwritten, in the layout of qf_bvh_intersect) and leaves every other ray's list alone.  No host round
+ * trip; a frame with a handful of overflowing pixels costs a few microseconds instead of a whole-image traversal.
+ * keep_mask [n_rays] uint64 / raw_count [n_rays] (both or neither, NULL to skip): when the handle's rule is on, the
+ * same launch also decides it for every other ray WITHOUT rewriting its list (the lists of a frame are 128 MB; the
+ * masks 8): bit i of keep_mask[r] = the i-th hit of ray r in (t, tri) order is kept, raw_count[r] = length of the
+ * stored list, hit_count[r] = number kept.  qf_pack_samples takes the two arrays.  Ignored while the rule is off. */
 int qf_bvh_repair_overflow(const qf_bvh *bvh, const float *rays_o, const float *rays_d, int64_t n_rays,
                            int32_t max_hits, int32_t image_width, int32_t *hit_tri, float *hit_t,
-                           int32_t *hit_count, void *stream);
+                           int32_t *hit_count, uint64_t *keep_mask, int32_t *raw_count, void *stream);
 
 /* Occupancy-grid ray marching: nerfacc 0.5.3 OccGridEstimator.sampling -> traverse_grids for one grid level and
  * cone_angle = 0 (examples/utils.py:137-147,266-285).  Samples are [t0 + k*step, t0 + (k+1)*step],
@@ -405,12 +409,16 @@ int qf_sample_offsets(const int32_t *hit_count, int64_t n_rays, int32_t max_hits
  * qf_derive_properties picks colour and density back up through sample_index = inverse.  Measured: the indirection
  * through `order` costs the field kernel 10 % (two scattered sector reads and a scattered write per point).
  * xyz / dirs / origins may then be NULL (all three) for a caller that only renders: the ray-major copies of the
- * positions are skipped; index_ray, depth and index_tri are always written.                      */
+ * positions are skipped; index_ray, depth and index_tri are always written.
+ * keep_mask / raw_count (both or neither; from qf_bvh_repair_overflow): the stored list of ray r has raw_count[r]
+ * entries of which the ones whose (t, tri)-sorted position has its bit set in keep_mask[r] are packed --
+ * hit_count[r] (and ray_offset) already count only those.                                          */
 int qf_pack_samples(const float *rays_o, const float *rays_d, int64_t n_rays, int32_t max_hits,
                     const int32_t *hit_tri, const float *hit_t, const int32_t *hit_count,
                     const int64_t *ray_offset, float *xyz, float *dirs, int64_t *index_ray,
                     float *depth, int64_t *index_tri, float *origins, const int32_t *inverse,
-                    float *xyz_c, float *dirs_c, void *stream);
+                    float *xyz_c, float *dirs_c, const uint64_t *keep_mask, const int32_t *raw_count,
+                    void *stream);
 
 /* Spatially coherent PROCESSING order for qf_field_forward when the rays are a row-major width x height image:
  * (8x8 pixel tile, hit rank, pixel in tile).  Two steps around one exclusive scan the caller does:

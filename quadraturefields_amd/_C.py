@@ -94,7 +94,7 @@ _SIGNATURES = {
     "qf_bvh_copy_nodes": (c_int, [_P, _P, c_int64]),
     "qf_bvh_copy_tri_ids": (c_int, [_P, _P, c_int64]),
     "qf_bvh_intersect": (c_int, [_P, _P, _P, c_int64, c_int32, c_int32, _P, _P, _P, _P]),
-    "qf_bvh_repair_overflow": (c_int, [_P, _P, _P, c_int64, c_int32, c_int32, _P, _P, _P, _P]),
+    "qf_bvh_repair_overflow": (c_int, [_P, _P, _P, c_int64, c_int32, c_int32, _P, _P, _P, _P, _P, _P]),
     "qf_raster_intersect": (c_int, [_P, POINTER(Camera), _P, _P, c_int64, c_int32, _P, _P, _P, _P, c_int32, _P]),
     "qf_raster_intersect_wide": (c_int, [_P, POINTER(Camera), _P, _P, c_int64, c_int32, c_int32, _P, _P, _P, _P, _P, _P, _P]),
     "qf_grid_march_count": (c_int, [POINTER(c_float), POINTER(c_int32), _P, _P, _P, _P, _P, c_int64, c_float, c_float,
@@ -105,7 +105,7 @@ _SIGNATURES = {
     "qf_scatter_max": (c_int, [_P, _P, c_int64, c_int64, _P, _P]),
     "qf_sample_offsets_temp_bytes": (c_int64, [c_int64]),
     "qf_sample_offsets": (c_int, [_P, c_int64, c_int32, _P, _P, c_int64, _P]),
-    "qf_pack_samples": (c_int, [_P, _P, c_int64, c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "qf_pack_samples": (c_int, [_P, _P, c_int64, c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "qf_tile_totals": (c_int, [_P, c_int32, c_int32, _P, _P]),
     "qf_coherent_order": (c_int, [_P, _P, _P, c_int32, c_int32, _P, _P]),
     "qf_coherent_layout": (c_int, [_P, _P, _P, c_int32, c_int32, _P, _P, _P]),
@@ -135,7 +135,7 @@ def lib() -> ctypes.CDLL:
             fn = getattr(handle, name)   # AttributeError if the symbol is not exported
             fn.restype = restype
             fn.argtypes = argtypes
-        if handle.qf_abi_version() != 1:
+        if handle.qf_abi_version() != 2:
             raise RuntimeError("libqf_hip.so ABI version mismatch")
         _lib = handle
     return _lib

@@ -149,39 +149,67 @@ struct OctList {
     }
 };
 
-__global__ __launch_bounds__(kTravThreads) void bvh8_traverse_kernel(
-    const float4 *__restrict__ nodes, const float4 *__restrict__ tris, int root_is_valid, const float *__restrict__ rays_o,
-    const float *__restrict__ rays_d, int64_t n_rays, int max_hits, int image_width, int image_height, int tiles_x,
-    int n_blocks, int blocks_per_xcd, int stack_cap, float min_sep, int32_t *__restrict__ hit_tri,
-    float *__restrict__ hit_t, int32_t *__restrict__ hit_count, int only_overflowed)
-{
-    extern __shared__ uint64_t trav_lds[];
-    const int K = max_hits;
-    const int tid = threadIdx.x, j = tid & 7, q = tid >> 3;
-    const int oct_base = (tid & 63) & 56;               // first lane of this octet within its wave
-    // XCD-aware block order: hardware deals workgroups round-robin to the 8 XCDs (private L2 each); XCD x walks the
-    // x-th CONTIGUOUS eighth of the blocks, i.e. one band of the image / one slice of the batch, so its L2 only has to
-    // hold that band's part of the tree
-    const int block = (int)(blockIdx.x & 7) * blocks_per_xcd + (int)(blockIdx.x >> 3);
-    if (block >= n_blocks) return;
-    int64_t ray;
-    if (image_width > 0) {          // workgroup = 8x4 pixels, wave = 4x2 pixels
-        const int w = q >> 3, r = q & 7;
-        const int px = (block % tiles_x) * 8 + (w & 1) * 4 + (r & 3);
-        const int py = (block / tiles_x) * 4 + (w >> 1) * 2 + (r >> 2);
-        if (px >= image_width || py >= image_height) return;
-        ray = (int64_t)py * image_width + px;
-    } else {
-        ray = (int64_t)block * kOctRays + q;
-    }
-    if (ray >= n_rays) return;
-    // repair pass after the camera-coherent intersector: only the rays whose candidate list overflowed are traversed
-    if (only_overflowed && hit_count[ray] <= K) return;
+struct TravArgs {
+    const float4 *nodes, *tris;
+    const float *rays_o, *rays_d;
+    int64_t n_rays;
+    int root_is_valid, max_hits, image_width, image_height, tiles_x, n_blocks, blocks_per_xcd, stack_cap;
+    float min_sep;
+    int32_t *hit_tri;
+    float *hit_t;
+    int32_t *hit_count;
+    uint64_t *keep_mask;         // repair launch only (see bvh8_repair_kernel)
+    int32_t *raw_count;
+};
 
+// LDS of a workgroup: [kOctRays][K] keys | [kOctRays][K] sorted (only when min_sep > 0) | [kOctRays][stack_cap] stack
+extern __shared__ uint64_t trav_lds[];
+
+// The re-origin rule for a ray whose complete, unordered list (c <= K entries) is in hit_t / hit_tri, WITHOUT rewriting
+// the list: bit i of the result = the i-th hit in (t, tri) order is kept.  Octet-uniform; *kept_out = number kept.
+__device__ __forceinline__ uint64_t oct_keep_mask(const TravArgs &a, int64_t ray, int c, int j, int q, int *kept_out)
+{
+    const int K = a.max_hits;
+    uint64_t *keys = trav_lds + (size_t)q * K;
+    uint64_t *sorted = trav_lds + (size_t)kOctRays * K + (size_t)q * K;
+    for (int e = j; e < c; e += 8) keys[e] = hit_key(a.hit_t[ray * K + e], a.hit_tri[ray * K + e]);
+    oct_lds_sync();
+    for (int e = j; e < c; e += 8) {
+        const uint64_t k = keys[e];
+        int rank = 0;
+        for (int i = 0; i < c; ++i) rank += keys[i] < k ? 1 : 0;
+        sorted[rank] = k;
+    }
+    oct_lds_sync();
+    float last = key_t(sorted[0]);
+    int kept = 1;
+    uint64_t mask = 1ull;
+    for (int i = 1; i < c; ++i) {
+        const float t = key_t(sorted[i]);
+        if (t > last + a.min_sep) { mask |= 1ull << i; ++kept; last = t; }
+    }
+    oct_lds_sync();
+    *kept_out = kept;
+    return mask;
+}
+
+// One ray, traversed by the 8 lanes of an octet (j = lane in the octet, q = the octet's LDS slot in the workgroup).
+__device__ __forceinline__ void oct_traverse_ray(const TravArgs &ta, int64_t ray, int j, int q, int oct_base)
+{
+    const int K = ta.max_hits;
+    const float min_sep = ta.min_sep;
+    const float4 *__restrict__ nodes = ta.nodes;
+    const float4 *__restrict__ tris = ta.tris;
+    const int stack_cap = ta.stack_cap;
     uint64_t *keys = trav_lds + (size_t)q * K;
     uint64_t *sorted = trav_lds + (size_t)kOctRays * K + (size_t)q * K;          // only when min_sep > 0
     int *stack = reinterpret_cast<int *>(trav_lds + (size_t)kOctRays * K * (min_sep > 0.0f ? 2 : 1)) + (size_t)q * stack_cap;
-
+    const float *rays_o = ta.rays_o, *rays_d = ta.rays_d;
+    const int root_is_valid = ta.root_is_valid;
+    float *hit_t = ta.hit_t;
+    int32_t *hit_tri = ta.hit_tri, *hit_count = ta.hit_count;
+    uint64_t *keep_mask = ta.keep_mask;
+    int32_t *raw_count = ta.raw_count;
     const float ox = rays_o[ray * 3], oy = rays_o[ray * 3 + 1], oz = rays_o[ray * 3 + 2];
     const float dx = rays_d[ray * 3], dy = rays_d[ray * 3 + 1], dz = rays_d[ray * 3 + 2];
     const float ix = safe_inv(dx), iy = safe_inv(dy), iz = safe_inv(dz);
@@ -318,7 +346,84 @@ __global__ __launch_bounds__(kTravThreads) void bvh8_traverse_kernel(
         oct_lds_sync();
     }
     for (int i = kept + j; i < K; i += 8) { my_t[i] = INFINITY; my_tri[i] = -1; }
-    if (j == 0) hit_count[ray] = kept;
+    if (j == 0) {
+        hit_count[ray] = kept;
+        if (keep_mask) { keep_mask[ray] = kept >= 64 ? ~0ull : ((1ull << kept) - 1ull); raw_count[ray] = kept; }
+    }
+}
+
+// XCD-aware block order: hardware deals workgroups round-robin to the 8 XCDs (private L2 each); XCD x walks the x-th
+// CONTIGUOUS eighth of the blocks, i.e. one band of the image / one slice of the batch, so its L2 only has to hold
+// that band's part of the tree.
+__device__ __forceinline__ int xcd_block(const TravArgs &a) { return (int)(blockIdx.x & 7) * a.blocks_per_xcd + (int)(blockIdx.x >> 3); }
+
+// Every ray of the batch: a workgroup = 32 rays (image-shaped batches: 8x4 pixels, a wave = 4x2 pixels).
+__global__ __launch_bounds__(kTravThreads) void bvh8_traverse_kernel(TravArgs a)
+{
+    const int tid = threadIdx.x, j = tid & 7, q = tid >> 3;
+    const int oct_base = (tid & 63) & 56;               // first lane of this octet within its wave
+    const int block = xcd_block(a);
+    if (block >= a.n_blocks) return;
+    int64_t ray;
+    if (a.image_width > 0) {
+        const int w = q >> 3, r = q & 7;
+        const int px = (block % a.tiles_x) * 8 + (w & 1) * 4 + (r & 3);
+        const int py = (block / a.tiles_x) * 4 + (w >> 1) * 2 + (r >> 2);
+        if (px >= a.image_width || py >= a.image_height) return;
+        ray = (int64_t)py * a.image_width + px;
+    } else {
+        ray = (int64_t)block * kOctRays + q;
+    }
+    if (ray >= a.n_rays) return;
+    oct_traverse_ray(a, ray, j, q, oct_base);
+}
+
+// The repair pass after the camera-coherent intersector: only the rays whose candidate list overflowed (count > K) are
+// traversed.  With keep_mask (and min_sep > 0) the same launch decides the re-origin rule for every OTHER ray's
+// complete, unordered list without rewriting it (oct_keep_mask): keep_mask[ray], raw_count[ray] = the length of the
+// stored list, hit_count[ray] = the number kept -- qf_pack_samples sorts the list the same way and drops the masked
+// entries.  A workgroup owns 256 consecutive rays: one lane per ray classifies them (coalesced count reads; rays with
+// fewer than two hits are finished here), the rays that need an octet are compacted into an LDS list, and the
+// workgroup's 32 octets work that list off -- no octet idles on a background ray.
+__global__ __launch_bounds__(kTravThreads) void bvh8_repair_kernel(TravArgs a)
+{
+    __shared__ int s_list[kTravThreads];
+    __shared__ int s_n;
+    const int tid = threadIdx.x, j = tid & 7, q = tid >> 3;
+    const int oct_base = (tid & 63) & 56;
+    const int block = xcd_block(a);
+    if (block >= a.n_blocks) return;
+    const int K = a.max_hits;
+    if (tid == 0) s_n = 0;
+    __syncthreads();
+    const int64_t ray0 = (int64_t)block * kTravThreads;
+    {
+        const int64_t ray = ray0 + tid;
+        if (ray < a.n_rays) {
+            const int c = a.hit_count[ray];
+            int need = 0;
+            if (c > K) need = 2;
+            else if (a.keep_mask) {
+                if (c >= 2) need = 1;
+                else { a.keep_mask[ray] = (uint64_t)c; a.raw_count[ray] = c; }       // 0 or 1 hit: mask 0b0 / 0b1
+            }
+            if (need) s_list[atomicAdd(&s_n, 1)] = tid | (need << 16);
+        }
+    }
+    __syncthreads();
+    const int n = s_n;
+    for (int e = q; e < n; e += kOctRays) {
+        const int entry = s_list[e];
+        const int64_t ray = ray0 + (entry & 0xffff);
+        if ((entry >> 16) == 2) {
+            oct_traverse_ray(a, ray, j, q, oct_base);
+        } else {
+            const int c = a.hit_count[ray];
+            int kept;
+            const uint64_t mask = oct_keep_mask(a, ray, c, j, q, &kept);
+            if (j == 0) { a.keep_mask[ray] = mask; a.raw_count[ray] = c; a.hit_count[ray] = kept; }
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -598,7 +703,7 @@ __global__ __launch_bounds__(kPackRays) void pack_samples_kernel(
     const int64_t *__restrict__ ray_offset, float *__restrict__ xyz, float *__restrict__ dirs,
     int64_t *__restrict__ index_ray, float *__restrict__ depth, int64_t *__restrict__ index_tri,
     float *__restrict__ origins, const int32_t *__restrict__ inverse, float *__restrict__ xyz_c,
-    float *__restrict__ dirs_c)
+    float *__restrict__ dirs_c, const uint64_t *__restrict__ keep_mask, const int32_t *__restrict__ raw_count)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int K = max_hits, Kp = max_hits | 1;            // odd row stride: conflict-free column access
@@ -621,7 +726,7 @@ __global__ __launch_bounds__(kPackRays) void pack_samples_kernel(
     const int64_t block_base = ray_offset[ray0];
     if (tid < nr) {
         const int64_t ray = ray0 + tid;
-        int cnt = hit_count[ray];
+        int cnt = keep_mask ? raw_count[ray] : hit_count[ray];
         if (cnt > K) cnt = K;
         float *row_t = s_t + tid * Kp;
         int32_t *row_i = s_tri + tid * Kp;
@@ -632,6 +737,13 @@ __global__ __launch_bounds__(kPackRays) void pack_samples_kernel(
             while (j >= 0 && hit_less(t, id, row_t[j], row_i[j])) { row_t[j + 1] = row_t[j]; row_i[j + 1] = row_i[j]; --j; }
             row_t[j + 1] = t;
             row_i[j + 1] = id;
+        }
+        if (keep_mask) {                                      // the re-origin rule, decided by qf_bvh_repair_overflow
+            const uint64_t mask = keep_mask[ray];
+            int kept = 0;
+            for (int i = 0; i < cnt; ++i)
+                if ((mask >> i) & 1ull) { row_t[kept] = row_t[i]; row_i[kept] = row_i[i]; ++kept; }
+            cnt = kept;
         }
         if (cnt > 1) {
             const double o64[3] = {(double)rays_o[ray * 3], (double)rays_o[ray * 3 + 1], (double)rays_o[ray * 3 + 2]};
@@ -1067,7 +1179,7 @@ int fill_tex_args(const qf_texture_set *tex, TexArgs *t)
 
 static int bvh_launch(const qf_bvh *bvh, const float *rays_o, const float *rays_d, int64_t n_rays, int32_t max_hits,
                       int32_t image_width, int32_t *hit_tri, float *hit_t, int32_t *hit_count, int only_overflowed,
-                      void *stream)
+                      uint64_t *keep_mask, int32_t *raw_count, void *stream)
 {
     if (!bvh || n_rays < 0 || max_hits < 1 || max_hits > kMaxHits || image_width < 0) return QF_ERR_INVALID_ARGUMENT;
     if (bvh->n_tri >= (1 << 28)) return QF_ERR_UNSUPPORTED;      // leaf tokens of the traversal pack (first, count)
@@ -1081,20 +1193,31 @@ static int bvh_launch(const qf_bvh *bvh, const float *rays_o, const float *rays_
         tiles_x = (image_width + 7) / 8;
         n_blocks = (int64_t)tiles_x * ((height + 3) / 4);
     }
-    const int64_t per_xcd = qf_div_up(n_blocks, 8);
-    if (per_xcd * 8 > 0x7fffffff) return QF_ERR_UNSUPPORTED;
     const bool sep = bvh->min_sep > 0.0f;
     const int stack_cap = (bvh->max_stack8 < 2 ? 2 : bvh->max_stack8) | 1;       // odd row stride
     const size_t lds = (size_t)kOctRays * ((size_t)max_hits * 8 * (sep ? 2 : 1) + (size_t)stack_cap * 4);
-    if (lds > 160 * 1024) return QF_ERR_UNSUPPORTED;
-    if (lds > 48 * 1024)
-        QF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(bvh8_traverse_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(bvh8_traverse_kernel, dim3((unsigned)(per_xcd * 8)), dim3(kTravThreads), lds, qf_stream(stream),
-                       reinterpret_cast<const float4 *>(bvh->d_nodes8), reinterpret_cast<const float4 *>(bvh->d_tris),
-                       bvh->n_tri > 0 ? 1 : 0, rays_o, rays_d, n_rays, (int)max_hits, (int)image_width, height, tiles_x,
-                       (int)n_blocks, (int)per_xcd, stack_cap, sep ? bvh->min_sep : 0.0f, hit_tri, hit_t, hit_count,
-                       only_overflowed);
+    if (lds > 160 * 1024 - 2048) return QF_ERR_UNSUPPORTED;
+    TravArgs a;
+    a.nodes = reinterpret_cast<const float4 *>(bvh->d_nodes8);
+    a.tris = reinterpret_cast<const float4 *>(bvh->d_tris);
+    a.rays_o = rays_o; a.rays_d = rays_d; a.n_rays = n_rays;
+    a.root_is_valid = bvh->n_tri > 0 ? 1 : 0;
+    a.max_hits = (int)max_hits; a.image_width = (int)image_width; a.image_height = height; a.tiles_x = tiles_x;
+    a.stack_cap = stack_cap; a.min_sep = sep ? bvh->min_sep : 0.0f;
+    a.hit_tri = hit_tri; a.hit_t = hit_t; a.hit_count = hit_count;
+    a.keep_mask = (only_overflowed && sep) ? keep_mask : nullptr;
+    a.raw_count = a.keep_mask ? raw_count : nullptr;
+    if (only_overflowed) n_blocks = qf_div_up(n_rays, kTravThreads);        // 256 consecutive rays per workgroup
+    const int64_t per_xcd = qf_div_up(n_blocks, 8);
+    if (per_xcd * 8 > 0x7fffffff) return QF_ERR_UNSUPPORTED;
+    a.n_blocks = (int)n_blocks; a.blocks_per_xcd = (int)per_xcd;
+    const void *fn = only_overflowed ? reinterpret_cast<const void *>(bvh8_repair_kernel)
+                                     : reinterpret_cast<const void *>(bvh8_traverse_kernel);
+    if (lds > 48 * 1024) QF_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (only_overflowed)
+        hipLaunchKernelGGL(bvh8_repair_kernel, dim3((unsigned)(per_xcd * 8)), dim3(kTravThreads), lds, qf_stream(stream), a);
+    else
+        hipLaunchKernelGGL(bvh8_traverse_kernel, dim3((unsigned)(per_xcd * 8)), dim3(kTravThreads), lds, qf_stream(stream), a);
     QF_LAUNCH_CHECK();
     return QF_OK;
 }
@@ -1125,22 +1248,26 @@ extern "C" int qf_bvh_intersect(const qf_bvh *bvh, const float *rays_o, const fl
                                 int32_t max_hits, int32_t image_width, int32_t *hit_tri, float *hit_t,
                                 int32_t *hit_count, void *stream)
 {
-    return bvh_launch(bvh, rays_o, rays_d, n_rays, max_hits, image_width, hit_tri, hit_t, hit_count, 0, stream);
+    return bvh_launch(bvh, rays_o, rays_d, n_rays, max_hits, image_width, hit_tri, hit_t, hit_count, 0, nullptr, nullptr,
+                      stream);
 }
 
 extern "C" int qf_bvh_repair_overflow(const qf_bvh *bvh, const float *rays_o, const float *rays_d, int64_t n_rays,
                                       int32_t max_hits, int32_t image_width, int32_t *hit_tri, float *hit_t,
-                                      int32_t *hit_count, void *stream)
+                                      int32_t *hit_count, uint64_t *keep_mask, int32_t *raw_count, void *stream)
 {
-    return bvh_launch(bvh, rays_o, rays_d, n_rays, max_hits, image_width, hit_tri, hit_t, hit_count, 1, stream);
+    if ((keep_mask == nullptr) != (raw_count == nullptr)) return QF_ERR_INVALID_ARGUMENT;
+    return bvh_launch(bvh, rays_o, rays_d, n_rays, max_hits, image_width, hit_tri, hit_t, hit_count, 1, keep_mask, raw_count,
+                      stream);
 }
 
 extern "C" int qf_pack_samples(const float *rays_o, const float *rays_d, int64_t n_rays, int32_t max_hits,
                                const int32_t *hit_tri, const float *hit_t, const int32_t *hit_count,
                                const int64_t *ray_offset, float *xyz, float *dirs, int64_t *index_ray, float *depth,
                                int64_t *index_tri, float *origins, const int32_t *inverse, float *xyz_c, float *dirs_c,
-                               void *stream)
+                               const uint64_t *keep_mask, const int32_t *raw_count, void *stream)
 {
+    if ((keep_mask == nullptr) != (raw_count == nullptr)) return QF_ERR_INVALID_ARGUMENT;
     if (n_rays < 0 || max_hits < 1 || max_hits > kMaxHits) return QF_ERR_INVALID_ARGUMENT;
     if (n_rays == 0) return QF_OK;
     if (!rays_o || !rays_d || !hit_tri || !hit_t || !hit_count || !ray_offset) return QF_ERR_INVALID_ARGUMENT;
@@ -1154,7 +1281,7 @@ extern "C" int qf_pack_samples(const float *rays_o, const float *rays_d, int64_t
     if (blocks > 0x7fffffff) return QF_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(pack_samples_kernel, dim3((unsigned)blocks), dim3(kPackRays), lds, qf_stream(stream), rays_o, rays_d,
                        n_rays, (int)max_hits, hit_tri, hit_t, hit_count, ray_offset, xyz, dirs, index_ray, depth, index_tri,
-                       origins, inverse, xyz_c, dirs_c);
+                       origins, inverse, xyz_c, dirs_c, keep_mask, raw_count);
     QF_LAUNCH_CHECK();
     return QF_OK;
 }

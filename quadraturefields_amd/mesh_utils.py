@@ -274,13 +274,17 @@ class RayIntersector:
                                                   _C.ptr(hit_tri), _C.ptr(hit_t), _C.ptr(hit_count), _C.ptr(overflow),
                                                   0, _C.stream()), "qf_raster_intersect")
         # pixels that collected more than K candidates: exact K nearest through the BVH, those rays only, no host
-        # round trip (afterwards every count is <= K)
+        # round trip (afterwards every count is <= K).  With the reference's re-origin rule on, the same launch decides
+        # it for every other ray as a keep-mask over its sorted list (the lists are not rewritten); the mask rides on
+        # the count tensor to qf_pack_samples.
+        mask = raw = None
+        if self.min_separation > 0:
+            mask = torch.empty((n,), dtype=torch.int64, device=self.device)
+            raw = torch.empty((n,), dtype=torch.int32, device=self.device)
         _C.check(_C.lib().qf_bvh_repair_overflow(self._handle, _C.ptr(o), _C.ptr(d), n, k, int(camera.width),
-                                                 _C.ptr(hit_tri), _C.ptr(hit_t), _C.ptr(hit_count), _C.stream()),
-                 "qf_bvh_repair_overflow")
-        if self.min_separation > 0:     # the reference's re-origin rule on the (now complete) lists; no launch when off
-            _C.check(_C.lib().qf_filter_hits(self._handle, n, k, _C.ptr(hit_tri), _C.ptr(hit_t), _C.ptr(hit_count),
-                                             _C.stream()), "qf_filter_hits")
+                                                 _C.ptr(hit_tri), _C.ptr(hit_t), _C.ptr(hit_count), _C.ptr(mask), _C.ptr(raw),
+                                                 _C.stream()), "qf_bvh_repair_overflow")
+        hit_count._qf_keep = (mask, raw) if mask is not None else None
         return hit_tri, hit_t, hit_count, overflow
 
     def pack_hits(self, o, d, k, hit_tri, hit_t, hit_count, overflow, width, lean=False, layout=True):
@@ -328,12 +332,14 @@ class RayIntersector:
             xyz_c = torch.empty((cap, 3), dtype=torch.float32, device=dev)
             dirs_c = torch.empty((cap, 3), dtype=torch.float32, device=dev)
             layout = (inverse, xyz_c, dirs_c)
+        keep = getattr(hit_count, "_qf_keep", None) or (None, None)      # from _hits_raster_frame (re-origin rule)
         _C.check(_C.lib().qf_pack_samples(_C.ptr(o), _C.ptr(d), n, k, _C.ptr(hit_tri), _C.ptr(hit_t),
                                           _C.ptr(hit_count), _C.ptr(buf), _C.ptr(xyz), _C.ptr(dirs),
                                           _C.ptr(index_ray), _C.ptr(depth), _C.ptr(index_tri), _C.ptr(org),
-                                          _C.ptr(inverse), _C.ptr(xyz_c), _C.ptr(dirs_c), _C.stream()), "qf_pack_samples")
+                                          _C.ptr(inverse), _C.ptr(xyz_c), _C.ptr(dirs_c), _C.ptr(keep[0]),
+                                          _C.ptr(keep[1]), _C.stream()), "qf_pack_samples")
         return (o, d, k, width, (lean, want_layout), host, ev, [xyz, dirs, index_ray, depth, index_tri, org], order, layout,
-                (hit_tri, hit_t, hit_count))          # the lists stay referenced until the kernels reading them ran
+                (hit_tri, hit_t, hit_count, keep))    # the lists stay referenced until the kernels reading them ran
 
     @_on_device
     def pack_hits_end(self, pending):

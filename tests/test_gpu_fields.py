@@ -218,3 +218,35 @@ def test_stale_order_is_refused(device):
     for bad in (good[:100], good.long(), good.cpu()):
         with pytest.raises(ValueError):
             field(x, d, order=bad)
+
+
+def test_ngp_rgb_and_density_at_the_baseline_table_size(device):
+    """BASELINE configs[1]: T = 2^19 (6 299 960 rows), the size bench.py runs -- colour AND density against the oracle,
+    in ray-major and in a permuted processing order."""
+    from quadraturefields_amd.radiance_fields.ngp import NGPRadianceField
+    f = _make(NGPRadianceField, device, log2_T=19)
+    assert f.mlp_base.grid.n_rows == 6299960
+    x, d = helpers.random_points(6000, seed=19)
+    w = helpers.oracle_ngp_weights(f)
+    rgb_o, den_o = ofields.ngp_forward(x, d, w)
+    rgb, den = f(x.to(device), d.to(device))
+    _close(rgb, rgb_o, 2e-5, 2e-5)
+    _close(den, den_o, 1e-7, 5e-5)
+    order = torch.randperm(6000, device=device).to(torch.int32)
+    rgb2, den2 = f(x.to(device), d.to(device), order=order)
+    assert torch.equal(rgb, rgb2) and torch.equal(den, den2)
+
+
+def test_bf16_field_at_the_config3_table_size(device):
+    """BASELINE configs[2]: T = 2^21 (22 565 520 rows), bf16 tables + MLPs: field_kernel_bf16 against the oracle that
+    rounds to bf16 at the same places (tolerances of test_bf16_ngp_matches_bf16_oracle)."""
+    from quadraturefields_amd.radiance_fields.ngp import NGPRadianceField
+    f = _make(NGPRadianceField, device, log2_T=21)
+    assert f.mlp_base.grid.n_rows == 22565520
+    f.compute_dtype = "bf16"
+    x, d = helpers.random_points(4000, seed=21)
+    w = helpers.oracle_ngp_weights(f)
+    rgb_o, den_o = ofields.ngp_forward_bf16(x, d, w)
+    rgb, den = f(x.to(device), d.to(device))
+    _close(rgb, rgb_o, 2e-3, 2e-3)
+    _close(den, den_o, 1e-6, 1e-2)

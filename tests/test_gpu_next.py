@@ -126,6 +126,13 @@ def test_bake_texture_images_producer(device):
         assert int(d_col.max()) <= 1 and float((d_col > 0).float().mean()) < 0.02
         lam = off_by(comp.lambdas[i][r, c][:, 0], want["lambdas"][i][:, 0])
         assert int(lam.max()) <= 1
+        # azimuth (channel 1) wraps mod 256 (code 0 and 255 are neighbours on the circle, ngp.py:236-248),
+        # elevation (channel 2) does not
+        az = (comp.lambdas[i][r, c][:, 1].cpu().to(torch.int16) - want["lambdas"][i][:, 1].to(torch.int16)) % 256
+        az = torch.minimum(az, 256 - az)
+        assert int(az.max()) <= 1 and float((az > 0).float().mean()) < 0.02
+        el = off_by(comp.lambdas[i][r, c][:, 2], want["lambdas"][i][:, 2])
+        assert int(el.max()) <= 1 and float((el > 0).float().mean()) < 0.02
     # save / reload round trip of the PNG set
     import tempfile
     with tempfile.TemporaryDirectory() as tmp:

@@ -155,3 +155,117 @@ def test_frame_renderer_and_upsample(device):
     # nothing in view
     rgb, alpha, depth, n = fr.render(o.to(device) + 100.0, d.to(device))
     assert n == 0 and bool((rgb == 1).all()) and float(alpha.sum()) == 0.0
+
+
+def test_crop_fixture_on_the_gpu(device):
+    """The committed 100x100 crop image (tests/golden/crop_ref.npz, written by the CPU oracle: configs[0]) against the
+    HIP path on the same rays: ids bit-exact, pixels within the stated 2e-4."""
+    import os
+    from quadraturefields_amd.mesh_utils import MeshIntersection
+    from quadraturefields_amd.render import FrameRenderer, psnr
+    from tests.golden import gen_crop
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "crop_ref.npz"))
+    mesh, field, idx, o, d = gen_crop.scene()
+    mi = MeshIntersection(mesh, simplify_mesh=False, scale=1.0, num_intersections=25)
+    data = mi.sampling_raytrace_device(d.to(device), o.to(device), image_width=gen_crop.CROP)
+    assert np.array_equal(data[2].cpu().numpy(), z["index_ray"]) and np.array_equal(data[4].cpu().numpy(), z["index_tri"])
+    rgb, alpha, depth, n = FrameRenderer(mi, field.to(device)).render(o.to(device), d.to(device), image_width=gen_crop.CROP)
+    assert n == int(z["n_samples"])
+    assert float((rgb.cpu() - torch.from_numpy(z["rgb"])).abs().max()) <= 2e-4
+    assert psnr(rgb.cpu(), torch.from_numpy(z["rgb"])) >= 70.0
+    assert float((alpha.cpu() - torch.from_numpy(z["alpha"])).abs().max()) <= 2e-4
+
+
+def test_config3_bf16_dense_shell_frame_matches_the_bf16_oracle(device):
+    """BASELINE configs[2] end to end at test size: a dense-shell scene (most object rays meet more than K = 6
+    triangles), the camera-coherent pass with WIDE candidate lists -> K-nearest selection -> per-ray repair -> pack ->
+    field_kernel_bf16 -> compositing, against brute-force quadrature points (bit-exact) and the bf16 oracle on them.
+    Pixel tolerance 1e-2: bf16 field outputs agree to 2e-3 (test_bf16_ngp_matches_bf16_oracle) and are amplified by the
+    density exponential and the transmittance product; fp32-vs-bf16 itself moves pixels by several 1e-2."""
+    from quadraturefields_amd import synthetic
+    from quadraturefields_amd.mesh_utils import MeshIntersection, make_camera
+    from quadraturefields_amd.radiance_fields.ngp import NGPRadianceField
+    from quadraturefields_amd.render import FrameRenderer, psnr
+    K, w, h = 6, 128, 72
+    mesh = synthetic.shell_mesh(n_shells=10, subdivisions=3)
+    mi = MeshIntersection(mesh, simplify_mesh=False, scale=1.0, num_intersections=K)
+    field = NGPRadianceField(aabb=[-1.5] * 3 + [1.5] * 3, log2_hashmap_size=15)
+    field.load_state_dict(synthetic.seeded_ngp_state(15, field.mlp_base.grid.n_rows), strict=False)
+    field = field.to(device)
+    field.compute_dtype = "bf16"
+    fr = FrameRenderer(mi, field)
+    focal = synthetic.lego_focal(800) * w / 800.0
+    wts = helpers.oracle_ngp_weights(field)
+    bf = om.BVHIntersector(mesh.vertices, mesh.faces)
+    ri = mi.rayintersector
+    seen_wide = False
+    for i, c2w in enumerate(synthetic.orbit_cameras(3, seed=8)):
+        o, d = synthetic.camera_rays(c2w, focal, w, h)
+        rgb, alpha, depth, n = fr.render(o.to(device), d.to(device), camera=make_camera(c2w, focal, w, h))
+        seen_wide = seen_wide or ri.raster_wide > K
+        sample = om.sampling_raytrace_numpy(bf, d.numpy(), o.numpy(), K)
+        data = om.to_loader_tensors(sample)
+        assert n == data[0].shape[0]
+        got = ri.sample_device(o.to(device), d.to(device), K, camera=make_camera(c2w, focal, w, h))
+        for a, b in zip(got, data):
+            assert torch.equal(a.cpu(), b)                      # quadrature points bit-exact through the wide route
+        rgbs, sig = ofields.ngp_forward_bf16(data[0], data[1], wts)
+        rgb_o = om.volrend.derive_properties(rgbs, sig.squeeze(-1), data[3], torch.full_like(data[3], 5e-3),
+                                             om.volrend.mark_pack_boundaries(data[2]), data[2], bg_color="white",
+                                             render_bkgd=None, N=w * h)[0]
+        assert float((rgb.cpu() - rgb_o).abs().max()) <= 1e-2
+        assert psnr(rgb.cpu(), rgb_o) >= 50.0
+    assert seen_wide and ri.repaired_frames >= 1          # the dense-scene policy (wide lists) was exercised
+
+
+def test_config5_baked_render_at_full_texture_size(device):
+    """BASELINE configs[4] at its full texture size (4096^2, L = 6; 1.07 GB of texel records): the packed-record shade
+    equals the planar one bit for bit on a frame's samples, untextured rays come out white with alpha 0, the render is
+    invariant to how the frame is split into bands, and a 64x64 crop agrees with the oracle's baked render."""
+    from quadraturefields_amd import synthetic, utils
+    from quadraturefields_amd.mesh_utils import MeshIntersection, make_camera
+    from quadraturefields_amd.radiance_fields.ngp import NGPRadianceFieldSGNew
+    from quadraturefields_amd.render import FrameRenderer
+    from quadraturefields_amd.texture_utils import FeatureCompression
+    lobes, size, w, h = 6, 4096, 256, 256
+    mesh = synthetic.shell_mesh(n_shells=4, subdivisions=4)
+    mi = MeshIntersection(mesh, simplify_mesh=False, scale=1.0, num_intersections=25)
+    tex = synthetic.random_textures(size, lobes, seed=2)
+    comp = FeatureCompression.from_arrays(tex["alpha"], tex["diffuse"], tex["colors"], tex["lambdas"],
+                                          compression_type="sigmoid", lambda_thres=7.5, device=device)
+    uv_np = synthetic.scaled_uv(mesh, size)
+    uv = torch.from_numpy(uv_np).to(device)
+    sg = NGPRadianceFieldSGNew(aabb=[-1.5] * 3 + [1.5] * 3, use_viewdirs=False, num_g_lobes=lobes, log2_hashmap_size=12).to(device)
+    fr = FrameRenderer(mi, sg)
+    c2w = synthetic.orbit_cameras(1, seed=6)[0]
+    focal = synthetic.lego_focal(800) * w / 800.0
+    o, d = synthetic.camera_rays(c2w, focal, w, h, device=device)
+    rgb, alpha, depth, n = fr.render_baked(o, d, uv, comp, camera=make_camera(c2w, focal, w, h))
+    assert comp.records().shape == (size * size, 64) and n > 50000
+    assert torch.isfinite(rgb).all() and float(rgb.min()) >= 0.0 and float(rgb.max()) <= 1.0
+    miss = alpha.reshape(-1) == 0
+    assert bool(miss.any()) and bool((rgb[miss] == 1).all())
+    # packed records vs the reference's planes on the frame's samples
+    data = mi.sampling_raytrace_device(d, o, camera=make_camera(c2w, focal, w, h), layout=False)
+    texel = utils.texel_indices(mi, uv, data[0], data[4], size)
+    a = comp.shade(texel, data[1], packed=True)
+    b = comp.shade(texel, data[1], packed=False)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    # two bands = the frame
+    from quadraturefields_amd import parallel
+    parts = []
+    for y0, y1 in ((0, 104), (104, h)):
+        r, al, de, _ = fr.render_baked(o[y0 * w:y1 * w], d[y0 * w:y1 * w], uv, comp,
+                                       camera=parallel.band_camera(c2w, focal, w, h, y0, y1))
+        parts.append(torch.cat([r, al, de], dim=1))
+    assert torch.equal(torch.cat(parts), torch.cat([rgb, alpha, depth], dim=1))
+    # a crop against the oracle (uint8 textures on the host)
+    ys, xs = torch.meshgrid(torch.arange(96, 160), torch.arange(96, 160), indexing="ij")
+    idx = (ys * w + xs).reshape(-1)
+    oc, dc = o.cpu()[idx], d.cpu()[idx]
+    sample = om.sampling_raytrace_numpy(om.BVHIntersector(mesh.vertices, mesh.faces), dc.numpy(), oc.numpy(), 25)
+    t = {"alpha": torch.from_numpy(tex["alpha"]), "diffuse": torch.from_numpy(tex["diffuse"]),
+         "colors": [torch.from_numpy(c) for c in tex["colors"]], "lambdas": [torch.from_numpy(c) for c in tex["lambdas"]]}
+    rgb_o = om.render_image_bake_texture(om.to_loader_tensors(sample), idx.shape[0], mesh.vertices, mesh.faces,
+                                         torch.from_numpy(uv_np), t, lobes, "sigmoid", 7.5)[0]
+    assert float((rgb.cpu()[idx] - rgb_o).abs().max()) <= 2e-4

@@ -1,5 +1,7 @@
 """CPU: the oracle against the reference's own known-answer vectors (docstrings of
 examples/field_rendering.py) and closed forms."""
+import os
+
 import numpy as np
 import torch
 
@@ -171,3 +173,30 @@ def test_ray_generation_conventions():
     # pixel (0,0): x = (0 - 2 + 0.5)/50, y = -(0 - 1 + 0.5)/50, z = -1 (OpenGL)
     want = torch.tensor([-1.5 / 50, 0.5 / 50, -1.0])
     assert torch.allclose(d[0], want / want.norm(), atol=1e-7)
+
+
+def test_config1_crop_render_on_the_cpu_matches_the_committed_image():
+    """BASELINE configs[0] (SURVEY.md 8c fixture 6): the 100x100 crop of the 800x800 synthetic camera rendered end to
+    end on the CPU by the oracle -- brute-force multi-hit intersection (re-origin rule on), sampling_raytrace_numpy,
+    the loader's casts, hash grid + MLPs, derive_properties -- against the committed tests/golden/crop_ref.npz
+    (written by tests/golden/gen_crop.py).  The same crop through the host BVH walk must give the same samples.  No GPU,
+    no product code on the data path (the product module only supplies the seeded state dict)."""
+    import numpy as np
+    import torch
+    from oracle import meshpath as om
+    from tests.golden import gen_crop
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "crop_ref.npz"))
+    mesh, field, idx, o, d = gen_crop.scene()
+    assert np.array_equal(idx.numpy(), z["ray_ids"])
+    (rgb, alpha, depth, n, _, _, iray, itri), data = gen_crop.render_oracle(mesh, field, o, d)
+    assert n == int(z["n_samples"])
+    assert np.array_equal(iray.numpy(), z["index_ray"]) and np.array_equal(itri.numpy(), z["index_tri"])      # bit-exact ids
+    assert np.abs(rgb.numpy() - z["rgb"]).max() <= 2e-6          # fp32 summation order of the CPU GEMMs may differ
+    assert np.abs(alpha.numpy() - z["alpha"]).max() <= 2e-6 and np.abs(depth.numpy() - z["depth"]).max() <= 2e-5
+    frac = float((z["alpha"] > 0).mean())
+    assert 0.2 < frac < 0.95                                      # object rim + background in the crop
+    (_, _, _, n2, _, _, iray2, itri2), data2 = gen_crop.render_oracle(
+        mesh, field, o, d, om.BVHIntersector(mesh.vertices, mesh.faces))
+    assert n2 == n and torch.equal(iray2, iray) and torch.equal(itri2, itri)
+    for a, b in zip(data, data2):
+        assert torch.equal(a, b)
