@@ -12,7 +12,8 @@ for path in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recur
         name = r.get("Kernel_Name", "")[:60]
         acc[name][r["Counter_Name"]].append((r.get("Dispatch_Id"), float(r["Counter_Value"])))
 for name, ctrs in sorted(acc.items()):
-    if not any(k in name for k in ("field_kernel", "bvh_traverse", "pack_samples", "derive_properties", "deform")):
+    if not any(k in name for k in ("field_kernel", "bvh8_", "raster_kernel", "pack_samples", "derive_properties", "deform", "texture_shade",
+                                   "grid_backward")):
         continue
     print(name)
     for c, vals in sorted(ctrs.items()):
