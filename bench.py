@@ -298,11 +298,21 @@ def sharded_frames(device, rank, world, scene0, n_scenes, frames_per_scene, back
               for _, mi, field in scenes]
 
     def loop(sync_each):
+        """sync_each: the host waits for every gathered frame (latency).  Otherwise frame i's gather is waited for
+        after frame i+1's band has been launched (throughput: the exchange overlaps the next render)."""
+        pending = frame = None
         for sr in shards:
             for i in range(frames_per_scene):
-                frame = sr.render(rays[i][0], rays[i][1], cams[i], focal, W, H)
+                started = sr.render_async(rays[i][0], rays[i][1], cams[i], focal, W, H)
                 if sync_each:
+                    frame = started()
                     torch.cuda.synchronize()
+                else:
+                    if pending is not None:
+                        frame = pending()
+                    pending = started
+        if pending is not None:
+            frame = pending()
         return frame
 
     def timed(sync_each):
@@ -387,17 +397,25 @@ def main():
     stages = Stages(mi, field)
     gather = world > 1 and not args.no_gather
     staged = gather and args.backend == "gloo"          # rehearsal: gloo moves host memory
-    gather_buf = torch.empty((world * W * H, 5), dtype=torch.float32, device="cpu" if staged else device) if gather else None
+    gather_bufs = [torch.empty((world * W * H, 5), dtype=torch.float32, device="cpu" if staged else device)
+                   for _ in range(2)] if gather else None
 
     def run(first, last, record):
-        """Frames [first, last), one after the other; returns (last rgb, total points)."""
-        pts, rgb = 0, None
+        """Frames [first, last), one after the other; returns (last rgb, total points).  N > 1: every finished frame is
+        all-gathered to every rank; the collective of frame i (RCCL's own stream) overlaps the render of frame i+1 and
+        is waited for before frame i+1's gather starts (two receive buffers alternate)."""
+        pts, rgb, pending = 0, None, None
         for i in range(first, last):
             rgb, alpha, depth, n_pts = stages.frame(rays[i][0], rays[i][1], cameras[i], record)
             if gather:
                 mine = torch.cat([rgb, alpha, depth], dim=1)
-                torch.distributed.all_gather_into_tensor(gather_buf, mine.cpu() if staged else mine)
+                mine = mine.cpu() if staged else mine
+                if pending is not None:
+                    pending[0].wait()
+                pending = (torch.distributed.all_gather_into_tensor(gather_bufs[i & 1], mine, async_op=True), mine)
             pts += n_pts
+        if pending is not None:
+            pending[0].wait()
         return rgb, pts
 
     # Device spin-up (untimed, before the W warm-up steps): the scene build leaves the GPU idle for seconds and its

@@ -69,6 +69,15 @@ int qf_grid_encode(const qf_grid_desc *desc /* host */, const float *table /* [r
  * NULL to skip.  grad_x01 [n,3] is overwritten; pass NULL to skip.                               */
 int qf_grid_encode_backward(const qf_grid_desc *desc /* host */, const float *table, const float *x01,
                             const float *dfeat, int64_t n, float *grad_table, float *grad_x01, void *stream);
+/* The same with a caller-provided device workspace (qf_grid_backward_workspace_bytes(n) bytes; torch memory in the
+ * Python layer): from 2^15 points on the table gradient is computed by the LDS-partitioned scatter -- every
+ * (level, 20 000-row partition, point chunk) accumulates in a workgroup's LDS and is added to grad_table with
+ * contiguous atomics, instead of one scattered memory-side atomic request per corner pair.  Same result up to fp32
+ * summation order.  workspace NULL / too small or a small batch: falls back to qf_grid_encode_backward.          */
+int64_t qf_grid_backward_workspace_bytes(int64_t n);
+int qf_grid_encode_backward_ws(const qf_grid_desc *desc, const float *table, const float *x01,
+                               const float *dfeat, int64_t n, float *grad_table, float *grad_x01,
+                               void *workspace, int64_t workspace_bytes, void *stream);
 
 /* Second order: the backward of the INPUT gradient above, grad_x01 = J(x; table)^T dfeat, which the reference
  * reaches through Field.field_grad(create_graph=True) (examples/field.py:206-238) and the losses on it

@@ -57,6 +57,8 @@ _SIGNATURES = {
     "qf_grid_desc_init": (c_int, [POINTER(GridDesc), c_uint32, c_uint32, c_uint32, c_double]),
     "qf_grid_encode": (c_int, [POINTER(GridDesc), _P, _P, c_int64, _P, _P]),
     "qf_grid_encode_backward": (c_int, [POINTER(GridDesc), _P, _P, _P, c_int64, _P, _P, _P]),
+    "qf_grid_backward_workspace_bytes": (c_int64, [c_int64]),
+    "qf_grid_encode_backward_ws": (c_int, [POINTER(GridDesc), _P, _P, _P, c_int64, _P, _P, _P, c_int64, _P]),
     "qf_grid_encode_double_backward": (c_int, [POINTER(GridDesc), _P, _P, _P, _P, c_int64, _P, _P, _P, _P]),
     "qf_grid_mlp_forward": (c_int, [POINTER(GridDesc), _P, _P, _P, c_int64, _P, _P]),
     "qf_field_forward": (c_int, [POINTER(FieldDesc), _P, _P, _P, POINTER(SGHead), _P, _P, c_int64, _P, _P, _P, _P, _P, _P]),
@@ -186,3 +188,14 @@ def make_grid_desc(n_levels: int, log2_hashmap_size: int, base_resolution: int, 
     check(lib().qf_grid_desc_init(ctypes.byref(d), n_levels, log2_hashmap_size, base_resolution,
                                   float(per_level_scale)), "qf_grid_desc_init")
     return d
+
+
+def grid_encode_backward(desc, table, x01, dfeat, n: int, grad_table, grad_x01) -> None:
+    """qf_grid_encode_backward with the workspace of the LDS-partitioned table scatter (torch memory) when the batch
+    is large enough for it to pay; tensors as the C entry point takes them (None -> NULL)."""
+    ws, ws_bytes = None, 0
+    if grad_table is not None and n >= (1 << 15):
+        ws_bytes = int(lib().qf_grid_backward_workspace_bytes(n))
+        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=x01.device)
+    check(lib().qf_grid_encode_backward_ws(desc, ptr(table), ptr(x01), ptr(dfeat), n, ptr(grad_table), ptr(grad_x01),
+                                           ptr(ws), ws_bytes, stream()), "qf_grid_encode_backward")

@@ -49,6 +49,120 @@ __global__ void grid_backward_table_kernel(GridArgs ga, const float *x01, const 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Table scatter WITHOUT global atomics on the data path ("LDS-partitioned scatter").  Scattered no-return atomics run
+// at the memory side at ~1.9e10 requests/s chip-wide whatever the kernel does (MI355X_MICROARCH.md, "Global float
+// atomics"; the quad kernel above sits at 1.8e10), so the table gradient of 2^20 points costs 3.7 ms.  Here every
+// level's rows are cut into partitions of kLdsRows rows (160 KB of LDS = 20 000 float2 accumulators); a workgroup owns
+// one (level, partition, point chunk): it walks ITS chunk of the points, recomputes their corner rows for that level
+// and adds the contributions that fall into its partition to the LDS accumulators (ds_add_f32); at the end it adds
+// its accumulators to the gradient table with CONTIGUOUS atomics (256 B per wave instruction: full rate, 1.3 TB/s).
+// The price is that the points are read once per partition -- 8-byte dfeat pairs in level-major order (transposed
+// once into the workspace) and 12-byte positions, out of L2 / the Infinity Cache -- and the corner rows are hashed
+// once per partition; both are cheap next to a scattered atomic.  What bounds the kernel is the LDS atomic pipe, so
+// the work is dealt by ATOMICS per workgroup: a coarse dense level is one partition in which every corner of every
+// point lands, and gets ~100 point chunks; a hashed level's 26 partitions get 4 each (with 3 chunks everywhere the
+// three workgroups of level 0 ran 7.1 ms while the rest of the chip idled).  1.97 ms per 2^20 points, T = 2^19,
+// against 3.69 ms for the quad-atomic kernel (tools/train_bench.py).
+constexpr int kLdsRows = 20000;
+constexpr int kScatterThreads = 1024;
+constexpr int kScatterUnroll = 8;
+
+struct ScatterPlan {
+    int first_item[QF_MAX_LEVELS + 1];   // workgroups [first_item[l], first_item[l+1]) serve level l
+    int chunks[QF_MAX_LEVELS];           // point chunks per partition of level l: a level with few partitions (coarse,
+                                         // dense: EVERY corner of every point is an LDS atomic of its one partition)
+                                         // gets many chunks, so that no workgroup carries more atomics than the others
+};
+
+// dfeat [n][32] -> level-major [16][n] float2 (one coalesced 512-B segment per level and 64 points)
+__global__ __launch_bounds__(256) void dfeat_level_major_kernel(const float *__restrict__ dfeat, int64_t n, float2 *__restrict__ out)
+{
+    __shared__ float tile[64][33];
+    const int64_t p0 = (int64_t)blockIdx.x * 64;
+    for (int e = threadIdx.x; e < 64 * 32; e += 256) {
+        const int r = e >> 5, c = e & 31;
+        tile[r][c] = (p0 + r < n) ? dfeat[(p0 + r) * 32 + c] : 0.0f;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 16 * 64; e += 256) {
+        const int l = e >> 6, r = e & 63;
+        if (p0 + r < n) out[(int64_t)l * n + p0 + r] = make_float2(tile[r][2 * l], tile[r][2 * l + 1]);
+    }
+}
+
+__global__ __launch_bounds__(kScatterThreads) void grid_backward_table_lds_kernel(GridArgs ga, ScatterPlan plan,
+                                                                                const float *__restrict__ x01,
+                                                                                const float2 *__restrict__ dfeat_lm,
+                                                                                int64_t n, float *__restrict__ grad_table)
+{
+    extern __shared__ float2 acc[];
+    int level = 0;
+    while (level < QF_MAX_LEVELS - 1 && (int)blockIdx.x >= plan.first_item[level + 1]) ++level;
+    const int local = (int)blockIdx.x - plan.first_item[level];
+    const int n_chunks = plan.chunks[level];
+    const int part = local / n_chunks, chunk = local - part * n_chunks;
+    const LevelConst lc = level_const(ga, level);
+    const uint32_t row_lo = (uint32_t)part * kLdsRows;
+    const uint32_t row_cnt = lc.rows - row_lo < (uint32_t)kLdsRows ? lc.rows - row_lo : (uint32_t)kLdsRows;
+    for (uint32_t i = threadIdx.x; i < row_cnt; i += kScatterThreads) acc[i] = make_float2(0.0f, 0.0f);
+    __syncthreads();
+    const int64_t p_lo = n * chunk / n_chunks, p_hi = n * (chunk + 1) / n_chunks;
+    const float2 *gl = dfeat_lm + (int64_t)level * n;
+    // kScatterUnroll points per lane and trip, all their loads issued before the first is used (the walk is a chain of
+    // dependent L2 / Infinity-Cache reads otherwise)
+    for (int64_t base = p_lo + threadIdx.x; base < p_hi; base += (int64_t)kScatterUnroll * kScatterThreads) {
+        float2 gf[kScatterUnroll];
+        float px[kScatterUnroll], py[kScatterUnroll], pz[kScatterUnroll];
+#pragma unroll
+        for (int u = 0; u < kScatterUnroll; ++u) {
+            const int64_t pt = base + (int64_t)u * kScatterThreads;
+            const bool ok = pt < p_hi;
+            const int64_t q = ok ? pt : p_lo;
+            gf[u] = gl[q];
+            if (!ok) gf[u] = make_float2(0.0f, 0.0f);
+            px[u] = x01[q * 3];
+            py[u] = x01[q * 3 + 1];
+            pz[u] = x01[q * 3 + 2];
+        }
+#pragma unroll
+        for (int u = 0; u < kScatterUnroll; ++u) {
+            uint32_t idx[8];
+            float frac[3];
+            level_indices(lc, px[u], py[u], pz[u], idx, frac);
+            // corners of this point that fall into the partition, as a bit mask; a lane has 8 / partitions of them on
+            // average, so the wave works the masks off one set bit per trip (2-3 trips) instead of issuing 16 LDS
+            // atomics with one or two lanes each -- the LDS atomic pipe, not memory, bounds this kernel
+            unsigned mask = 0;
+            if (gf[u].x != 0.0f || gf[u].y != 0.0f) {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) mask |= (idx[c] - lc.offset - row_lo < row_cnt) ? (1u << c) : 0u;
+            }
+            while (__any(mask != 0)) {
+                if (mask) {
+                    const int c = __ffs(mask) - 1;
+                    mask &= mask - 1;
+                    uint32_t id = idx[0];
+#pragma unroll
+                    for (int k = 1; k < 8; ++k) id = (c == k) ? idx[k] : id;
+                    const uint32_t r = id - lc.offset - row_lo;
+                    const float w = (((c & 1) ? frac[0] : 1.0f - frac[0]) * ((c & 2) ? frac[1] : 1.0f - frac[1])) *
+                                    ((c & 4) ? frac[2] : 1.0f - frac[2]);
+                    atomicAdd(&acc[r].x, w * gf[u].x);
+                    atomicAdd(&acc[r].y, w * gf[u].y);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    float *dst = grad_table + 2 * ((int64_t)lc.offset + row_lo);
+    const float *src = reinterpret_cast<const float *>(acc);
+    for (uint32_t i = threadIdx.x; i < 2 * row_cnt; i += kScatterThreads) {
+        const float v = src[i];
+        if (v != 0.0f) atomicAdd(dst + i, v);          // contiguous across the wave: full-rate atomics
+    }
+}
+
 __global__ void grid_backward_input_kernel(GridArgs ga, const float2 *table, const float *x01, const float *dfeat,
                                            int64_t n, float *dx)
 {
@@ -175,6 +289,56 @@ extern "C" int qf_grid_encode_backward(const qf_grid_desc *desc, const float *ta
     }
     if (grad_x01) {
         hipLaunchKernelGGL(grid_backward_input_kernel, dim3(qf_grid_1d(n, 256)), dim3(256), 0, qf_stream(stream), ga,
+                           reinterpret_cast<const float2 *>(table), x01, dfeat, n, grad_x01);
+        QF_LAUNCH_CHECK();
+    }
+    return QF_OK;
+}
+
+extern "C" int64_t qf_grid_backward_workspace_bytes(int64_t n) { return n < 0 ? -1 : n * 32 * (int64_t)sizeof(float); }
+
+extern "C" int qf_grid_encode_backward_ws(const qf_grid_desc *desc, const float *table, const float *x01,
+                                          const float *dfeat, int64_t n, float *grad_table, float *grad_x01,
+                                          void *workspace, int64_t workspace_bytes, void *stream)
+{
+    // small batches: the quad-atomic kernel (the partitioned scatter re-reads the points once per partition and
+    // flushes 160 KB per workgroup: it only pays from a few tens of thousands of points on)
+    if (!grad_table || !workspace || n < (1 << 15) || workspace_bytes < qf_grid_backward_workspace_bytes(n))
+        return qf_grid_encode_backward(desc, table, x01, dfeat, n, grad_table, grad_x01, stream);
+    if (!desc) return QF_ERR_INVALID_ARGUMENT;
+    GridArgs ga;
+    int rc = fill_grid_args(desc, &ga);
+    if (rc != QF_OK) return rc;
+    if (!x01 || !dfeat || (grad_x01 && !table)) return QF_ERR_INVALID_ARGUMENT;
+    hipStream_t st = qf_stream(stream);
+    float2 *lm = reinterpret_cast<float2 *>(workspace);
+    hipLaunchKernelGGL(dfeat_level_major_kernel, dim3((unsigned)qf_div_up(n, 64)), dim3(256), 0, st, dfeat, n, lm);
+    QF_LAUNCH_CHECK();
+    ScatterPlan plan;
+    // ~96 workgroups per level on 256 CUs (measured 32 / 64 / 96 / 128 / 256 per level: 2.35 / 2.05 / 1.96 / 1.98 / 2.07 ms)
+    const int per_level = 3 * qf_cu_count_cached() / 8 > 16 ? 3 * qf_cu_count_cached() / 8 : 16;
+    int item = 0;
+    for (int l = 0; l < QF_MAX_LEVELS; ++l) {
+        const int parts = (int)qf_div_up(ga.rows[l], kLdsRows);
+        int chunks = (per_level + parts / 2) / parts;
+        if (chunks < 1) chunks = 1;
+        plan.chunks[l] = chunks;
+        plan.first_item[l] = item;
+        item += parts * chunks;
+    }
+    plan.first_item[QF_MAX_LEVELS] = item;
+    const size_t lds = (size_t)kLdsRows * sizeof(float2);
+    static bool attr_set = false;
+    if (!attr_set) {
+        QF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(grid_backward_table_lds_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(grid_backward_table_lds_kernel, dim3((unsigned)item), dim3(kScatterThreads), lds, st, ga, plan, x01,
+                       lm, n, grad_table);
+    QF_LAUNCH_CHECK();
+    if (grad_x01) {
+        hipLaunchKernelGGL(grid_backward_input_kernel, dim3(qf_grid_1d(n, 256)), dim3(256), 0, st, ga,
                            reinterpret_cast<const float2 *>(table), x01, dfeat, n, grad_x01);
         QF_LAUNCH_CHECK();
     }

@@ -65,8 +65,7 @@ class _DeformTrainFn(torch.autograd.Function):
             _C.check(lib.qf_deform_mlp_backward(_C.ptr(enc), _C.ptr(x01), _C.ptr(_C.f32c(d_out.reshape(-1))),
                                                 *[_C.ptr(t) for t in ws], n, _C.ptr(d_enc), None,
                                                 *[_C.ptr(t) for t in grads], _C.stream()), "qf_deform_mlp_backward")
-            _C.check(lib.qf_grid_encode_backward(desc, _C.ptr(table), _C.ptr(x01), _C.ptr(d_enc), n, _C.ptr(g_table), None,
-                                                 _C.stream()), "qf_grid_encode_backward")
+            _C.grid_encode_backward(desc, table, x01, d_enc, n, g_table, None)
         return (None, g_table, *grads, None)
 
 

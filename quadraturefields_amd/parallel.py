@@ -79,14 +79,17 @@ def band_camera(c2w, focal: float, width: int, height: int, y0: int, y1: int):
     return cam
 
 
-def gather_bands(local: torch.Tensor, cuts: Sequence[int], width: int, rank: int, world_size: int) -> torch.Tensor:
+def gather_bands(local: torch.Tensor, cuts: Sequence[int], width: int, rank: int, world_size: int,
+                 async_op: bool = False):
     """local [rows_r * width, C] (this rank's band, row-major) -> the full frame [H * width, C] on every rank with
-    one ``all_gather_into_tensor`` of the bands padded to the tallest band."""
+    one ``all_gather_into_tensor`` of the bands padded to the tallest band.  ``async_op``: returns a zero-argument
+    callable instead; the collective runs on the backend's own stream (RCCL) beside whatever is launched next, and
+    calling the callable makes the current stream wait for it and assembles the frame."""
     rows = [cuts[r + 1] - cuts[r] for r in range(world_size)]
     if local.shape[0] != rows[rank] * width:
         raise ValueError(f"rank {rank}: band has {local.shape[0]} rays, expected {rows[rank] * width}")
     if world_size == 1:
-        return local
+        return (lambda: local) if async_op else local
     c = local.shape[1]
     cap = max(rows) * width
     send = local if local.shape[0] == cap else torch.cat(
@@ -94,11 +97,18 @@ def gather_bands(local: torch.Tensor, cuts: Sequence[int], width: int, rank: int
     staged = local.is_cuda and dist.get_backend() == "gloo"     # rehearsal on one GPU: gloo moves host memory
     if staged:
         send = send.cpu()
+    send = send.contiguous()
     buf = torch.empty((world_size * cap, c), dtype=send.dtype, device=send.device)
-    dist.all_gather_into_tensor(buf, send.contiguous())
-    buf = buf.view(world_size, cap, c)
-    frame = torch.cat([buf[r, :rows[r] * width] for r in range(world_size)], dim=0)
-    return frame.to(local.device) if staged else frame
+    work = dist.all_gather_into_tensor(buf, send, async_op=async_op)
+
+    def finish():
+        if work is not None:
+            work.wait()                       # current stream waits for the collective; send / buf stay referenced here
+        b = buf.view(world_size, cap, c)
+        frame = torch.cat([b[r, :rows[r] * width] for r in range(world_size)], dim=0)
+        return frame.to(local.device) if staged else frame
+
+    return finish if async_op else finish()
 
 
 class ShardedFrameRenderer:
@@ -135,14 +145,25 @@ class ShardedFrameRenderer:
         return torch.cat([rgb, alpha, depth], dim=1)
 
     def render(self, origins, viewdirs, c2w, focal, width: int, height: int) -> torch.Tensor:
+        return self.render_async(origins, viewdirs, c2w, focal, width, height)()
+
+    def render_async(self, origins, viewdirs, c2w, focal, width: int, height: int):
+        """Renders this rank's band and STARTS the gather; returns a callable that waits for it and returns the frame.
+        A frame loop calls it after launching the next frame's band, so the exchange (RCCL's stream) overlaps that
+        render.  Frames must be finished in the order they were started."""
         if origins.shape[0] != width * height:
             raise ValueError("origins / viewdirs must be the frame's full row-major ray arrays")
         cuts = self.last_cuts = self.cuts_for(height)
         local = self.render_band(origins, viewdirs, c2w, focal, width, height, cuts[self.rank], cuts[self.rank + 1])
-        frame = gather_bands(local, cuts, width, self.rank, self.world)
-        if self.balance:
-            self._push_profile(frame, width, height)
-        return frame
+        pending = gather_bands(local, cuts, width, self.rank, self.world, async_op=True)
+
+        def finish():
+            frame = pending()
+            if self.balance:
+                self._push_profile(frame, width, height)
+            return frame
+
+        return finish
 
     def _push_profile(self, frame, width, height):
         rows = (frame[:, 3] > 0).view(height, width).sum(dim=1, dtype=torch.float32)

@@ -326,8 +326,7 @@ class _NGPTrainFn(torch.autograd.Function):
                                              _C.ptr(d_enc), _C.ptr(g_net), _C.ptr(g_head), _C.stream()),
                      "qf_ngp_mlp_backward")
             if need_base or need_x:
-                _C.check(lib.qf_grid_encode_backward(desc, _C.ptr(table), _C.ptr(x01), _C.ptr(d_enc), n, _C.ptr(g_table),
-                                                     _C.ptr(g_x01), _C.stream()), "qf_grid_encode_backward")
+                _C.grid_encode_backward(desc, table, x01, d_enc, n, g_table, g_x01)
         g_pos = None
         if need_x:
             lo, hi = torch.split(m.aabb, 3, dim=-1)
@@ -393,8 +392,7 @@ class _SGTrainFn(torch.autograd.Function):
                                             _C.ptr(d_enc), _C.ptr(g_net), ctypes.byref(ghead), _C.stream()),
                      "qf_sg_mlp_backward")
             if need_base or need_x:
-                _C.check(lib.qf_grid_encode_backward(desc, _C.ptr(table), _C.ptr(x01), _C.ptr(d_enc), n, _C.ptr(g_table),
-                                                     _C.ptr(g_x01), _C.stream()), "qf_grid_encode_backward")
+                _C.grid_encode_backward(desc, table, x01, d_enc, n, g_table, g_x01)
         g_pos = None
         if need_x:
             lo, hi = torch.split(m.aabb, 3, dim=-1)

@@ -135,9 +135,7 @@ class _GridEncodeFn(torch.autograd.Function):
         if need_t:
             gt = torch.zeros_like(table_c)
             if n:
-                _C.check(_C.lib().qf_grid_encode_backward(ctx.desc, _C.ptr(table_c), _C.ptr(x01_c),
-                                                          _C.ptr(_C.f32c(dfeat.detach())), n, _C.ptr(gt), None,
-                                                          _C.stream()), "qf_grid_encode_backward")
+                _C.grid_encode_backward(ctx.desc, table_c, x01_c, _C.f32c(dfeat.detach()), n, gt, None)
         if need_x:
             if torch.is_grad_enabled() and (dfeat.requires_grad or x01.requires_grad or table.requires_grad):
                 # create_graph=True: keep the input gradient in the graph

@@ -90,6 +90,17 @@ def main():
     lib = _C.lib()
     out["grid_backward_table_ms"] = _time(lambda: _C.check(lib.qf_grid_encode_backward(
         mb.grid.desc, _C.ptr(table), _C.ptr(x01), _C.ptr(dfeat), args.n, _C.ptr(gt), None, _C.stream()), "bwd"), args.iters)
+    ws = torch.empty((int(lib.qf_grid_backward_workspace_bytes(args.n)),), dtype=torch.uint8, device=dev)
+    out["grid_backward_table_lds_ms"] = _time(lambda: _C.check(lib.qf_grid_encode_backward_ws(
+        mb.grid.desc, _C.ptr(table), _C.ptr(x01), _C.ptr(dfeat), args.n, _C.ptr(gt), None, _C.ptr(ws), ws.numel(),
+        _C.stream()), "bwd"), args.iters)
+    ga, gb = torch.zeros_like(table), torch.zeros_like(table)
+    _C.check(lib.qf_grid_encode_backward(mb.grid.desc, _C.ptr(table), _C.ptr(x01), _C.ptr(dfeat), args.n, _C.ptr(ga), None,
+                                         _C.stream()), "bwd")
+    _C.check(lib.qf_grid_encode_backward_ws(mb.grid.desc, _C.ptr(table), _C.ptr(x01), _C.ptr(dfeat), args.n, _C.ptr(gb), None,
+                                            _C.ptr(ws), ws.numel(), _C.stream()), "bwd")
+    out["table_grad_max_abs_diff_quad_vs_lds"] = float((ga - gb).abs().max())
+    out["table_grad_max_abs"] = float(ga.abs().max())
     out["grid_backward_input_ms"] = _time(lambda: _C.check(lib.qf_grid_encode_backward(
         mb.grid.desc, _C.ptr(table), _C.ptr(x01), _C.ptr(dfeat), args.n, None, _C.ptr(gx), _C.stream()), "bwd"), args.iters)
     out["train_points_per_s"] = args.n / (out["train_step_ms"] * 1e-3)
