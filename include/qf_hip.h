@@ -407,6 +407,15 @@ int64_t qf_sample_offsets_temp_bytes(int64_t n_rays);
 int qf_sample_offsets(const int32_t *hit_count, int64_t n_rays, int32_t max_hits,
                       int64_t *ray_offset /* [n_rays+1] */, void *temp, int64_t temp_bytes, void *stream);
 
+/* One frame's offsets in three small launches: ray_offset [n_rays+1] exactly as qf_sample_offsets, and -- when
+ * tile_base is not NULL (rays = a row-major width x height image) -- tile_base [ceil(w/8)*ceil(h/8)] = the exclusive
+ * scan of the 8x8-tile sample totals that qf_coherent_layout takes (round 1: qf_tile_totals + a host-side cumsum).
+ * temp: qf_frame_offsets_temp_bytes(n_rays) bytes of device scratch.                              */
+int64_t qf_frame_offsets_temp_bytes(int64_t n_rays);
+int qf_frame_offsets(const int32_t *hit_count, int64_t n_rays, int32_t max_hits, int32_t width, int32_t height,
+                     int64_t *ray_offset /* [n_rays+1] */, int64_t *tile_base /* or NULL */, void *temp,
+                     int64_t temp_bytes, void *stream);
+
 /* Packs the per-ray hit lists into the sample arrays sampling_raytrace_numpy returns
  * (mesh_utils.py:359-387), already sorted by (ray, depth): location = o + t d in float64,
  * dirs = d/(|d|+1e-7), depth = |location - o| (float64, rounded to fp32 at the end).

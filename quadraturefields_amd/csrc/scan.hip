@@ -51,3 +51,153 @@ extern "C" int qf_sample_offsets(const int32_t *hit_count, int64_t n_rays, int32
                                                (int)(n_rays + 1), qf_stream(stream)));
     return QF_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// One frame's offsets in three small launches: the per-ray sample offsets (as qf_sample_offsets) AND, for an image-shaped
+// batch, the exclusive scan of the 8x8-tile totals that qf_coherent_layout needs -- round 1 issued a library scan (two
+// kernels), qf_tile_totals, torch.cumsum (two kernels) and a subtraction for the same numbers.
+//   1. frame_partials_kernel: workgroup b < n_blocks sums min(count, K) over its 1024 rays; the workgroups after those
+//      compute the tile totals (one wave per tile, four tiles per workgroup);
+//   2. frame_scan_kernel: ONE workgroup turns both arrays into exclusive prefix sums in place (a few thousand
+//      elements) and writes the grand total to ray_offset[n_rays];
+//   3. frame_ray_offsets_kernel: every workgroup scans its 1024 rays from its base.
+namespace {
+
+constexpr int kFoRays = 1024;          // rays per workgroup in steps 1 and 3
+constexpr int kFoThreads = 256;
+
+__device__ __forceinline__ int64_t clamped(const int32_t *hit_count, int64_t r, int64_t n, int32_t cap)
+{
+    if (r >= n) return 0;
+    const int32_t c = hit_count[r];
+    return c < 0 ? 0 : (c < cap ? c : cap);
+}
+
+// block-wide inclusive scan of one int64 per thread (kFoThreads threads); returns the inclusive value, *total = block sum
+__device__ __forceinline__ int64_t block_inclusive_scan(int64_t v, int64_t *s_wave, int64_t *total)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int64_t o = __shfl_up(v, off, 64);
+        if (lane >= off) v += o;
+    }
+    if (lane == 63) s_wave[wave] = v;
+    __syncthreads();
+    int64_t base = 0, sum = 0;
+    for (int w = 0; w < kFoThreads / 64; ++w) {
+        if (w < wave) base += s_wave[w];
+        sum += s_wave[w];
+    }
+    __syncthreads();
+    *total = sum;
+    return v + base;
+}
+
+__global__ __launch_bounds__(kFoThreads) void frame_partials_kernel(const int32_t *__restrict__ hit_count, int64_t n_rays,
+                                                                    int32_t cap, int n_blocks, int w, int h, int tiles_x,
+                                                                    int n_tiles, int64_t *__restrict__ partial,
+                                                                    int64_t *__restrict__ tile_total)
+{
+    __shared__ int64_t s_wave[kFoThreads / 64];
+    if ((int)blockIdx.x < n_blocks) {
+        const int64_t r0 = (int64_t)blockIdx.x * kFoRays;
+        int64_t v = 0;
+#pragma unroll
+        for (int k = 0; k < kFoRays / kFoThreads; ++k) v += clamped(hit_count, r0 + threadIdx.x + (int64_t)k * kFoThreads, n_rays, cap);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        if ((threadIdx.x & 63) == 0) s_wave[threadIdx.x >> 6] = v;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int64_t s = 0;
+            for (int q = 0; q < kFoThreads / 64; ++q) s += s_wave[q];
+            partial[blockIdx.x] = s;
+        }
+        return;
+    }
+    const int tile = ((int)blockIdx.x - n_blocks) * (kFoThreads / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (tile >= n_tiles) return;
+    const int px = (tile % tiles_x) * 8 + (lane & 7), py = (tile / tiles_x) * 8 + (lane >> 3);
+    int64_t cnt = (px < w && py < h) ? clamped(hit_count, (int64_t)py * w + px, n_rays, cap) : 0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
+    if (lane == 0) tile_total[tile] = cnt;
+}
+
+__global__ __launch_bounds__(kFoThreads) void frame_scan_kernel(int64_t *partial, int n_blocks, int64_t *tile_total, int n_tiles,
+                                                                int64_t *grand_total)
+{
+    __shared__ int64_t s_wave[kFoThreads / 64];
+    for (int pass = 0; pass < 2; ++pass) {
+        int64_t *a = pass == 0 ? partial : tile_total;
+        const int m = pass == 0 ? n_blocks : n_tiles;
+        if (!a) continue;
+        int64_t carry = 0;
+        for (int i0 = 0; i0 < m; i0 += kFoThreads) {
+            const int i = i0 + threadIdx.x;
+            const int64_t v = i < m ? a[i] : 0;
+            int64_t total;
+            const int64_t inc = block_inclusive_scan(v, s_wave, &total);
+            if (i < m) a[i] = carry + inc - v;
+            carry += total;
+        }
+        if (pass == 0 && threadIdx.x == 0) *grand_total = carry;
+    }
+}
+
+__global__ __launch_bounds__(kFoThreads) void frame_ray_offsets_kernel(const int32_t *__restrict__ hit_count, int64_t n_rays,
+                                                                       int32_t cap, const int64_t *__restrict__ partial,
+                                                                       int64_t *__restrict__ ray_offset)
+{
+    __shared__ int64_t s_wave[kFoThreads / 64];
+    const int64_t r0 = (int64_t)blockIdx.x * kFoRays + (int64_t)threadIdx.x * (kFoRays / kFoThreads);
+    int64_t c[kFoRays / kFoThreads], v = 0;
+#pragma unroll
+    for (int k = 0; k < kFoRays / kFoThreads; ++k) { c[k] = clamped(hit_count, r0 + k, n_rays, cap); v += c[k]; }
+    int64_t total;
+    int64_t run = partial[blockIdx.x] + block_inclusive_scan(v, s_wave, &total) - v;
+#pragma unroll
+    for (int k = 0; k < kFoRays / kFoThreads; ++k) {
+        if (r0 + k < n_rays) ray_offset[r0 + k] = run;
+        run += c[k];
+    }
+}
+
+}  // namespace
+
+extern "C" int64_t qf_frame_offsets_temp_bytes(int64_t n_rays)
+{
+    if (n_rays < 0) return -1;
+    return (qf_div_up(n_rays, kFoRays) + 1) * (int64_t)sizeof(int64_t);
+}
+
+extern "C" int qf_frame_offsets(const int32_t *hit_count, int64_t n_rays, int32_t max_hits, int32_t width, int32_t height,
+                                int64_t *ray_offset, int64_t *tile_base, void *temp, int64_t temp_bytes, void *stream)
+{
+    if (n_rays < 0 || n_rays >= 0x7fffffff || max_hits < 1 || width < 0 || height < 0) return QF_ERR_INVALID_ARGUMENT;
+    if (!ray_offset || !temp || (n_rays > 0 && !hit_count)) return QF_ERR_INVALID_ARGUMENT;
+    if (temp_bytes < qf_frame_offsets_temp_bytes(n_rays)) return QF_ERR_INVALID_ARGUMENT;
+    const bool tiles = tile_base != nullptr;
+    if (tiles && (width < 1 || height < 1 || (int64_t)width * height != n_rays)) return QF_ERR_INVALID_ARGUMENT;
+    hipStream_t st = qf_stream(stream);
+    const int n_blocks = (int)qf_div_up(n_rays, kFoRays);
+    const int tiles_x = tiles ? (width + 7) / 8 : 0;
+    const int n_tiles = tiles ? tiles_x * ((height + 7) / 8) : 0;
+    int64_t *partial = reinterpret_cast<int64_t *>(temp);
+    const int tile_blocks = (int)qf_div_up(n_tiles, kFoThreads / 64);
+    if (n_blocks + tile_blocks > 0) {
+        hipLaunchKernelGGL(frame_partials_kernel, dim3((unsigned)(n_blocks + tile_blocks)), dim3(kFoThreads), 0, st, hit_count,
+                           n_rays, max_hits, n_blocks, (int)width, (int)height, tiles_x, n_tiles, partial, tile_base);
+        QF_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(frame_scan_kernel, dim3(1), dim3(kFoThreads), 0, st, partial, n_blocks, tile_base, n_tiles,
+                       ray_offset + n_rays);
+    QF_LAUNCH_CHECK();
+    if (n_blocks > 0) {
+        hipLaunchKernelGGL(frame_ray_offsets_kernel, dim3((unsigned)n_blocks), dim3(kFoThreads), 0, st, hit_count, n_rays,
+                           max_hits, partial, ray_offset);
+        QF_LAUNCH_CHECK();
+    }
+    return QF_OK;
+}

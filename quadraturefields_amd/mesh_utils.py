@@ -240,9 +240,9 @@ class RayIntersector:
         s = self._scratch.get(key)
         if s is None:
             buf = torch.zeros((n + 2,), dtype=torch.int64, device=self.device)
-            nbytes = int(_C.lib().qf_sample_offsets_temp_bytes(n))
+            nbytes = int(_C.lib().qf_frame_offsets_temp_bytes(n))
             if nbytes < 0:
-                raise _C.QFError("qf_sample_offsets_temp_bytes failed")
+                raise _C.QFError("qf_frame_offsets_temp_bytes failed")
             temp = torch.empty((nbytes,), dtype=torch.uint8, device=self.device)
             host = torch.zeros((2,), dtype=torch.int64).pin_memory()
             s = self._scratch[key] = (buf, temp, host, torch.cuda.Event())
@@ -310,12 +310,18 @@ class RayIntersector:
         buf, temp, host, ev = self._frame_scratch(n)
         if overflow is None:
             buf[n + 1].zero_()
-        _C.check(_C.lib().qf_sample_offsets(_C.ptr(hit_count), n, k, _C.ptr(buf), _C.ptr(temp), temp.numel(),
-                                            _C.stream()), "qf_sample_offsets")
-        host.copy_(buf[n:], non_blocking=True)
-        ev.record()
         cap = n * k
         image = bool(layout) and width > 0 and n % width == 0
+        # sample offsets (+ total) and, for an image, the tile bases of the coherent order: three small launches
+        tile_base = None
+        if image:
+            height = n // width
+            tile_base = torch.empty((((width + 7) // 8) * ((height + 7) // 8),), dtype=torch.int64, device=dev)
+        _C.check(_C.lib().qf_frame_offsets(_C.ptr(hit_count), n, k, int(width) if image else 0, n // width if image else 0,
+                                           _C.ptr(buf), _C.ptr(tile_base), _C.ptr(temp), temp.numel(), _C.stream()),
+                 "qf_frame_offsets")
+        host.copy_(buf[n:], non_blocking=True)
+        ev.record()
         lean = bool(lean) and image
         want_layout = layout
         xyz = dirs = org = None
@@ -328,7 +334,7 @@ class RayIntersector:
         depth = torch.empty((cap,), dtype=torch.float32, device=dev)
         order = inverse = xyz_c = dirs_c = layout = None          # (from here on ``layout`` is the result tuple)
         if image:                             # the coherent order, its inverse, and streamed copies
-            order, inverse = self.coherent_layout(hit_count, buf, cap, width)
+            order, inverse = self.coherent_layout(hit_count, buf, cap, width, tile_base)
             xyz_c = torch.empty((cap, 3), dtype=torch.float32, device=dev)
             dirs_c = torch.empty((cap, 3), dtype=torch.float32, device=dev)
             layout = (inverse, xyz_c, dirs_c)
@@ -386,20 +392,22 @@ class RayIntersector:
         return data
 
     @_on_device
-    def coherent_layout(self, hit_count, ray_offset, total: int, width: int):
+    def coherent_layout(self, hit_count, ray_offset, total: int, width: int, tile_base=None):
         """``coherent_order`` and its inverse map (``inverse[sample] = position``).  Given the inverse,
         ``qf_pack_samples`` also writes ``xyz[order]`` / ``dirs[order]``, so ``field(xyz_c, dirs_c)`` reads and writes
         sequentially (the indirection through ``order`` costs it 10 %), and
-        ``derive_properties(..., sample_index=inverse)`` picks colour and density back up per ray."""
+        ``derive_properties(..., sample_index=inverse)`` picks colour and density back up per ray.  ``tile_base``: the
+        exclusive scan of the tile totals when ``qf_frame_offsets`` already produced it."""
         height = hit_count.shape[0] // width
         tiles = ((width + 7) // 8) * ((height + 7) // 8)
         dev = hit_count.device
-        totals = torch.empty((tiles,), dtype=torch.int64, device=dev)
-        _C.check(_C.lib().qf_tile_totals(_C.ptr(hit_count), width, height, _C.ptr(totals), _C.stream()), "qf_tile_totals")
-        base = (torch.cumsum(totals, dim=0) - totals).contiguous()
+        if tile_base is None:
+            totals = torch.empty((tiles,), dtype=torch.int64, device=dev)
+            _C.check(_C.lib().qf_tile_totals(_C.ptr(hit_count), width, height, _C.ptr(totals), _C.stream()), "qf_tile_totals")
+            tile_base = (torch.cumsum(totals, dim=0) - totals).contiguous()
         order = torch.empty((total,), dtype=torch.int32, device=dev)
         inverse = torch.empty((total,), dtype=torch.int32, device=dev)
-        _C.check(_C.lib().qf_coherent_layout(_C.ptr(hit_count), _C.ptr(ray_offset), _C.ptr(base), width, height,
+        _C.check(_C.lib().qf_coherent_layout(_C.ptr(hit_count), _C.ptr(ray_offset), _C.ptr(tile_base), width, height,
                                              _C.ptr(order), _C.ptr(inverse), _C.stream()), "qf_coherent_layout")
         return order, inverse
 
