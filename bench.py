@@ -99,15 +99,16 @@ class Stages:
         hit_tri, hit_t, hit_count, overflow = hits
         pending = self._timed("pack", lambda: ri.pack_hits_begin(o, d, MAX_HITS, hit_tri, hit_t, hit_count, overflow,
                                                                  self.width, lean=self.coherent), record)
-        return pending, overflow is not None, record, o.shape[0]
+        return pending, overflow is not None, record, o.shape[0], (o, d, cam)
 
     def finish(self, begun):
         """Second half, on the stream ``begin`` ran on: wait for the sample count, field, compositing."""
         from quadraturefields_amd import utils
-        pending, rastered, record, n_rays = begun
+        pending, rastered, record, n_rays, frame_in = begun
         ri = self.mi.rayintersector
         before = ri._raster_backoff
-        data, order = ri.pack_hits_end(pending)
+        # the intersector's optimistic re-origin check is read after the field / compositing launches (rule_violated)
+        data, order = ri.pack_hits_end(pending, defer_rule_check=True)
         if rastered and ri._raster_backoff > before:
             self.fallbacks = getattr(self, "fallbacks", 0) + 1
         xyz, dirs, index_ray, ts, index_tri, org = data
@@ -121,6 +122,9 @@ class Stages:
         out = self._timed("composite", lambda: utils.derive_properties(
             rgbs, sigmas.reshape(-1), ts, STEP, None, index_ray, bg_color="white", N=n_rays, sample_index=inverse), record)
         rgb, alpha, _, depth, _ = out
+        if ri.rule_violated():          # some ray had hits closer than the re-origin distance: this frame again, exactly
+            self.rule_redone = getattr(self, "rule_redone", 0) + 1
+            return self.frame(*frame_in, record)
         return rgb, alpha, depth, index_ray.shape[0]
 
     def _pack(self, hits):
@@ -513,6 +517,7 @@ def main():
             "min_hit_separation": float(mi.rayintersector.min_separation),
             "bvh_fallback_frames": getattr(stages, "fallbacks", 0),
             "overflow_repaired_frames": mi.rayintersector.repaired_frames,
+            "reorigin_rule_redone_frames": mi.rayintersector.rule_redone_frames,
             "parallelism": f"{world} rank(s), the frames dealt round-robin to the ranks, one frame per rank per step"
                            + (", all_gather_into_tensor of the finished frames" if gather else ", no data-path collective"),
         },

@@ -410,11 +410,14 @@ int qf_sample_offsets(const int32_t *hit_count, int64_t n_rays, int32_t max_hits
 /* One frame's offsets in three small launches: ray_offset [n_rays+1] exactly as qf_sample_offsets, and -- when
  * tile_base is not NULL (rays = a row-major width x height image) -- tile_base [ceil(w/8)*ceil(h/8)] = the exclusive
  * scan of the 8x8-tile sample totals that qf_coherent_layout takes (round 1: qf_tile_totals + a host-side cumsum).
- * temp: qf_frame_offsets_temp_bytes(n_rays) bytes of device scratch.                              */
+ * temp: qf_frame_offsets_temp_bytes(n_rays) bytes of device scratch.
+ * host_out (or NULL): device-accessible PINNED HOST memory, int64[2]; the scan writes (total, *overflow_in) there
+ * itself, so the frame's readback needs no copy kernel -- the host waits for an event recorded after this call.
+ * overflow_in (or NULL): the device counter of qf_raster_intersect.                                */
 int64_t qf_frame_offsets_temp_bytes(int64_t n_rays);
 int qf_frame_offsets(const int32_t *hit_count, int64_t n_rays, int32_t max_hits, int32_t width, int32_t height,
                      int64_t *ray_offset /* [n_rays+1] */, int64_t *tile_base /* or NULL */, void *temp,
-                     int64_t temp_bytes, void *stream);
+                     int64_t temp_bytes, const int32_t *overflow_in, int64_t *host_out, void *stream);
 
 /* Packs the per-ray hit lists into the sample arrays sampling_raytrace_numpy returns
  * (mesh_utils.py:359-387), already sorted by (ray, depth): location = o + t d in float64,
@@ -430,13 +433,18 @@ int qf_frame_offsets(const int32_t *hit_count, int64_t n_rays, int32_t max_hits,
  * positions are skipped; index_ray, depth and index_tri are always written.
  * keep_mask / raw_count (both or neither; from qf_bvh_repair_overflow): the stored list of ray r has raw_count[r]
  * entries of which the ones whose (t, tri)-sorted position has its bit set in keep_mask[r] are packed --
- * hit_count[r] (and ray_offset) already count only those.                                          */
+ * hit_count[r] (and ray_offset) already count only those.
+ * close_flag (device int32, or NULL) with min_separation > 0 and no keep_mask: the OPTIMISTIC route of the re-origin
+ * rule.  The lists are packed as if the rule dropped nothing and, once a list is sorted, that is verified exactly; if
+ * some ray does have a hit within min_separation of its predecessor, *close_flag is set to 1 (the caller zeroes it)
+ * and the caller must run qf_bvh_repair_overflow with keep_mask, the offsets and this call again.  A scene without
+ * near-coincident faces never raises it and pays nothing for the rule.                              */
 int qf_pack_samples(const float *rays_o, const float *rays_d, int64_t n_rays, int32_t max_hits,
                     const int32_t *hit_tri, const float *hit_t, const int32_t *hit_count,
                     const int64_t *ray_offset, float *xyz, float *dirs, int64_t *index_ray,
                     float *depth, int64_t *index_tri, float *origins, const int32_t *inverse,
                     float *xyz_c, float *dirs_c, const uint64_t *keep_mask, const int32_t *raw_count,
-                    void *stream);
+                    float min_separation, int32_t *close_flag, void *stream);
 
 /* Spatially coherent PROCESSING order for qf_field_forward when the rays are a row-major width x height image:
  * (8x8 pixel tile, hit rank, pixel in tile).  Two steps around one exclusive scan the caller does:

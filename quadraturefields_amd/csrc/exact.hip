@@ -160,6 +160,7 @@ struct TravArgs {
     int32_t *hit_count;
     uint64_t *keep_mask;         // repair launch only (see bvh8_repair_kernel)
     int32_t *raw_count;
+    int tcol_offset;             // repair launch: float offset of the [K][256] distance columns in the LDS
 };
 
 // LDS of a workgroup: [kOctRays][K] keys | [kOctRays][K] sorted (only when min_sep > 0) | [kOctRays][stack_cap] stack
@@ -404,8 +405,33 @@ __global__ __launch_bounds__(kTravThreads) void bvh8_repair_kernel(TravArgs a)
             int need = 0;
             if (c > K) need = 2;
             else if (a.keep_mask) {
-                if (c >= 2) need = 1;
-                else { a.keep_mask[ray] = (uint64_t)c; a.raw_count[ray] = c; }       // 0 or 1 hit: mask 0b0 / 0b1
+                // The rule can only drop a hit if two of the ray's hits lie within min_sep of each other.  One lane
+                // tests that on the distances alone -- no sort: with no such pair every hit is kept whatever the order
+                // -- and only the (rare) rays with a close pair go to an octet for the sorted chain.  The margin covers
+                // the rounding of the chain's fp32 addition, so "no close pair" can never hide a drop.
+                bool close_pair = false;
+                if (c >= 2) {
+                    const float *row = a.hit_t + ray * K;
+                    float *col = reinterpret_cast<float *>(trav_lds) + a.tcol_offset + tid;      // [K][kTravThreads]
+                    for (int i0 = 0; i0 < c; i0 += 8) {
+                        float v[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) v[u] = (i0 + u < c) ? row[i0 + u] : 0.0f;
+#pragma unroll
+                        for (int u = 0; u < 8; ++u)
+                            if (i0 + u < c) col[(i0 + u) * kTravThreads] = v[u];
+                    }
+                    const float ms = a.min_sep * 1.0001f;
+                    for (int i = 1; i < c; ++i) {
+                        const float ti = col[i * kTravThreads];
+                        for (int k = 0; k < i; ++k) {
+                            const float tk = col[k * kTravThreads];
+                            close_pair |= !(fabsf(ti - tk) > ms + 4e-7f * fmaxf(ti, tk));
+                        }
+                    }
+                }
+                if (close_pair) need = 1;
+                else { a.keep_mask[ray] = c >= 64 ? ~0ull : ((1ull << c) - 1ull); a.raw_count[ray] = c; }
             }
             if (need) s_list[atomicAdd(&s_n, 1)] = tid | (need << 16);
         }
@@ -703,7 +729,8 @@ __global__ __launch_bounds__(kPackRays) void pack_samples_kernel(
     const int64_t *__restrict__ ray_offset, float *__restrict__ xyz, float *__restrict__ dirs,
     int64_t *__restrict__ index_ray, float *__restrict__ depth, int64_t *__restrict__ index_tri,
     float *__restrict__ origins, const int32_t *__restrict__ inverse, float *__restrict__ xyz_c,
-    float *__restrict__ dirs_c, const uint64_t *__restrict__ keep_mask, const int32_t *__restrict__ raw_count)
+    float *__restrict__ dirs_c, const uint64_t *__restrict__ keep_mask, const int32_t *__restrict__ raw_count,
+    float min_sep, int32_t *__restrict__ close_flag)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int K = max_hits, Kp = max_hits | 1;            // odd row stride: conflict-free column access
@@ -744,6 +771,13 @@ __global__ __launch_bounds__(kPackRays) void pack_samples_kernel(
             for (int i = 0; i < cnt; ++i)
                 if ((mask >> i) & 1ull) { row_t[kept] = row_t[i]; row_i[kept] = row_i[i]; ++kept; }
             cnt = kept;
+        } else if (close_flag && min_sep > 0.0f) {
+            // optimistic route: the lists were packed as if the rule dropped nothing; here, with the list sorted, that
+            // is checked exactly (the chain drops a hit iff some hit is not more than min_sep behind its predecessor).
+            // A violation raises the frame's flag: the host then decides the rule per ray (keep_mask) and packs again.
+            bool drop = false;
+            for (int i = 1; i < cnt; ++i) drop |= !(row_t[i] > row_t[i - 1] + min_sep);
+            if (drop) *close_flag = 1;
         }
         if (cnt > 1) {
             const double o64[3] = {(double)rays_o[ray * 3], (double)rays_o[ray * 3 + 1], (double)rays_o[ray * 3 + 2]};
@@ -1195,7 +1229,9 @@ static int bvh_launch(const qf_bvh *bvh, const float *rays_o, const float *rays_
     }
     const bool sep = bvh->min_sep > 0.0f;
     const int stack_cap = (bvh->max_stack8 < 2 ? 2 : bvh->max_stack8) | 1;       // odd row stride
-    const size_t lds = (size_t)kOctRays * ((size_t)max_hits * 8 * (sep ? 2 : 1) + (size_t)stack_cap * 4);
+    size_t lds = (size_t)kOctRays * ((size_t)max_hits * 8 * (sep ? 2 : 1) + (size_t)stack_cap * 4);
+    const size_t tcol_offset = (lds + 3) / 4;
+    if (only_overflowed && sep && keep_mask) lds = tcol_offset * 4 + (size_t)kTravThreads * max_hits * 4;   // distance columns
     if (lds > 160 * 1024 - 2048) return QF_ERR_UNSUPPORTED;
     TravArgs a;
     a.nodes = reinterpret_cast<const float4 *>(bvh->d_nodes8);
@@ -1207,6 +1243,7 @@ static int bvh_launch(const qf_bvh *bvh, const float *rays_o, const float *rays_
     a.hit_tri = hit_tri; a.hit_t = hit_t; a.hit_count = hit_count;
     a.keep_mask = (only_overflowed && sep) ? keep_mask : nullptr;
     a.raw_count = a.keep_mask ? raw_count : nullptr;
+    a.tcol_offset = (int)tcol_offset;
     if (only_overflowed) n_blocks = qf_div_up(n_rays, kTravThreads);        // 256 consecutive rays per workgroup
     const int64_t per_xcd = qf_div_up(n_blocks, 8);
     if (per_xcd * 8 > 0x7fffffff) return QF_ERR_UNSUPPORTED;
@@ -1265,7 +1302,8 @@ extern "C" int qf_pack_samples(const float *rays_o, const float *rays_d, int64_t
                                const int32_t *hit_tri, const float *hit_t, const int32_t *hit_count,
                                const int64_t *ray_offset, float *xyz, float *dirs, int64_t *index_ray, float *depth,
                                int64_t *index_tri, float *origins, const int32_t *inverse, float *xyz_c, float *dirs_c,
-                               const uint64_t *keep_mask, const int32_t *raw_count, void *stream)
+                               const uint64_t *keep_mask, const int32_t *raw_count, float min_separation,
+                               int32_t *close_flag, void *stream)
 {
     if ((keep_mask == nullptr) != (raw_count == nullptr)) return QF_ERR_INVALID_ARGUMENT;
     if (n_rays < 0 || max_hits < 1 || max_hits > kMaxHits) return QF_ERR_INVALID_ARGUMENT;
@@ -1281,7 +1319,7 @@ extern "C" int qf_pack_samples(const float *rays_o, const float *rays_d, int64_t
     if (blocks > 0x7fffffff) return QF_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(pack_samples_kernel, dim3((unsigned)blocks), dim3(kPackRays), lds, qf_stream(stream), rays_o, rays_d,
                        n_rays, (int)max_hits, hit_tri, hit_t, hit_count, ray_offset, xyz, dirs, index_ray, depth, index_tri,
-                       origins, inverse, xyz_c, dirs_c, keep_mask, raw_count);
+                       origins, inverse, xyz_c, dirs_c, keep_mask, raw_count, min_separation, close_flag);
     QF_LAUNCH_CHECK();
     return QF_OK;
 }

@@ -125,24 +125,36 @@ __global__ __launch_bounds__(kFoThreads) void frame_partials_kernel(const int32_
     if (lane == 0) tile_total[tile] = cnt;
 }
 
+// one workgroup; every thread owns a CONTIGUOUS run of each array, so an array is scanned with one block scan
 __global__ __launch_bounds__(kFoThreads) void frame_scan_kernel(int64_t *partial, int n_blocks, int64_t *tile_total, int n_tiles,
-                                                                int64_t *grand_total)
+                                                                int64_t *grand_total, const int32_t *overflow_in,
+                                                                int64_t *host_out)
 {
     __shared__ int64_t s_wave[kFoThreads / 64];
     for (int pass = 0; pass < 2; ++pass) {
         int64_t *a = pass == 0 ? partial : tile_total;
         const int m = pass == 0 ? n_blocks : n_tiles;
         if (!a) continue;
-        int64_t carry = 0;
-        for (int i0 = 0; i0 < m; i0 += kFoThreads) {
-            const int i = i0 + threadIdx.x;
-            const int64_t v = i < m ? a[i] : 0;
-            int64_t total;
-            const int64_t inc = block_inclusive_scan(v, s_wave, &total);
-            if (i < m) a[i] = carry + inc - v;
-            carry += total;
+        const int per = (m + kFoThreads - 1) / kFoThreads;
+        const int i0 = threadIdx.x * per, i1 = i0 + per < m ? i0 + per : m;
+        int64_t sum = 0;
+#pragma unroll 8
+        for (int i = i0; i < i1; ++i) sum += a[i];
+        int64_t total;
+        int64_t run = block_inclusive_scan(sum, s_wave, &total) - sum;
+#pragma unroll 8
+        for (int i = i0; i < i1; ++i) {
+            const int64_t v = a[i];
+            a[i] = run;
+            run += v;
         }
-        if (pass == 0 && threadIdx.x == 0) *grand_total = carry;
+        if (pass == 0 && threadIdx.x == 0) {
+            *grand_total = total;
+            if (host_out) {                 // pinned host memory: the frame's 16-byte readback without a copy kernel
+                host_out[0] = total;
+                host_out[1] = overflow_in ? (int64_t)*overflow_in : 0;
+            }
+        }
     }
 }
 
@@ -173,7 +185,8 @@ extern "C" int64_t qf_frame_offsets_temp_bytes(int64_t n_rays)
 }
 
 extern "C" int qf_frame_offsets(const int32_t *hit_count, int64_t n_rays, int32_t max_hits, int32_t width, int32_t height,
-                                int64_t *ray_offset, int64_t *tile_base, void *temp, int64_t temp_bytes, void *stream)
+                                int64_t *ray_offset, int64_t *tile_base, void *temp, int64_t temp_bytes,
+                                const int32_t *overflow_in, int64_t *host_out, void *stream)
 {
     if (n_rays < 0 || n_rays >= 0x7fffffff || max_hits < 1 || width < 0 || height < 0) return QF_ERR_INVALID_ARGUMENT;
     if (!ray_offset || !temp || (n_rays > 0 && !hit_count)) return QF_ERR_INVALID_ARGUMENT;
@@ -192,7 +205,7 @@ extern "C" int qf_frame_offsets(const int32_t *hit_count, int64_t n_rays, int32_
         QF_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(frame_scan_kernel, dim3(1), dim3(kFoThreads), 0, st, partial, n_blocks, tile_base, n_tiles,
-                       ray_offset + n_rays);
+                       ray_offset + n_rays, overflow_in, host_out);
     QF_LAUNCH_CHECK();
     if (n_blocks > 0) {
         hipLaunchKernelGGL(frame_ray_offsets_kernel, dim3((unsigned)n_blocks), dim3(kFoThreads), 0, st, hit_count, n_rays,

@@ -89,6 +89,9 @@ class RayIntersector:
         self.repaired_frames = 0         # frames on which some pixels overflowed K and were repaired through the BVH
         self._raster_streak = 0          # consecutive camera-coherent attempts that overflowed (see want_raster)
         self._raster_trying = False
+        self._rule_upfront = 0           # frames left that decide the re-origin rule up front (see _hits_raster_frame)
+        self._rule_pending = None        # the frame whose optimistic pack has not been checked yet (rule_violated)
+        self.rule_redone_frames = 0      # frames packed twice because the optimistic check failed
         self.raster_wide = 0             # > 0: the camera-coherent pass keeps this many candidates per ray (dense scenes)
         self._wide_scratch = {}
         self._scratch = {}               # per-ray-count frame scratch, see _frame_scratch
@@ -234,8 +237,9 @@ class RayIntersector:
         return hit_tri.reshape(-1).cpu().numpy()
 
     def _frame_scratch(self, n):
-        """Per-ray-count scratch reused across frames: [n+2] int64 = sample offsets | total | raster overflow flag,
-        the scan's temp storage, a pinned host mirror of (total, overflow) and the event that guards it."""
+        """Per-ray-count scratch reused across frames: [n+2] int64 = sample offsets | total | raster overflow counter,
+        the scan's temp storage, a pinned (device-writable) host block [total, overflow, close-pair flag, -] that the
+        kernels write directly, and the two events that guard it (after the offsets; after the pack)."""
         key = (n, torch.cuda.current_stream().cuda_stream)      # frames in flight on different streams do not share it
         s = self._scratch.get(key)
         if s is None:
@@ -244,8 +248,8 @@ class RayIntersector:
             if nbytes < 0:
                 raise _C.QFError("qf_frame_offsets_temp_bytes failed")
             temp = torch.empty((nbytes,), dtype=torch.uint8, device=self.device)
-            host = torch.zeros((2,), dtype=torch.int64).pin_memory()
-            s = self._scratch[key] = (buf, temp, host, torch.cuda.Event())
+            host = torch.zeros((4,), dtype=torch.int64).pin_memory()
+            s = self._scratch[key] = (buf, temp, host, (torch.cuda.Event(), torch.cuda.Event()))
             if len(self._scratch) > 8:
                 self._scratch.pop(next(iter(self._scratch)))
         return s
@@ -277,17 +281,32 @@ class RayIntersector:
         # round trip (afterwards every count is <= K).  With the reference's re-origin rule on, the same launch decides
         # it for every other ray as a keep-mask over its sorted list (the lists are not rewritten); the mask rides on
         # the count tensor to qf_pack_samples.
+        # The rule for the OTHER rays (complete lists) is applied optimistically: pack_hits packs as if it dropped
+        # nothing and verifies that exactly on the sorted lists (qf_pack_samples close_flag).  Only after a frame that
+        # did have a close pair (duplicated / near-coincident faces) the following RULE_UPFRONT_FRAMES frames decide it
+        # up front, per ray, in the repair launch (keep mask; ~0.05 ms per 800x800 frame).
+        upfront = self.min_separation > 0 and self._rule_upfront > 0
+        if upfront:
+            self._rule_upfront -= 1
+        self._repair(o, d, k, int(camera.width), hit_tri, hit_t, hit_count, with_mask=upfront)
+        return hit_tri, hit_t, hit_count, overflow
+
+    #: frames that decide the re-origin rule up front after one frame's optimistic pack found a close pair
+    RULE_UPFRONT_FRAMES = 64
+
+    def _repair(self, o, d, k, width, hit_tri, hit_t, hit_count, with_mask):
+        n = o.shape[0]
         mask = raw = None
-        if self.min_separation > 0:
+        if with_mask:
             mask = torch.empty((n,), dtype=torch.int64, device=self.device)
             raw = torch.empty((n,), dtype=torch.int32, device=self.device)
-        _C.check(_C.lib().qf_bvh_repair_overflow(self._handle, _C.ptr(o), _C.ptr(d), n, k, int(camera.width),
+        _C.check(_C.lib().qf_bvh_repair_overflow(self._handle, _C.ptr(o), _C.ptr(d), n, k, int(width),
                                                  _C.ptr(hit_tri), _C.ptr(hit_t), _C.ptr(hit_count), _C.ptr(mask), _C.ptr(raw),
                                                  _C.stream()), "qf_bvh_repair_overflow")
         hit_count._qf_keep = (mask, raw) if mask is not None else None
-        return hit_tri, hit_t, hit_count, overflow
 
-    def pack_hits(self, o, d, k, hit_tri, hit_t, hit_count, overflow, width, lean=False, layout=True):
+    def pack_hits(self, o, d, k, hit_tri, hit_t, hit_count, overflow, width, lean=False, layout=True,
+                  defer_rule_check=False):
         """Per-ray hit lists -> ([xyzs, dirs, index_ray, ts, index_tri, origins] or None, coherent order or None).
 
         The output size is data dependent.  Instead of stalling on it, the offsets are scanned on the device, the
@@ -297,7 +316,8 @@ class RayIntersector:
         ``overflow`` (from ``_hits_raster_frame``) counts candidates beyond K; those rays were already repaired on the
         device, the count only steers the intersector policy.  ``pack_hits_begin`` / ``pack_hits_end`` are the two halves, for callers
         that keep several frames in flight on different streams."""
-        return self.pack_hits_end(self.pack_hits_begin(o, d, k, hit_tri, hit_t, hit_count, overflow, width, lean, layout))
+        return self.pack_hits_end(self.pack_hits_begin(o, d, k, hit_tri, hit_t, hit_count, overflow, width, lean, layout),
+                                  defer_rule_check)
 
     @_on_device
     def pack_hits_begin(self, o, d, k, hit_tri, hit_t, hit_count, overflow, width, lean=False, layout=True):
@@ -307,9 +327,7 @@ class RayIntersector:
         do not evaluate a field on the samples, e.g. the baked-texture render)."""
         n = o.shape[0]
         dev = self.device
-        buf, temp, host, ev = self._frame_scratch(n)
-        if overflow is None:
-            buf[n + 1].zero_()
+        buf, temp, host, (ev, ev_flag) = self._frame_scratch(n)
         cap = n * k
         image = bool(layout) and width > 0 and n % width == 0
         # sample offsets (+ total) and, for an image, the tile bases of the coherent order: three small launches
@@ -318,10 +336,9 @@ class RayIntersector:
             height = n // width
             tile_base = torch.empty((((width + 7) // 8) * ((height + 7) // 8),), dtype=torch.int64, device=dev)
         _C.check(_C.lib().qf_frame_offsets(_C.ptr(hit_count), n, k, int(width) if image else 0, n // width if image else 0,
-                                           _C.ptr(buf), _C.ptr(tile_base), _C.ptr(temp), temp.numel(), _C.stream()),
-                 "qf_frame_offsets")
-        host.copy_(buf[n:], non_blocking=True)
-        ev.record()
+                                           _C.ptr(buf), _C.ptr(tile_base), _C.ptr(temp), temp.numel(), _C.ptr(overflow),
+                                           ctypes.c_void_p(host.data_ptr()), _C.stream()), "qf_frame_offsets")
+        ev.record()                           # (total, overflow) are in pinned memory once this event has passed
         lean = bool(lean) and image
         want_layout = layout
         xyz = dirs = org = None
@@ -338,21 +355,43 @@ class RayIntersector:
             xyz_c = torch.empty((cap, 3), dtype=torch.float32, device=dev)
             dirs_c = torch.empty((cap, 3), dtype=torch.float32, device=dev)
             layout = (inverse, xyz_c, dirs_c)
-        keep = getattr(hit_count, "_qf_keep", None) or (None, None)      # from _hits_raster_frame (re-origin rule)
+        keep = getattr(hit_count, "_qf_keep", None) or (None, None)      # from _repair (re-origin rule decided up front)
+        optimistic = keep[0] is None and self.min_separation > 0
+        flag = None
+        if optimistic:                        # the pack kernel verifies "nothing dropped" and raises host[2] otherwise
+            host[2] = 0
+            flag = ctypes.c_void_p(host.data_ptr() + 16)
         _C.check(_C.lib().qf_pack_samples(_C.ptr(o), _C.ptr(d), n, k, _C.ptr(hit_tri), _C.ptr(hit_t),
                                           _C.ptr(hit_count), _C.ptr(buf), _C.ptr(xyz), _C.ptr(dirs),
                                           _C.ptr(index_ray), _C.ptr(depth), _C.ptr(index_tri), _C.ptr(org),
                                           _C.ptr(inverse), _C.ptr(xyz_c), _C.ptr(dirs_c), _C.ptr(keep[0]),
-                                          _C.ptr(keep[1]), _C.stream()), "qf_pack_samples")
-        return (o, d, k, width, (lean, want_layout), host, ev, [xyz, dirs, index_ray, depth, index_tri, org], order, layout,
+                                          _C.ptr(keep[1]), float(self.min_separation) if optimistic else 0.0, flag,
+                                          _C.stream()), "qf_pack_samples")
+        if optimistic:
+            ev_flag.record()
+        return (o, d, k, width, (lean, want_layout), host, (ev, ev_flag if optimistic else None),
+                [xyz, dirs, index_ray, depth, index_tri, org], order, layout,
                 (hit_tri, hit_t, hit_count, keep))    # the lists stay referenced until the kernels reading them ran
 
     @_on_device
-    def pack_hits_end(self, pending):
-        """Wait for the 16-byte readback of ``pack_hits_begin`` and slice the results (same stream as ``begin``)."""
-        o, d, k, width, lean, host, ev, arrays, order, layout, _lists = pending
+    def pack_hits_end(self, pending, defer_rule_check=False):
+        """Wait for the 16-byte readback of ``pack_hits_begin`` and slice the results (same stream as ``begin``).
+        When the re-origin rule was applied optimistically the pack kernel's verdict arrives a little later (after the
+        pack): by default it is waited for here and, if some ray did have a close pair, the frame is packed again with
+        the rule decided per ray -- the caller always gets exact samples.  ``defer_rule_check=True`` returns at once
+        instead; the caller launches its field / compositing kernels and THEN asks ``rule_violated()`` (by which time
+        the verdict is long there); on True it must discard its results and sample again."""
+        o, d, k, width, lean, host, (ev, ev_flag), arrays, order, layout, _lists = pending
         ev.synchronize()
         total, ovf = int(host[0]), int(host[1])
+        self._rule_pending = None
+        if ev_flag is not None:
+            if defer_rule_check:
+                self._rule_pending = (ev_flag, host)
+            else:
+                ev_flag.synchronize()
+                if int(host[2]) != 0:
+                    return self._repack_exact(pending)
         if ovf:                                # already repaired on the device (qf_bvh_repair_overflow); policy only
             self.repaired_frames += 1
             if ovf > 0.05 * o.shape[0]:        # much of the image overflows (dense shells)
@@ -368,9 +407,38 @@ class RayIntersector:
             self.last_layout = tuple(t[:total] for t in layout)
         return [None if t is None else t[:total] for t in arrays], (order[:total] if order is not None else None)
 
+    def rule_violated(self) -> bool:
+        """After ``pack_hits_end(..., defer_rule_check=True)``: did the optimistic pack of that frame find a ray whose
+        hits the re-origin rule would thin out?  True -> the samples (and everything computed from them) are not the
+        reference's; sample again (the following frames decide the rule up front, so the retry is exact)."""
+        pend, self._rule_pending = self._rule_pending, None
+        if pend is None:
+            return False
+        ev_flag, host = pend
+        ev_flag.synchronize()
+        if int(host[2]) == 0:
+            return False
+        self._rule_violation()
+        return True
+
+    def _rule_violation(self):
+        """A frame's optimistic pack was refuted: decide the rule up front for the next frames -- 64 after the first
+        time, doubling (up to 4096) each time the optimistic retry at the end of such a window fails again."""
+        self._rule_window = min(4096, 2 * getattr(self, "_rule_window", self.RULE_UPFRONT_FRAMES // 2))
+        self._rule_upfront = self._rule_window
+        self.rule_redone_frames += 1
+
+    def _repack_exact(self, pending):
+        """The optimistic pack of ``pending`` failed its check: decide the rule per ray (keep masks over the same
+        lists) and pack again."""
+        o, d, k, width, (lean, want_layout), _host, _evs, _arrays, _order, _layout, (hit_tri, hit_t, hit_count, _keep) = pending
+        self._rule_violation()
+        self._repair(o, d, k, width, hit_tri, hit_t, hit_count, with_mask=True)
+        return self.pack_hits_end(self.pack_hits_begin(o, d, k, hit_tri, hit_t, hit_count, None, width, lean, want_layout))
+
     @_on_device
     def sample_device(self, origins, vectors, max_hits: Optional[int] = None, image_width: int = 0, camera=None,
-                      lean: bool = False, layout: bool = True):
+                      lean: bool = False, layout: bool = True, defer_rule_check: bool = False):
         """Packed, sorted samples on the device: [xyzs, dirs, index_ray, ts, index_tri, origins] -- the six
         tensors the reference's DataLoader hands to the renderers (nerf_synthetic.py:256-257) -- or None
         when no ray hits anything."""
@@ -388,7 +456,7 @@ class RayIntersector:
             hit_tri, hit_t, hit_count = self._hits_bvh(o, d, k, image_width)
             overflow = None
         data, self.last_order = self.pack_hits(o, d, k, hit_tri, hit_t, hit_count, overflow, int(image_width), lean,
-                                               layout)
+                                               layout, defer_rule_check)
         return data
 
     @_on_device

@@ -42,14 +42,16 @@ class FrameRenderer:
             image_width = camera.width
         # without deformation only the streamed copies are read: skip the ray-major position arrays
         lean = self.field_net is None or scaling == 0
-        data = self.mesh_intersect.rayintersector.sample_device(origins, viewdirs, self.mesh_intersect.num_intersections,
-                                                                image_width, camera, lean=lean)
+        ri = self.mesh_intersect.rayintersector
+        # lean frames let the intersector verify its optimistic re-origin rule AFTER the field / compositing launches
+        data = ri.sample_device(origins, viewdirs, self.mesh_intersect.num_intersections, image_width, camera, lean=lean,
+                                defer_rule_check=lean)
         if data is None:
+            ri.rule_violated()
             dev = origins.device
             fill = 0.0 if self.bg_color == "black" else 1.0
             return (torch.full((n_rays, 3), fill, device=dev), torch.zeros((n_rays, 1), device=dev),
                     torch.zeros((n_rays, 1), device=dev), 0)
-        ri = self.mesh_intersect.rayintersector
         if (self.field_net is None or scaling == 0) and ri.last_layout is not None:
             # No deformation: the samples are already sorted by (ray, depth), the re-sort of sampling_indexing is the
             # identity, and the field can stream the copies laid out in its processing order (same bits).
@@ -58,7 +60,11 @@ class FrameRenderer:
             rgb, alpha, _, depth, _ = utils.derive_properties(
                 rgbs, sigmas.reshape(-1), data[3], self.render_step_size, None, data[2], render_bkgd=render_bkgd,
                 bg_color=self.bg_color, N=n_rays, sample_index=inverse)
+            if ri.rule_violated():      # rare (near-coincident faces): these samples are not the reference's; again, exactly
+                return self.render(origins, viewdirs, image_width, scaling, render_bkgd, camera)
             return rgb, alpha, depth, data[2].shape[0]
+        if ri.rule_violated():
+            return self.render(origins, viewdirs, image_width, scaling, render_bkgd, camera)
         rays = Rays(origins=origins, viewdirs=viewdirs)
         rgb, alpha, depth, n_samples, *_ = utils.render_image_finetune_with_occgrid(
             self.radiance_field, self.field_net, None, rays, data, render_step_size=self.render_step_size,

@@ -269,3 +269,39 @@ def test_config5_baked_render_at_full_texture_size(device):
     rgb_o = om.render_image_bake_texture(om.to_loader_tensors(sample), idx.shape[0], mesh.vertices, mesh.faces,
                                          torch.from_numpy(uv_np), t, lobes, "sigmoid", 7.5)[0]
     assert float((rgb.cpu()[idx] - rgb_o).abs().max()) <= 2e-4
+
+
+def test_frame_on_duplicated_shells_takes_the_exact_rule_route(device):
+    """A mesh whose every face exists twice (the reference concatenates two iso-surfaces, marching_cubes.py:81): the
+    frame renderer's optimistic re-origin pack is refuted by the pack kernel's check, the frame is sampled again with
+    the rule decided per ray, and the pixels are the oracle's (which skips the second copy of every crossing); the
+    following frames decide the rule up front and are not redone."""
+    from quadraturefields_amd import synthetic
+    from quadraturefields_amd.mesh_io import TriMesh
+    from quadraturefields_amd.mesh_utils import MeshIntersection, make_camera
+    from quadraturefields_amd.radiance_fields.ngp import NGPRadianceField
+    from quadraturefields_amd.render import FrameRenderer, psnr
+    base = synthetic.shell_mesh(n_shells=3, subdivisions=3)
+    nv = base.vertices.shape[0]
+    mesh = TriMesh(np.concatenate([base.vertices, base.vertices]), np.concatenate([base.faces, base.faces + nv]))
+    mi = MeshIntersection(mesh, simplify_mesh=False, scale=1.0, num_intersections=25)
+    field = NGPRadianceField(aabb=[-1.5] * 3 + [1.5] * 3, log2_hashmap_size=14)
+    field.load_state_dict(synthetic.seeded_ngp_state(14, field.mlp_base.grid.n_rows), strict=False)
+    field = field.to(device)
+    fr = FrameRenderer(mi, field)
+    w = h = 80
+    focal = synthetic.lego_focal(800) * w / 800.0
+    ri = mi.rayintersector
+    wts = helpers.oracle_ngp_weights(field)
+    bf = om.BVHIntersector(mesh.vertices, mesh.faces)
+    for i, c2w in enumerate(synthetic.orbit_cameras(3, seed=12)):
+        o, d = synthetic.camera_rays(c2w, focal, w, h)
+        rgb, alpha, depth, n = fr.render(o.to(device), d.to(device), camera=make_camera(c2w, focal, w, h))
+        data = om.to_loader_tensors(om.sampling_raytrace_numpy(bf, d.numpy(), o.numpy(), 25))
+        rgb_o = om.render_image_finetune(wts, None, data, w * h)[0]
+        assert n == data[0].shape[0]
+        assert float((rgb.cpu() - rgb_o).abs().max()) <= 2e-4 and psnr(rgb.cpu(), rgb_o) >= 70.0
+        assert ri.rule_redone_frames == 1                      # frame 0 was redone, frames 1-2 went the exact way at once
+    every = om.to_loader_tensors(om.sampling_raytrace_numpy(
+        om.BVHIntersector(mesh.vertices, mesh.faces, min_separation=0.0), d.numpy(), o.numpy(), 25))
+    assert every[0].shape[0] > 1.5 * data[0].shape[0]          # the rule did remove the second copies
