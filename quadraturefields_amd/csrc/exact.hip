@@ -154,6 +154,7 @@ struct TravArgs {
     const float *rays_o, *rays_d;
     int64_t n_rays;
     int root_is_valid, max_hits, image_width, image_height, tiles_x, n_blocks, blocks_per_xcd, stack_cap;
+    int list_cap;                // entries of the LDS K-list: max_hits, or a few more when the re-origin rule is on
     float min_sep;
     int32_t *hit_tri;
     float *hit_t;
@@ -170,9 +171,9 @@ extern __shared__ uint64_t trav_lds[];
 // the list: bit i of the result = the i-th hit in (t, tri) order is kept.  Octet-uniform; *kept_out = number kept.
 __device__ __forceinline__ uint64_t oct_keep_mask(const TravArgs &a, int64_t ray, int c, int j, int q, int *kept_out)
 {
-    const int K = a.max_hits;
-    uint64_t *keys = trav_lds + (size_t)q * K;
-    uint64_t *sorted = trav_lds + (size_t)kOctRays * K + (size_t)q * K;
+    const int K = a.max_hits, Kc = a.list_cap;
+    uint64_t *keys = trav_lds + (size_t)q * Kc;
+    uint64_t *sorted = trav_lds + (size_t)kOctRays * Kc + (size_t)q * Kc;
     for (int e = j; e < c; e += 8) keys[e] = hit_key(a.hit_t[ray * K + e], a.hit_tri[ray * K + e]);
     oct_lds_sync();
     for (int e = j; e < c; e += 8) {
@@ -198,13 +199,17 @@ __device__ __forceinline__ uint64_t oct_keep_mask(const TravArgs &a, int64_t ray
 __device__ __forceinline__ void oct_traverse_ray(const TravArgs &ta, int64_t ray, int j, int q, int oct_base)
 {
     const int K = ta.max_hits;
+    // With the re-origin rule on the list holds a few more than K entries: the chain usually drops a hit or two (a
+    // grazing ray crosses a shell twice within min_sep), and with exactly K collected every drop would cost another
+    // whole traversal for the next page.
+    const int Kc = ta.list_cap;
     const float min_sep = ta.min_sep;
     const float4 *__restrict__ nodes = ta.nodes;
     const float4 *__restrict__ tris = ta.tris;
     const int stack_cap = ta.stack_cap;
-    uint64_t *keys = trav_lds + (size_t)q * K;
-    uint64_t *sorted = trav_lds + (size_t)kOctRays * K + (size_t)q * K;          // only when min_sep > 0
-    int *stack = reinterpret_cast<int *>(trav_lds + (size_t)kOctRays * K * (min_sep > 0.0f ? 2 : 1)) + (size_t)q * stack_cap;
+    uint64_t *keys = trav_lds + (size_t)q * Kc;
+    uint64_t *sorted = trav_lds + (size_t)kOctRays * Kc + (size_t)q * Kc;        // only when min_sep > 0
+    int *stack = reinterpret_cast<int *>(trav_lds + (size_t)kOctRays * Kc * (min_sep > 0.0f ? 2 : 1)) + (size_t)q * stack_cap;
     const float *rays_o = ta.rays_o, *rays_d = ta.rays_d;
     const int root_is_valid = ta.root_is_valid;
     float *hit_t = ta.hit_t;
@@ -219,7 +224,7 @@ __device__ __forceinline__ void oct_traverse_ray(const TravArgs &ta, int64_t ray
     int32_t *my_tri = hit_tri + ray * K;
 
     OctList list;
-    list.keys = keys; list.K = K; list.j = j;
+    list.keys = keys; list.K = Kc; list.j = j;
     int kept = 0;                    // hits written so far (min_sep chain)
     float last_t = 0.0f;             // t of the last kept hit
     uint64_t lo_key = 0;             // page lower bound: only keys > lo_key are collected
@@ -281,21 +286,21 @@ __device__ __forceinline__ void oct_traverse_ray(const TravArgs &ta, int64_t ray
                 const unsigned m8 = (unsigned)(__ballot(h) >> oct_base) & 0xffu;
                 if (m8) {
                     const int n = __popc(m8);
-                    if (list.count + n <= K) {
+                    if (list.count + n <= Kc) {
                         if (h) keys[list.count + __popc(m8 & ((1u << j) - 1u))] = key;
                         list.count += n;
                         oct_lds_sync();
-                        if (list.count == K) list.find_worst();
+                        if (list.count == Kc) list.find_worst();
                     } else {                                    // the list fills up or is full: one hit at a time
                         for (unsigned mm = m8; mm; mm &= mm - 1u) {
                             const int src = __ffs(mm) - 1;
                             const uint64_t k = ((uint64_t)(unsigned)oct_bcast((int)(unsigned)(key >> 32), oct_base, src) << 32) |
                                                (unsigned)oct_bcast((int)(unsigned)key, oct_base, src);
-                            if (list.count < K) {
+                            if (list.count < Kc) {
                                 if (j == 0) keys[list.count] = k;
                                 ++list.count;
                                 oct_lds_sync();
-                                if (list.count == K) list.find_worst();
+                                if (list.count == Kc) list.find_worst();
                             } else if (k < list.worst) {
                                 if (j == 0) keys[list.worst_slot] = k;
                                 oct_lds_sync();
@@ -303,7 +308,7 @@ __device__ __forceinline__ void oct_traverse_ray(const TravArgs &ta, int64_t ray
                             }
                         }
                     }
-                    if (list.count == K) t_limit = key_t(list.worst);
+                    if (list.count == Kc) t_limit = key_t(list.worst);
                 }
             }
             cur = kDone;
@@ -340,8 +345,8 @@ __device__ __forceinline__ void oct_traverse_ray(const TravArgs &ta, int64_t ray
                 last_t = t;
             }
         }
-        if (count < K || kept >= K) break;          // every hit of the ray has been seen, or K are kept
-        lo_key = sorted[K - 1];
+        if (count < Kc || kept >= K) break;         // every hit of the ray has been seen, or K are kept
+        lo_key = sorted[Kc - 1];
         t_lo = key_t(lo_key) * 0.999999f;
         t_accept = last_t + min_sep;                // anything closer is dropped by the chain whatever follows
         oct_lds_sync();
@@ -1229,7 +1234,10 @@ static int bvh_launch(const qf_bvh *bvh, const float *rays_o, const float *rays_
     }
     const bool sep = bvh->min_sep > 0.0f;
     const int stack_cap = (bvh->max_stack8 < 2 ? 2 : bvh->max_stack8) | 1;       // odd row stride
-    size_t lds = (size_t)kOctRays * ((size_t)max_hits * 8 * (sep ? 2 : 1) + (size_t)stack_cap * 4);
+    // headroom only in the repair launch (dense scenes: every traversed ray fills its list); the all-rays traversal
+    // keeps the smaller LDS footprint (measured: +6 % on a frame, +8 % on a training batch with the headroom)
+    const int list_cap = (sep && only_overflowed) ? (max_hits + 8 < kMaxHits ? max_hits + 8 : kMaxHits) : max_hits;
+    size_t lds = (size_t)kOctRays * ((size_t)list_cap * 8 * (sep ? 2 : 1) + (size_t)stack_cap * 4);
     const size_t tcol_offset = (lds + 3) / 4;
     if (only_overflowed && sep && keep_mask) lds = tcol_offset * 4 + (size_t)kTravThreads * max_hits * 4;   // distance columns
     if (lds > 160 * 1024 - 2048) return QF_ERR_UNSUPPORTED;
@@ -1239,7 +1247,7 @@ static int bvh_launch(const qf_bvh *bvh, const float *rays_o, const float *rays_
     a.rays_o = rays_o; a.rays_d = rays_d; a.n_rays = n_rays;
     a.root_is_valid = bvh->n_tri > 0 ? 1 : 0;
     a.max_hits = (int)max_hits; a.image_width = (int)image_width; a.image_height = height; a.tiles_x = tiles_x;
-    a.stack_cap = stack_cap; a.min_sep = sep ? bvh->min_sep : 0.0f;
+    a.stack_cap = stack_cap; a.list_cap = list_cap; a.min_sep = sep ? bvh->min_sep : 0.0f;
     a.hit_tri = hit_tri; a.hit_t = hit_t; a.hit_count = hit_count;
     a.keep_mask = (only_overflowed && sep) ? keep_mask : nullptr;
     a.raw_count = a.keep_mask ? raw_count : nullptr;
