@@ -23,6 +23,13 @@ def test_header_and_binding_agree(lib):
         assert getattr(lib, name) is not None
 
 
+def test_integration_index_lists_every_entry_point():
+    """INTEGRATION.md's entry-point index names every function the header declares."""
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    missing = [f for f in _header_functions() if f"`{f}`" not in text]
+    assert not missing, missing
+
+
 def test_library_exports_every_symbol(lib):
     from quadraturefields_amd import _C
     raw = ctypes.CDLL(_C.LIB_PATH)
