@@ -605,3 +605,72 @@ def test_device_refit_equals_a_fresh_intersector(device):
     b = fresh.sample_device(oc.to(device), dc.to(device), 25, image_width=64)
     for x, y in zip(a, b):
         assert torch.equal(x, y)
+
+
+def test_frame_offsets_equal_a_cumsum(device):
+    """qf_frame_offsets (ray offsets + tile bases in three launches, total and overflow written to pinned memory)
+    against torch.cumsum, for image-shaped and plain batches, sizes that are not multiples of the block, empty input."""
+    import ctypes
+    from quadraturefields_amd import _C
+    g = torch.Generator().manual_seed(4)
+    for n, w in [(0, 0), (1, 0), (1023, 0), (1024, 0), (70001, 0), (48 * 40, 48), (50 * 37, 50), (800 * 800, 800)]:
+        k = 25
+        cnt = torch.randint(0, 40, (n,), generator=g, dtype=torch.int32).to(device)           # some above K: clamped
+        buf = torch.zeros((n + 2,), dtype=torch.int64, device=device)
+        temp = torch.empty((int(_C.lib().qf_frame_offsets_temp_bytes(n)),), dtype=torch.uint8, device=device)
+        host = torch.full((4,), -1, dtype=torch.int64).pin_memory()
+        ovf = torch.tensor([7], dtype=torch.int32, device=device)
+        tiles = None
+        if w:
+            h = n // w
+            tiles = torch.empty((((w + 7) // 8) * ((h + 7) // 8),), dtype=torch.int64, device=device)
+        _C.check(_C.lib().qf_frame_offsets(_C.ptr(cnt), n, k, w, n // w if w else 0, _C.ptr(buf), _C.ptr(tiles),
+                                           _C.ptr(temp), temp.numel(), _C.ptr(ovf), ctypes.c_void_p(host.data_ptr()),
+                                           _C.stream()), "qf_frame_offsets")
+        torch.cuda.synchronize()
+        c = cnt.clamp(max=k).long()
+        want = torch.cumsum(c, 0) - c
+        assert torch.equal(buf[:n], want) and int(buf[n]) == int(c.sum())
+        assert int(host[0]) == int(c.sum()) and int(host[1]) == 7
+        if w:
+            h = n // w
+            pad = torch.zeros(((h + 7) // 8 * 8, (w + 7) // 8 * 8), dtype=torch.int64, device=device)
+            pad[:h, :w] = c.view(h, w)
+            tot = pad.view((h + 7) // 8, 8, (w + 7) // 8, 8).sum(dim=(1, 3)).reshape(-1)
+            assert torch.equal(tiles, torch.cumsum(tot, 0) - tot)
+
+
+def test_filter_hits_applies_the_rule_in_place(device):
+    """qf_filter_hits on unordered complete lists = sort + the oracle's chain (the route of RayIntersector.hits with a
+    camera); no-op with the rule off."""
+    from quadraturefields_amd import _C
+    from quadraturefields_amd.mesh_utils import RayIntersector
+    mesh = _scene(2, 2)
+    ri = RayIntersector(mesh, max_hits=8, min_separation=0.05)
+    rng = np.random.default_rng(3)
+    n, k = 500, 8
+    cnt = rng.integers(0, k + 1, size=n).astype(np.int32)
+    t = np.full((n, k), np.inf, np.float32)
+    tri = np.full((n, k), -1, np.int32)
+    for r in range(n):
+        t[r, :cnt[r]] = rng.choice(np.arange(1, 60), size=cnt[r], replace=False).astype(np.float32) * 0.02   # gaps of 0.02: some < 0.05
+        tri[r, :cnt[r]] = rng.permutation(1000)[:cnt[r]]
+    dt, dtri, dc = (torch.from_numpy(x.copy()).to(device) for x in (t, tri, cnt))
+    _C.check(_C.lib().qf_filter_hits(ri._handle, n, k, _C.ptr(dtri), _C.ptr(dt), _C.ptr(dc), _C.stream()), "qf_filter_hits")
+    sep = np.float32(ri.min_separation)
+    for r in range(n):
+        order = np.lexsort((tri[r, :cnt[r]], t[r, :cnt[r]]))
+        kept_t, kept_i = [], []
+        for i in order:
+            if not kept_t or t[r, i] > np.float32(kept_t[-1] + sep):
+                kept_t.append(t[r, i])
+                kept_i.append(tri[r, i])
+        assert int(dc[r]) == len(kept_t)
+        assert np.array_equal(dt[r, :len(kept_t)].cpu().numpy(), np.array(kept_t, np.float32))
+        assert np.array_equal(dtri[r, :len(kept_i)].cpu().numpy(), np.array(kept_i, np.int32))
+        assert bool(torch.isinf(dt[r, len(kept_t):]).all()) and bool((dtri[r, len(kept_i):] == -1).all())
+    ri.set_min_separation(0.0)
+    d2 = torch.from_numpy(t.copy()).to(device)
+    _C.check(_C.lib().qf_filter_hits(ri._handle, n, k, _C.ptr(torch.from_numpy(tri.copy()).to(device)), _C.ptr(d2),
+                                     _C.ptr(torch.from_numpy(cnt.copy()).to(device)), _C.stream()), "qf_filter_hits")
+    assert torch.equal(d2.cpu(), torch.from_numpy(t))                    # rule off: untouched

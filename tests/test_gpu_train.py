@@ -634,3 +634,29 @@ def test_fused_backward_equals_library_route(device, n):
         for k in a:
             scale = float(b[k].abs().max())
             assert float((a[k] - b[k]).abs().max()) <= 2e-4 * max(scale, 1e-6), (type(module).__name__, k, n)
+
+
+@pytest.mark.gpu
+def test_lds_partitioned_table_scatter_equals_the_atomic_one(device):
+    """qf_grid_encode_backward_ws (LDS-partitioned scatter, from 2^15 points on) gives the table gradient of the
+    quad-atomic kernel up to fp32 summation order, for a hashed-table config and a tiny all-dense one, and falls back
+    to it without a workspace or for a small batch."""
+    from quadraturefields_amd import _C
+    from quadraturefields_amd import tinycudann as tcnn
+    from oracle import fields as ofields
+    lib = _C.lib()
+    g = torch.Generator().manual_seed(0)
+    for log2_t, n in ((19, 70000), (8, 40000), (14, 1000)):
+        desc = _C.make_grid_desc(16, log2_t, 16, ofields.ngp_per_level_scale(4096, 16, 16))
+        rows = int(desc.offset[16])
+        table = (torch.rand(rows * 2, generator=g) - 0.5).to(device)
+        x01 = torch.rand(n, 3, generator=g).to(device)
+        dfeat = torch.randn(n, 32, generator=g).to(device)
+        dfeat[::7] = 0.0
+        ga, gb = torch.zeros_like(table), torch.zeros_like(table)
+        _C.check(lib.qf_grid_encode_backward(desc, _C.ptr(table), _C.ptr(x01), _C.ptr(dfeat), n, _C.ptr(ga), None,
+                                             _C.stream()), "bwd")
+        _C.grid_encode_backward(desc, table, x01, dfeat, n, gb, None)
+        scale = float(ga.abs().max())
+        assert scale > 0 and float((ga - gb).abs().max()) <= 2e-5 * max(scale, 1.0)
+        assert int((ga != 0).sum()) == int((gb != 0).sum()) or n < (1 << 15)
