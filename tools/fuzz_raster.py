@@ -18,6 +18,10 @@ def main():
     ap.add_argument("--cases", type=int, default=200)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--dense", action="store_true")
+    ap.add_argument("--oracle", action="store_true",
+                    help="also compare the BVH traversal with the CPU oracle's host-BVH walk on 400 random rays of every case "
+                         "(the oracle is test infrastructure: this tool is a test, not product code)")
+    ap.add_argument("--min-sep", default="trimesh", help="'trimesh' (default), or a distance, or 0")
     args = ap.parse_args()
     from quadraturefields_amd import _C, synthetic
     from quadraturefields_amd.mesh_utils import RayIntersector
@@ -30,7 +34,12 @@ def main():
         shells, sub = int(rng.integers(1, 7)), int(rng.integers(0, 6))
         key = (shells, sub)
         if key not in meshes:
-            meshes[key] = RayIntersector(synthetic.shell_mesh(n_shells=shells, subdivisions=sub, seed=int(rng.integers(1 << 30))), max_hits=25)
+            m = synthetic.shell_mesh(n_shells=shells, subdivisions=sub, seed=int(rng.integers(1 << 30)))
+            sep = args.min_sep if args.min_sep == "trimesh" else float(args.min_sep)
+            meshes[key] = RayIntersector(m, max_hits=25, min_separation=sep)
+            if args.oracle:
+                from oracle import meshpath as om
+                meshes[key].oracle = om.BVHIntersector(m.vertices, m.faces, meshes[key].min_separation)
         ri = meshes[key]
         w, h = int(rng.integers(8, 400)), int(rng.integers(8, 400))
         c2w = synthetic.orbit_cameras(1, radius=float(np.exp(rng.uniform(np.log(0.05), np.log(8.0)))), seed=int(rng.integers(1 << 30)))[0].clone()
@@ -65,6 +74,13 @@ def main():
             skipped += 1
             continue
         tri_b, t_b, cnt_b = ri._hits_bvh(o, d, 25, w)
+        if args.oracle:
+            pick = torch.from_numpy(rng.choice(w * h, size=min(400, w * h), replace=False)).to(dev)
+            tri_o, t_o, cnt_o = ri.oracle.hits(o[pick].cpu().numpy(), d[pick].cpu().numpy(), 25)
+            if not (np.array_equal(cnt_b[pick].cpu().numpy(), cnt_o) and np.array_equal(tri_b[pick].cpu().numpy(), tri_o)
+                    and np.array_equal(t_b[pick].cpu().numpy(), t_o)):
+                print(f"ORACLE MISMATCH case {case}: mesh {key} image {w}x{h} focal {focal:.1f}")
+                sys.exit(1)
         if not (torch.equal(cnt_r, cnt_b) and torch.equal(tri_r, tri_b) and torch.equal(t_r, t_b)):
             bad = torch.nonzero(cnt_r != cnt_b)[:5].flatten().tolist()
             print(f"MISMATCH case {case}: mesh {key} image {w}x{h} focal {focal:.1f} rays {bad}")
