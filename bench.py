@@ -99,13 +99,17 @@ class Stages:
         hit_tri, hit_t, hit_count, overflow = hits
         pending = self._timed("pack", lambda: ri.pack_hits_begin(o, d, MAX_HITS, hit_tri, hit_t, hit_count, overflow,
                                                                  self.width, lean=self.coherent), record)
-        return pending, overflow is not None, record, o.shape[0], (o, d, cam)
+        packed = torch.cuda.Event()
+        packed.record()                   # a back-half stream waits for this before it reads the samples
+        return pending, overflow is not None, record, o.shape[0], (o, d, cam), packed
 
     def finish(self, begun):
         """Second half, on the stream ``begin`` ran on: wait for the sample count, field, compositing."""
         from quadraturefields_amd import utils
-        pending, rastered, record, n_rays, frame_in = begun
+        pending, rastered, record, n_rays, frame_in, packed = begun
         ri = self.mi.rayintersector
+        here = torch.cuda.current_stream()
+        here.wait_event(packed)           # no-op when begin() ran on this stream
         before = ri._raster_backoff
         # the intersector's optimistic re-origin check is read after the field / compositing launches (rule_violated)
         data, order = ri.pack_hits_end(pending, defer_rule_check=True)
@@ -113,6 +117,9 @@ class Stages:
             self.fallbacks = getattr(self, "fallbacks", 0) + 1
         xyz, dirs, index_ray, ts, index_tri, org = data
         layout = ri.last_layout if self.coherent else None
+        for t in (xyz, dirs, index_ray, ts) + (tuple(layout) if layout is not None else ()) + ((order,) if order is not None else ()):
+            if t is not None:
+                t.record_stream(here)     # allocated on the front-half stream, read here: keep the allocator from reusing them early
         if layout is not None:      # stream the coherent copies; compositing picks colour / density up through the inverse map
             inverse, xyz_c, dirs_c = layout
             rgbs, sigmas = self._timed("field", lambda: self.field(xyz_c, dirs_c), record)
@@ -365,6 +372,12 @@ def main():
     ap.add_argument("--up-sample", type=int, default=1, choices=[1, 2],
                     help="render at up_sample x 800 per side as the reference's eval does with up_sample 2 "
                          "(train_finetune.py:620-627); the headline configuration is 1")
+    ap.add_argument("--pipeline", type=int, default=1, choices=[1, 2],
+                    help="1 (default): one frame after the other on one stream.  2: front / back pipeline -- the next frame's "
+                         "intersection + pack on one stream beside this frame's field kernel + compositing on another.  "
+                         "Measured in round 2: 1.98 ms/frame against 1.87 -- the field kernel runs 1.80 ms instead of 1.32 "
+                         "beside the next frame's atomics and streaming writes (it is bound by the memory system, and so "
+                         "are they); round 1's whole-frame pipelining lost 4-5 %% for the same reason")
     ap.add_argument("--no-gather", action="store_true",
                     help="N > 1: do not all_gather the finished frames of the frame-parallel loop")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -404,13 +417,21 @@ def main():
     gather_bufs = [torch.empty((world * W * H, 5), dtype=torch.float32, device="cpu" if staged else device)
                    for _ in range(2)] if gather else None
 
+    # --pipeline 2 (measured, not the default -- see its help text): two frames in flight as a FRONT / BACK pipeline:
+    # frame i+1's intersection, offsets, ordering and pack (~0.45 ms) on one stream while frame i's field kernel and
+    # compositing (~1.4 ms) run on another; the field kernels of consecutive frames never overlap each other.
+    front, back = torch.cuda.Stream(device=device), torch.cuda.Stream(device=device)
+    ri0 = mi.rayintersector
+
     def run(first, last, record):
-        """Frames [first, last), one after the other; returns (last rgb, total points).  N > 1: every finished frame is
-        all-gathered to every rank; the collective of frame i (RCCL's own stream) overlaps the render of frame i+1 and
-        is waited for before frame i+1's gather starts (two receive buffers alternate)."""
-        pts, rgb, pending = 0, None, None
-        for i in range(first, last):
-            rgb, alpha, depth, n_pts = stages.frame(rays[i][0], rays[i][1], cameras[i], record)
+        """Frames [first, last); returns (last rgb, total points).  N > 1: every finished frame is all-gathered to
+        every rank; the collective of frame i (RCCL's own stream) overlaps the render of frame i+1 and is waited for
+        before frame i+1's gather starts (two receive buffers alternate)."""
+        pts, rgb, pending, prev = 0, None, None, None
+
+        def complete(begun, i):
+            nonlocal pts, rgb, pending
+            rgb, alpha, depth, n_pts = stages.finish(begun)
             if gather:
                 mine = torch.cat([rgb, alpha, depth], dim=1)
                 mine = mine.cpu() if staged else mine
@@ -418,6 +439,23 @@ def main():
                     pending[0].wait()
                 pending = (torch.distributed.all_gather_into_tensor(gather_bufs[i & 1], mine, async_op=True), mine)
             pts += n_pts
+
+        if args.pipeline == 1:
+            for i in range(first, last):
+                complete(stages.begin(rays[i][0], rays[i][1], cameras[i], record), i)
+        else:
+            for i in range(first, last):
+                ri0.scratch_slot = i & 1
+                with torch.cuda.stream(front):
+                    begun = stages.begin(rays[i][0], rays[i][1], cameras[i], record)
+                if prev is not None:
+                    with torch.cuda.stream(back):
+                        complete(*prev)
+                prev = (begun, i)
+            if prev is not None:
+                with torch.cuda.stream(back):
+                    complete(*prev)
+            ri0.scratch_slot = 0
         if pending is not None:
             pending[0].wait()
         return rgb, pts
@@ -518,6 +556,7 @@ def main():
             "bvh_fallback_frames": getattr(stages, "fallbacks", 0),
             "overflow_repaired_frames": mi.rayintersector.repaired_frames,
             "reorigin_rule_redone_frames": mi.rayintersector.rule_redone_frames,
+            "frames_in_flight": args.pipeline,
             "parallelism": f"{world} rank(s), the frames dealt round-robin to the ranks, one frame per rank per step"
                            + (", all_gather_into_tensor of the finished frames" if gather else ", no data-path collective"),
         },

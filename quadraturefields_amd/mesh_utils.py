@@ -89,6 +89,7 @@ class RayIntersector:
         self.repaired_frames = 0         # frames on which some pixels overflowed K and were repaired through the BVH
         self._raster_streak = 0          # consecutive camera-coherent attempts that overflowed (see want_raster)
         self._raster_trying = False
+        self.scratch_slot = 0            # see _frame_scratch
         self._rule_upfront = 0           # frames left that decide the re-origin rule up front (see _hits_raster_frame)
         self._rule_pending = None        # the frame whose optimistic pack has not been checked yet (rule_violated)
         self.rule_redone_frames = 0      # frames packed twice because the optimistic check failed
@@ -240,7 +241,10 @@ class RayIntersector:
         """Per-ray-count scratch reused across frames: [n+2] int64 = sample offsets | total | raster overflow counter,
         the scan's temp storage, a pinned (device-writable) host block [total, overflow, close-pair flag, -] that the
         kernels write directly, and the two events that guard it (after the offsets; after the pack)."""
-        key = (n, torch.cuda.current_stream().cuda_stream)      # frames in flight on different streams do not share it
+        # frames in flight on different streams, or two consecutive frames of a front / back pipeline (``scratch_slot``
+        # alternates: the next frame's offsets kernel must not overwrite the pinned block the host has not read yet),
+        # do not share it
+        key = (n, torch.cuda.current_stream().cuda_stream, self.scratch_slot)
         s = self._scratch.get(key)
         if s is None:
             buf = torch.zeros((n + 2,), dtype=torch.int64, device=self.device)
@@ -250,7 +254,7 @@ class RayIntersector:
             temp = torch.empty((nbytes,), dtype=torch.uint8, device=self.device)
             host = torch.zeros((4,), dtype=torch.int64).pin_memory()
             s = self._scratch[key] = (buf, temp, host, (torch.cuda.Event(), torch.cuda.Event()))
-            if len(self._scratch) > 8:
+            if len(self._scratch) > 16:
                 self._scratch.pop(next(iter(self._scratch)))
         return s
 
