@@ -127,7 +127,9 @@ typedef struct qf_sg_head {
 int qf_field_forward(const qf_field_desc *desc /* host */, const float *table,
                      const float *base_w, const float *head_ngp_w, const qf_sg_head *head_sg /* host */,
                      const float *xyz, const float *dirs, int64_t n, const int32_t *order,
-                     float *rgb, float *sigma, float *geo, float *features, void *stream);
+                     float *rgb, float *sigma, float *geo, float *features,
+                     float *enc_out /* [n,32] or NULL: the hash-grid encoding, for the training step's backward */,
+                     void *stream);
 
 /* bf16 variant (BASELINE config 3): hash tables as bf16x2 rows, MLP weights as bf16 (round-to-nearest-even copies of
  * the fp32 parameters, same layouts), activations rounded to bf16 between layers, fp32 accumulate on
@@ -184,7 +186,7 @@ int qf_deform_field_forward(const qf_grid_desc *grid /* host */, const float *ta
                             int32_t hidden, const float *w1, const float *b1, const float *w2,
                             const float *b2, const float *wout, const float *bout,
                             const float *xyz, int64_t n, const int32_t *order, float *out /* [n] */,
-                            void *stream);
+                            float *enc_out /* [n,32] or NULL */, void *stream);
 
 /* Backward of the decoder of qf_deform_field_forward, fused (training: the deformation field of
  * train_finetune.py:387-399 is optimised together with the radiance field).  enc [n,32] = grid encoding of x01 [n,3],

@@ -61,13 +61,13 @@ _SIGNATURES = {
     "qf_grid_encode_backward_ws": (c_int, [POINTER(GridDesc), _P, _P, _P, c_int64, _P, _P, _P, c_int64, _P]),
     "qf_grid_encode_double_backward": (c_int, [POINTER(GridDesc), _P, _P, _P, _P, c_int64, _P, _P, _P, _P]),
     "qf_grid_mlp_forward": (c_int, [POINTER(GridDesc), _P, _P, _P, c_int64, _P, _P]),
-    "qf_field_forward": (c_int, [POINTER(FieldDesc), _P, _P, _P, POINTER(SGHead), _P, _P, c_int64, _P, _P, _P, _P, _P, _P]),
+    "qf_field_forward": (c_int, [POINTER(FieldDesc), _P, _P, _P, POINTER(SGHead), _P, _P, c_int64, _P, _P, _P, _P, _P, _P, _P]),
     "qf_field_forward_bf16": (c_int, [POINTER(FieldDesc), _P, _P, _P, POINTER(SGHead), _P, _P, c_int64, _P, _P, _P, _P, _P]),
     "qf_ngp_mlp_backward": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int64, _P, _P, _P, _P]),
     "qf_sg_mlp_backward": (c_int, [_P, _P, _P, c_int64, _P, _P, POINTER(SGHead), c_int32, c_int64, _P, _P, POINTER(SGHead), _P]),
     "qf_sg_features_to_rgb": (c_int, [_P, c_int64, _P, c_int64, c_int32, _P, _P]),
     "qf_sg_features_to_rgb_backward": (c_int, [_P, c_int64, _P, _P, c_int64, c_int32, _P, c_int64, _P]),
-    "qf_deform_field_forward": (c_int, [POINTER(GridDesc), _P, c_float, c_int32, _P, _P, _P, _P, _P, _P, _P, c_int64, _P, _P, _P]),
+    "qf_deform_field_forward": (c_int, [POINTER(GridDesc), _P, c_float, c_int32, _P, _P, _P, _P, _P, _P, _P, c_int64, _P, _P, _P, _P]),
     "qf_deform_mlp_backward": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "qf_apply_deformation": (c_int, [_P, c_float, _P, _P, _P, c_int64, _P]),
     "qf_mark_pack_boundaries": (c_int, [_P, c_int64, _P, _P]),

@@ -57,6 +57,7 @@ struct FieldArgs {
     float *geo;
     float *features;
     float *raw16;       // optional [n,16]: raw base-MLP outputs (tcnn NetworkWithInputEncoding.forward)
+    float *enc_out;     // optional [n,32]: the hash-grid encoding, kept for the training step's backward
     const int32_t *order;   // optional [n]: point processed at slot i
     int32_t n_lobes;
     int32_t n_out;      // 3 + 7L
@@ -247,6 +248,11 @@ __global__ __launch_bounds__(kBlock, 4) void field_kernel(const FieldArgs a)
         float feat[8];
 #pragma unroll
         for (int j = 0; j < 4; ++j) level_blend(val[j], frac[j], &feat[2 * j], &feat[2 * j + 1]);
+        if (a.enc_out && valid) {          // training: the backward reads this instead of gathering the table again
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                *reinterpret_cast<float2 *>(a.enc_out + pt * 32 + 2 * (4 * j + g)) = make_float2(feat[2 * j], feat[2 * j + 1]);
+        }
 
         // ---- base MLP 32 -> 64 (ReLU) -> 16
         f32x4 h[4];
@@ -497,6 +503,7 @@ struct DeformArgs {
     const int32_t *order;
     int64_t n;
     float *out;
+    float *enc_out;     // optional [n,32], see FieldArgs
 };
 
 constexpr int kDeformMfma = 18 + 16 + 8;
@@ -573,6 +580,11 @@ __global__ __launch_bounds__(kBlock, 4) void deform_kernel(const DeformArgs a)
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) level_blend(val[j], frac[j], &in[2 * j], &in[2 * j + 1]);
+        if (a.enc_out && valid) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                *reinterpret_cast<float2 *>(a.enc_out + pt * 32 + 2 * (4 * j + g)) = make_float2(in[2 * j], in[2 * j + 1]);
+        }
         int loff = lane;
         asm volatile("" : "+v"(loff));
         const float *wl = lds + loff;
@@ -645,10 +657,11 @@ extern "C" int qf_grid_encode(const qf_grid_desc *desc, const float *table, cons
 extern "C" int qf_field_forward(const qf_field_desc *desc, const float *table, const float *base_w,
                                 const float *head_ngp_w, const qf_sg_head *head_sg, const float *xyz,
                                 const float *dirs, int64_t n, const int32_t *order, float *rgb, float *sigma,
-                                float *geo, float *features, void *stream)
+                                float *geo, float *features, float *enc_out, void *stream)
 {
     if (!desc || !table || !base_w || n < 0 || n > 0x7fffffff) return QF_ERR_INVALID_ARGUMENT;
     FieldArgs a = {};
+    a.enc_out = enc_out;
     int rc = fill_grid_args(&desc->grid, &a.grid);
     if (rc != QF_OK) return rc;
     for (int k = 0; k < 3; ++k) {
@@ -727,7 +740,7 @@ extern "C" int qf_sg_features_to_rgb(const float *features, int64_t feat_stride,
 extern "C" int qf_deform_field_forward(const qf_grid_desc *grid, const float *table, float scale, int32_t hidden,
                                        const float *w1, const float *b1, const float *w2, const float *b2,
                                        const float *wout, const float *bout, const float *xyz, int64_t n,
-                                       const int32_t *order, float *out, void *stream)
+                                       const int32_t *order, float *out, float *enc_out, void *stream)
 {
     if (!grid || !table || n < 0 || !(scale > 0.0f)) return QF_ERR_INVALID_ARGUMENT;
     if (hidden != 32) return QF_ERR_UNSUPPORTED;
@@ -744,6 +757,7 @@ extern "C" int qf_deform_field_forward(const qf_grid_desc *grid, const float *ta
     a.order = order;
     a.n = n;
     a.out = out;
+    a.enc_out = enc_out;
     const size_t lds_bytes = (size_t)(kDeformMfma * 64 + 64) * sizeof(float);
     int64_t blocks = qf_div_up((n + 15) / 16, kBlock / 64);
     const int64_t cap = (int64_t)qf_cu_count_cached();     // one workgroup per CU, see launch_field

@@ -40,14 +40,16 @@ class _DeformTrainFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, table, w1, b1, w2, b2, wout, bout, module):
         x = _C.f32c(x.detach().reshape(-1, 3))
-        ctx.save_for_backward(x, table, w1, b1, w2, b2, wout, bout)
+        enc = torch.empty((x.shape[0], 32), dtype=torch.float32, device=x.device)     # kept for the backward
+        out = module._density_fused(x, None, enc_out=enc)
+        ctx.save_for_backward(x, table, w1, b1, w2, b2, wout, bout, enc)
         ctx.module = module
-        return module._density_fused(x, None)
+        return out
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, d_out):
-        x, table, w1, b1, w2, b2, wout, bout = ctx.saved_tensors
+        x, table, w1, b1, w2, b2, wout, bout, enc = ctx.saved_tensors
         m = ctx.module
         n = x.shape[0]
         dev = x.device
@@ -59,9 +61,7 @@ class _DeformTrainFn(torch.autograd.Function):
         if n:
             x01 = _C.f32c((x - m.xyz_min) / (m.xyz_max - m.xyz_min))
             desc = m.xyz_encoder.grid.desc
-            enc = torch.empty((n, 32), dtype=torch.float32, device=dev)
             d_enc = torch.empty((n, 32), dtype=torch.float32, device=dev)
-            _C.check(lib.qf_grid_encode(desc, _C.ptr(table), _C.ptr(x01), n, _C.ptr(enc), _C.stream()), "qf_grid_encode")
             _C.check(lib.qf_deform_mlp_backward(_C.ptr(enc), _C.ptr(x01), _C.ptr(_C.f32c(d_out.reshape(-1))),
                                                 *[_C.ptr(t) for t in ws], n, _C.ptr(d_enc), None,
                                                 *[_C.ptr(t) for t in grads], _C.stream()), "qf_deform_mlp_backward")
@@ -112,7 +112,7 @@ class Field(nn.Module):
     #: (``_DeformTrainFn``); the input-gradient / second-order route always goes through the hash-grid autograd Function.
     fused_backward = True
 
-    def _density_fused(self, x, order=None):
+    def _density_fused(self, x, order=None, enc_out=None):
         x = _C.f32c(x.reshape(-1, 3))
         n = x.shape[0]
         out = torch.empty((n,), dtype=torch.float32, device=x.device)
@@ -122,7 +122,7 @@ class Field(nn.Module):
         _C.check(_C.lib().qf_deform_field_forward(
             self.xyz_encoder.grid.desc, _C.ptr(self.xyz_encoder.params.detach()), float(self.scale), 32,
             *[_C.ptr(t) for t in w], _C.ptr(x), n, _C.ptr(order, torch.int32) if order is not None and order.shape[0] == n else None,
-            _C.ptr(out), _C.stream()), "qf_deform_field_forward")
+            _C.ptr(out), _C.ptr(enc_out), _C.stream()), "qf_deform_field_forward")
         return out[:, None]
 
     def field(self, x, order=None):

@@ -187,7 +187,7 @@ class _FusedFieldBase(nn.Module):
         return selector, x
 
     def _launch(self, head, n_lobes, xyz, dirs, want_rgb=False, want_sigma=False, want_geo=False, want_features=0,
-                head_ngp=None, head_sg=None, order=None):
+                head_ngp=None, head_sg=None, order=None, enc_out=None):
         xyz = _C.f32c(xyz.reshape(-1, 3))
         n = xyz.shape[0]
         dev = xyz.device
@@ -221,7 +221,8 @@ class _FusedFieldBase(nn.Module):
         _C.check(_C.lib().qf_field_forward(
             ctypes.byref(desc), _C.ptr(self.mlp_base.grid_params()), _C.ptr(self.mlp_base.network_params()),
             _C.ptr(head_ngp), ctypes.byref(sg) if sg is not None else None, _C.ptr(xyz), _C.ptr(dirs), n,
-            _C.ptr(order, torch.int32), _C.ptr(rgb), _C.ptr(sigma), _C.ptr(geo), _C.ptr(feats), _C.stream()), "qf_field_forward")
+            _C.ptr(order, torch.int32), _C.ptr(rgb), _C.ptr(sigma), _C.ptr(geo), _C.ptr(feats), _C.ptr(enc_out), _C.stream()),
+                 "qf_field_forward")
         return rgb, sigma, geo, feats
 
     def _recording(self, *inputs) -> bool:
@@ -290,16 +291,19 @@ class _NGPTrainFn(torch.autograd.Function):
     def forward(ctx, positions, directions, base_params, head_params, module):
         xyz = _C.f32c(positions.detach().reshape(-1, 3))
         dirs = _C.f32c(directions.detach().reshape(-1, 3))
+        # the forward IS the inference kernel; it also leaves the hash-grid encoding behind for the backward (128 B per
+        # point) -- gathering the table a second time there cost 0.64 ms per 0.8 M points
+        enc = torch.empty((xyz.shape[0], 32), dtype=torch.float32, device=xyz.device)
         rgb, sigma, _, _ = module._launch(_C.HEAD_NGP, 0, xyz, dirs, want_rgb=True, want_sigma=True,
-                                          head_ngp=head_params.detach())
-        ctx.save_for_backward(xyz, dirs, base_params, head_params)
+                                          head_ngp=head_params.detach(), enc_out=enc)
+        ctx.save_for_backward(xyz, dirs, base_params, head_params, enc)
         ctx.module = module
         return rgb, sigma
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, d_rgb, d_sigma):
-        xyz, dirs, base_params, head_params = ctx.saved_tensors
+        xyz, dirs, base_params, head_params, enc = ctx.saved_tensors
         m = ctx.module
         n = xyz.shape[0]
         dev = xyz.device
@@ -312,7 +316,6 @@ class _NGPTrainFn(torch.autograd.Function):
         sel = selector.to(torch.uint8).contiguous()
         lib = _C.lib()
         desc = m.mlp_base.grid.desc
-        enc = torch.empty((n, 32), dtype=torch.float32, device=dev)
         d_enc = torch.empty((n, 32), dtype=torch.float32, device=dev)
         g_net = torch.zeros_like(net_w)
         g_head = torch.zeros_like(head_w)
@@ -320,7 +323,6 @@ class _NGPTrainFn(torch.autograd.Function):
         g_table = torch.zeros_like(table) if need_base else None
         g_x01 = torch.empty_like(x01) if need_x else None
         if n:
-            _C.check(lib.qf_grid_encode(desc, _C.ptr(table), _C.ptr(x01), n, _C.ptr(enc), _C.stream()), "qf_grid_encode")
             _C.check(lib.qf_ngp_mlp_backward(_C.ptr(enc), _C.ptr(dirs), _C.ptr(sel), _C.ptr(_C.f32c(d_rgb.reshape(-1, 3))),
                                              _C.ptr(_C.f32c(d_sigma.reshape(-1))), _C.ptr(net_w), _C.ptr(head_w), n,
                                              _C.ptr(d_enc), _C.ptr(g_net), _C.ptr(g_head), _C.stream()),
@@ -346,19 +348,20 @@ class _SGTrainFn(torch.autograd.Function):
         n = xyz.shape[0]
         head = [_C.f32c(t.detach()) for t in (w1, b1, w2, b2, wout, bout)]
         width = 3 + 7 * module.num_g_lobes + 1
+        enc = torch.empty((n, 32), dtype=torch.float32, device=xyz.device)        # kept for the backward, see _NGPTrainFn
         _, _, _, feats = module._launch(_C.HEAD_SG_FEATURES, module.num_g_lobes, xyz, None, want_features=width,
-                                        head_sg=head)
+                                        head_sg=head, enc_out=enc)
         rgb = torch.empty((n, 3), dtype=torch.float32, device=xyz.device)
         _C.check(_C.lib().qf_sg_features_to_rgb(_C.ptr(feats), width, _C.ptr(dirs), n, module.num_g_lobes, _C.ptr(rgb),
                                                 _C.stream()), "qf_sg_features_to_rgb")
-        ctx.save_for_backward(xyz, dirs, feats, base_params, *head)
+        ctx.save_for_backward(xyz, dirs, feats, base_params, enc, *head)
         ctx.module = module
         return rgb, feats[:, -1].contiguous()
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, d_rgb, d_sigma):
-        xyz, dirs, feats, base_params, w1, b1, w2, b2, wout, bout = ctx.saved_tensors
+        xyz, dirs, feats, base_params, enc, w1, b1, w2, b2, wout, bout = ctx.saved_tensors
         m = ctx.module
         n = xyz.shape[0]
         dev = xyz.device
@@ -374,7 +377,6 @@ class _SGTrainFn(torch.autograd.Function):
         desc = m.mlp_base.grid.desc
         need_x, need_base = ctx.needs_input_grad[0], ctx.needs_input_grad[2]
         d_feat = torch.empty((n, 3 + 7 * L), dtype=torch.float32, device=dev)
-        enc = torch.empty((n, 32), dtype=torch.float32, device=dev)
         d_enc = torch.empty((n, 32), dtype=torch.float32, device=dev)
         g_net = torch.zeros_like(net_w)
         grads = [torch.zeros_like(t) for t in (w1, b1, w2, b2, wout, bout)]
@@ -384,7 +386,6 @@ class _SGTrainFn(torch.autograd.Function):
             _C.check(lib.qf_sg_features_to_rgb_backward(_C.ptr(feats), width, _C.ptr(dirs), _C.ptr(_C.f32c(d_rgb.reshape(-1, 3))),
                                                         n, L, _C.ptr(d_feat), d_feat.shape[1], _C.stream()),
                      "qf_sg_features_to_rgb_backward")
-            _C.check(lib.qf_grid_encode(desc, _C.ptr(table), _C.ptr(x01), n, _C.ptr(enc), _C.stream()), "qf_grid_encode")
             head = _C.SGHead(*[_C.ptr(t) for t in (w1, b1, w2, b2, wout, bout)])
             ghead = _C.SGHead(*[_C.ptr(t) for t in grads])
             _C.check(lib.qf_sg_mlp_backward(_C.ptr(enc), _C.ptr(sel), _C.ptr(d_feat), d_feat.shape[1],
