@@ -172,8 +172,29 @@ def ptr(t, dtype=None, device_required: bool = True):
     return c_void_p(t.data_ptr())
 
 
+_OWNER_PID = os.getpid()          # the process that imported the package (and will own the HIP context)
+_FORKED = False
+
+
+def _after_fork_in_child():
+    global _FORKED
+    _FORKED = True
+
+
+os.register_at_fork(after_in_child=_after_fork_in_child)
+
+
 def stream():
-    """The current torch HIP stream as a raw handle."""
+    """The current torch HIP stream as a raw handle.  Every kernel launch of the package goes through here, so this is
+    also where a FORKED child is stopped: the reference runs its intersector inside DataLoader worker processes
+    (train_finetune.py:313 with num_workers > 0), and a HIP context cannot be created or used in a forked child -- it
+    hangs or corrupts the parent's.  Use num_workers=0 for the device path, or keep only ray generation in the workers
+    (INTEGRATION.md section 1)."""
+    if _FORKED:
+        raise RuntimeError(
+            "quadraturefields_amd was called from a forked child process (a DataLoader worker?): the HIP kernels must run "
+            f"in the process that imported the package (pid {_OWNER_PID}).  Use num_workers=0 for the device path, or a "
+            "'spawn' multiprocessing context.")
     return c_void_p(torch.cuda.current_stream().cuda_stream)
 
 

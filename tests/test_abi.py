@@ -75,3 +75,25 @@ def test_product_does_not_import_oracle():
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
                 assert "oracle/" not in src or f.endswith(".hip") or f.endswith(".h"), f
+
+
+def test_forked_worker_is_refused():
+    """SURVEY 8b "Threading": the reference calls its intersector from forked DataLoader workers; a HIP context must not
+    be touched there.  The package refuses the call in a forked child with a clear error instead of hanging."""
+    import multiprocessing as mp
+    from quadraturefields_amd import _C
+
+    def child(q):
+        try:
+            _C.stream()
+            q.put("no error")
+        except RuntimeError as e:
+            q.put(str(e))
+
+    ctx = mp.get_context("fork")
+    q = ctx.Queue()
+    p = ctx.Process(target=child, args=(q,))
+    p.start()
+    msg = q.get(timeout=60)
+    p.join(timeout=30)
+    assert "forked child" in msg and "num_workers=0" in msg
