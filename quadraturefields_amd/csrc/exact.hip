@@ -154,6 +154,7 @@ struct TravArgs {
     const float *rays_o, *rays_d;
     int64_t n_rays;
     int root_is_valid, max_hits, image_width, image_height, tiles_x, n_blocks, blocks_per_xcd, stack_cap;
+    int stripe_blocks;           // > 0: image-shaped launch, blocks per stripe of the XCD comb (see xcd_block)
     int list_cap;                // entries of the LDS K-list: max_hits, or a few more when the re-origin rule is on
     float min_sep;
     int32_t *hit_tri;
@@ -358,10 +359,21 @@ __device__ __forceinline__ void oct_traverse_ray(const TravArgs &ta, int64_t ray
     }
 }
 
-// XCD-aware block order: hardware deals workgroups round-robin to the 8 XCDs (private L2 each); XCD x walks the x-th
-// CONTIGUOUS eighth of the blocks, i.e. one band of the image / one slice of the batch, so its L2 only has to hold
-// that band's part of the tree.
-__device__ __forceinline__ int xcd_block(const TravArgs &a) { return (int)(blockIdx.x & 7) * a.blocks_per_xcd + (int)(blockIdx.x >> 3); }
+// XCD-aware block order: hardware deals workgroups round-robin to the 8 XCDs (private L2 each).  A plain batch: XCD x
+// walks the x-th CONTIGUOUS eighth of the blocks (one slice of the batch), so its L2 only has to hold that slice's part
+// of the tree.  An image: contiguous eighths are row bands, and the object sits in the middle ones -- the XCDs of the
+// top and bottom bands idle while two XCDs carry the frame (PMC: one resident wave per SIMD on average).  So the image
+// is dealt in STRIPES of two tile rows (8 pixel rows): stripe s goes to XCD s % 8, every XCD gets a comb over the whole
+// image (balanced), and consecutive blocks of an XCD are still neighbouring tiles of one stripe (L2-friendly).
+__device__ __forceinline__ int xcd_block(const TravArgs &a)
+{
+    const int x = (int)(blockIdx.x & 7), k = (int)(blockIdx.x >> 3);
+    if (a.stripe_blocks > 0) {
+        const int s = k / a.stripe_blocks, p = k - s * a.stripe_blocks;
+        return (s * 8 + x) * a.stripe_blocks + p;
+    }
+    return x * a.blocks_per_xcd + k;
+}
 
 // Every ray of the batch: a workgroup = 32 rays (image-shaped batches: 8x4 pixels, a wave = 4x2 pixels).
 __global__ __launch_bounds__(kTravThreads) void bvh8_traverse_kernel(TravArgs a)
@@ -397,7 +409,7 @@ __global__ __launch_bounds__(kTravThreads) void bvh8_repair_kernel(TravArgs a)
     __shared__ int s_n;
     const int tid = threadIdx.x, j = tid & 7, q = tid >> 3;
     const int oct_base = (tid & 63) & 56;
-    const int block = xcd_block(a);
+    const int block = (int)blockIdx.x;          // consecutive blocks on different XCDs: the work (object rays) is spread evenly
     if (block >= a.n_blocks) return;
     const int K = a.max_hits;
     if (tid == 0) s_n = 0;
@@ -1253,7 +1265,20 @@ static int bvh_launch(const qf_bvh *bvh, const float *rays_o, const float *rays_
     a.raw_count = a.keep_mask ? raw_count : nullptr;
     a.tcol_offset = (int)tcol_offset;
     if (only_overflowed) n_blocks = qf_div_up(n_rays, kTravThreads);        // 256 consecutive rays per workgroup
-    const int64_t per_xcd = qf_div_up(n_blocks, 8);
+    int64_t per_xcd = qf_div_up(n_blocks, 8);
+    a.stripe_blocks = 0;
+    if (!only_overflowed) {
+        // image: stripes of two tile rows; a large plain batch: stripes of 256 blocks (8 192 consecutive rays) -- it may well
+        // be a row-major image handed over without its width, and contiguous eighths would be as lopsided as bands
+        // (1.65 -> 1.01 ms for the bench frame); batches under 2^18 rays keep contiguous eighths (a 2^17-ray batch sorted
+        // by camera and pixel: 0.42 ms contiguous, 0.63 ms in 64-block stripes)
+        a.stripe_blocks = image_width > 0 ? tiles_x * 2 : 256;
+        if (n_blocks < (int64_t)a.stripe_blocks * (image_width > 0 ? 16 : 32)) a.stripe_blocks = 0;
+    }
+    if (a.stripe_blocks > 0) {
+        const int64_t stripes = qf_div_up(n_blocks, a.stripe_blocks);
+        per_xcd = qf_div_up(stripes, 8) * a.stripe_blocks;
+    }
     if (per_xcd * 8 > 0x7fffffff) return QF_ERR_UNSUPPORTED;
     a.n_blocks = (int)n_blocks; a.blocks_per_xcd = (int)per_xcd;
     const void *fn = only_overflowed ? reinterpret_cast<const void *>(bvh8_repair_kernel)
