@@ -457,7 +457,8 @@ int qf_pack_samples(const float *rays_o, const float *rays_d, int64_t n_rays, in
 int qf_tile_totals(const int32_t *hit_count, int32_t width, int32_t height, int64_t *tile_total, void *stream);
 int qf_coherent_order(const int32_t *hit_count, const int64_t *ray_offset, const int64_t *tile_base,
                       int32_t width, int32_t height, int32_t *order, void *stream);
-/* Same order together with its inverse: inverse[sample] = position (see qf_pack_samples).      */
+/* Same order together with its inverse: inverse[sample] = position (see qf_pack_samples).  order may be NULL
+ * (a render-only frame streams the coherent copies and only needs the inverse).                  */
 int qf_coherent_layout(const int32_t *hit_count, const int64_t *ray_offset, const int64_t *tile_base,
                        int32_t width, int32_t height, int32_t *order, int32_t *inverse, void *stream);
 

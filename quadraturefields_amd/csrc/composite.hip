@@ -431,7 +431,7 @@ __global__ __launch_bounds__(64) void coherent_order_kernel(const int32_t *hit_c
         if (mask == 0ull) break;                      // wave-uniform exit
         if (cnt > k) {
             const int64_t pos = base + __popcll(mask & below), smp = first + k;
-            order[pos] = (int32_t)smp;
+            if (order) order[pos] = (int32_t)smp;
             if (inverse) inverse[smp] = (int32_t)pos;
         }
         base += __popcll(mask);
@@ -464,7 +464,7 @@ extern "C" int qf_coherent_order(const int32_t *hit_count, const int64_t *ray_of
 extern "C" int qf_coherent_layout(const int32_t *hit_count, const int64_t *ray_offset, const int64_t *tile_base,
                                   int32_t width, int32_t height, int32_t *order, int32_t *inverse, void *stream)
 {
-    if (width < 1 || height < 1 || !hit_count || !ray_offset || !tile_base || !order || !inverse)
+    if (width < 1 || height < 1 || !hit_count || !ray_offset || !tile_base || !inverse)       // order may be NULL
         return QF_ERR_INVALID_ARGUMENT;
     const int tiles_x = (width + 7) / 8, tiles_y = (height + 7) / 8;
     hipLaunchKernelGGL(coherent_order_kernel, dim3(tiles_x * tiles_y), dim3(64), 0, qf_stream(stream), hit_count,

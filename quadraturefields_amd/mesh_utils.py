@@ -355,7 +355,7 @@ class RayIntersector:
         depth = torch.empty((cap,), dtype=torch.float32, device=dev)
         order = inverse = xyz_c = dirs_c = layout = None          # (from here on ``layout`` is the result tuple)
         if image:                             # the coherent order, its inverse, and streamed copies
-            order, inverse = self.coherent_layout(hit_count, buf, cap, width, tile_base)
+            order, inverse = self.coherent_layout(hit_count, buf, cap, width, tile_base, want_order=not lean)
             xyz_c = torch.empty((cap, 3), dtype=torch.float32, device=dev)
             dirs_c = torch.empty((cap, 3), dtype=torch.float32, device=dev)
             layout = (inverse, xyz_c, dirs_c)
@@ -464,7 +464,7 @@ class RayIntersector:
         return data
 
     @_on_device
-    def coherent_layout(self, hit_count, ray_offset, total: int, width: int, tile_base=None):
+    def coherent_layout(self, hit_count, ray_offset, total: int, width: int, tile_base=None, want_order=True):
         """``coherent_order`` and its inverse map (``inverse[sample] = position``).  Given the inverse,
         ``qf_pack_samples`` also writes ``xyz[order]`` / ``dirs[order]``, so ``field(xyz_c, dirs_c)`` reads and writes
         sequentially (the indirection through ``order`` costs it 10 %), and
@@ -477,7 +477,8 @@ class RayIntersector:
             totals = torch.empty((tiles,), dtype=torch.int64, device=dev)
             _C.check(_C.lib().qf_tile_totals(_C.ptr(hit_count), width, height, _C.ptr(totals), _C.stream()), "qf_tile_totals")
             tile_base = (torch.cumsum(totals, dim=0) - totals).contiguous()
-        order = torch.empty((total,), dtype=torch.int32, device=dev)
+        # a lean (render-only) frame streams the coherent copies and never reads the forward permutation: skip it
+        order = torch.empty((total,), dtype=torch.int32, device=dev) if want_order else None
         inverse = torch.empty((total,), dtype=torch.int32, device=dev)
         _C.check(_C.lib().qf_coherent_layout(_C.ptr(hit_count), _C.ptr(ray_offset), _C.ptr(tile_base), width, height,
                                              _C.ptr(order), _C.ptr(inverse), _C.stream()), "qf_coherent_layout")

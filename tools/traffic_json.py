@@ -22,7 +22,7 @@ fetch, n_f = per_launch("FETCH_SIZE")
 write, n_w = per_launch("WRITE_SIZE")
 bench = json.load(open(os.path.join(root, "pmc_FETCH_SIZE.json")))
 print(json.dumps({
-    "kernel": "field_kernel<1>", "fetch_bytes_per_launch": fetch, "write_bytes_per_launch": write,
+    "kernel": "field_kernel<1, false>", "fetch_bytes_per_launch": fetch, "write_bytes_per_launch": write,
     "points_per_launch": bench["quadrature_points_per_frame"],
     "source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) over `python bench.py --steps 5 "
               f"--warmup 1 --no-cpu-baseline`, mean of {n_f} / {n_w} dispatches (tools/profile_bench.sh)",
