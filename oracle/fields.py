@@ -209,21 +209,31 @@ def basic_decoder(h: Tensor, layers: List[Tuple[Tensor, Tensor]]) -> Tensor:
     return F.linear(h, w, b)
 
 
-def spherical_gaussian_mixture(x: Tensor, direction: Tensor, n_lobes: int) -> Tensor:
-    """ngp.py:371-393 (discretize=False): sum_l c_l * exp(|lambda_l| (a_l/|a_l| . d - 1))."""
+def spherical_gaussian_mixture(x: Tensor, direction: Tensor, n_lobes: int, discretize: bool = False) -> Tensor:
+    """ngp.py:371-393: sum_l c_l * exp(|lambda_l| (a_l/|a_l| . d - 1)); ``discretize`` sends axis, sharpness and
+    colour of every lobe through their uint8 codecs and back first (ngp.py:377-382)."""
+    from . import quantize as q
     rgb = torch.zeros((x.shape[0], 3), dtype=x.dtype)
     for lobe in torch.chunk(x, n_lobes, dim=-1):
         axis = lobe[..., :3]
         axis = axis / torch.linalg.norm(axis, dim=-1, keepdim=True)
         lam = torch.abs(lobe[..., 3])
         c = lobe[..., 4:]
+        if discretize:
+            axis = q.inverse_of_azimuth_and_elevation(*q.compress_polar_coordinates(axis))
+            lam = q.inverse_of_compressed_lambda(q.compress_lambda(lam))
+            c = q.inverse_of_compressed_colors(q.compress_colors(c))
         rgb = rgb + c * torch.exp(lam * (torch.sum(axis * direction, -1) - 1))[..., None]
     return rgb
 
 
-def features_to_rgb(features: Tensor, d: Tensor, n_lobes: int) -> Tensor:
-    """ngp.py:456-461 (discretize=False)."""
-    return torch.sigmoid(features[:, :3] + spherical_gaussian_mixture(features[:, 3:], d, n_lobes))
+def features_to_rgb(features: Tensor, d: Tensor, n_lobes: int, discretize: bool = False) -> Tensor:
+    """ngp.py:456-461; ``discretize`` also round-trips the diffuse colour (ngp.py:458-459)."""
+    diffuse = features[:, :3]
+    if discretize:
+        from . import quantize as q
+        diffuse = q.inverse_of_compressed_colors(q.compress_colors(diffuse))
+    return torch.sigmoid(diffuse + spherical_gaussian_mixture(features[:, 3:], d, n_lobes, discretize))
 
 
 def sg_features(x: Tensor, wts: NGPWeights) -> Tensor:

@@ -589,7 +589,13 @@ __global__ __launch_bounds__(256) void raster_kernel(const float4 *__restrict__ 
 // bvh_traverse_kernel -- in the ordinary [ray][K] lists (arrival order; qf_pack_samples sorts).  lane = ray, its K
 // running entries in a private LDS column.  Rays that lost candidates even at `wide` keep count > K and go to
 // qf_bvh_repair_overflow.
-constexpr int kSelectBlock = 64;     // one wave: K = 64 needs 32 KB of LDS
+constexpr int kSelectBlock = 64;     // one wave: K = 64 (+ headroom) needs 36 KB of LDS
+constexpr int kSelectHeadroom = 8;   // with the re-origin rule: candidates kept beyond K so that dropped hits can be replaced
+__host__ __device__ inline int select_capacity(int max_hits, int wide, float min_sep)
+{
+    const int cap = min_sep > 0.0f ? max_hits + kSelectHeadroom : max_hits;
+    return cap < wide ? cap : wide;
+}
 __global__ __launch_bounds__(kSelectBlock) void select_nearest_kernel(int64_t n_rays, int wide, int max_hits, float min_sep,
                                                                       const int32_t *__restrict__ wide_tri,
                                                                       const float *__restrict__ wide_t,
@@ -597,8 +603,9 @@ __global__ __launch_bounds__(kSelectBlock) void select_nearest_kernel(int64_t n_
                                                                       int32_t *__restrict__ hit_count)
 {
     extern __shared__ float select_lds[];
-    float *lt = select_lds + threadIdx.x;                                                  // [max_hits][block]
-    int *li = reinterpret_cast<int *>(select_lds + (size_t)max_hits * kSelectBlock) + threadIdx.x;
+    const int cap = select_capacity(max_hits, wide, min_sep);
+    float *lt = select_lds + threadIdx.x;                                                  // [cap][block]
+    int *li = reinterpret_cast<int *>(select_lds + (size_t)cap * kSelectBlock) + threadIdx.x;
     const int64_t r = (int64_t)blockIdx.x * kSelectBlock + threadIdx.x;
     if (r >= n_rays) return;
     const int cnt = hit_count[r];
@@ -612,16 +619,18 @@ __global__ __launch_bounds__(kSelectBlock) void select_nearest_kernel(int64_t n_
         }
         return;
     }
+    // the `held` nearest candidates under (t, tri); all of them when cnt <= cap
+    const int held = cnt < cap ? cnt : cap;
     float worst_t = -INFINITY;
     int worst_i = -1, worst_slot = 0;
-    for (int i = 0; i < max_hits; ++i) {
+    for (int i = 0; i < held; ++i) {
         const float t = wide_t[(int64_t)i * n_rays + r];
         const int id = wide_tri[(int64_t)i * n_rays + r];
         lt[i * kSelectBlock] = t;
         li[i * kSelectBlock] = id;
         if (hit_less(worst_t, worst_i, t, id)) { worst_t = t; worst_i = id; worst_slot = i; }
     }
-    for (int i = max_hits; i < cnt; ++i) {
+    for (int i = held; i < cnt; ++i) {
         const float t = wide_t[(int64_t)i * n_rays + r];
         const int id = wide_tri[(int64_t)i * n_rays + r];
         if (!hit_less(t, id, worst_t, worst_i)) continue;
@@ -629,41 +638,53 @@ __global__ __launch_bounds__(kSelectBlock) void select_nearest_kernel(int64_t n_
         li[worst_slot * kSelectBlock] = id;
         worst_t = -INFINITY;
         worst_i = -1;
-        for (int s = 0; s < max_hits; ++s) {
+        for (int s = 0; s < held; ++s) {
             const float ts = lt[s * kSelectBlock];
             const int is = li[s * kSelectBlock];
             if (hit_less(worst_t, worst_i, ts, is)) { worst_t = ts; worst_i = is; worst_slot = s; }
         }
     }
-    if (min_sep > 0.0f) {
-        // The re-origin rule (bvh8_traverse_kernel) runs over a ray's hits in ascending order; with more than K
-        // candidates the K nearest only decide it if the chain keeps all of them.  Sort the column, run the chain; if
-        // it drops anything the ray goes to the paged BVH traversal (count > K marks it for qf_bvh_repair_overflow).
-        for (int i = 1; i < max_hits; ++i) {
-            const float t = lt[i * kSelectBlock];
-            const int id = li[i * kSelectBlock];
-            int j = i - 1;
-            while (j >= 0 && hit_less(t, id, lt[j * kSelectBlock], li[j * kSelectBlock])) {
-                lt[(j + 1) * kSelectBlock] = lt[j * kSelectBlock];
-                li[(j + 1) * kSelectBlock] = li[j * kSelectBlock];
-                --j;
-            }
-            lt[(j + 1) * kSelectBlock] = t;
-            li[(j + 1) * kSelectBlock] = id;
+    if (min_sep <= 0.0f) {                   // held == K: arrival order, qf_pack_samples sorts
+        for (int i = 0; i < max_hits; ++i) {
+            row_t[i] = lt[i * kSelectBlock];
+            row_i[i] = li[i * kSelectBlock];
         }
-        float last_t = lt[0];
-        bool dropped = false;
-        for (int i = 1; i < max_hits; ++i) {
-            const float t = lt[i * kSelectBlock];
-            if (t > last_t + min_sep) last_t = t; else dropped = true;
-        }
-        if (dropped) return;                 // hit_count[r] stays > K
+        hit_count[r] = max_hits;
+        return;
     }
-    for (int i = 0; i < max_hits; ++i) {
+    // The re-origin rule (bvh8_traverse_kernel) runs over a ray's hits in ascending order, so the K nearest alone do
+    // not decide it: every hit the chain drops lets a farther one in.  Sort the held prefix of the ray's hits and run
+    // the chain over it.  K kept hits are the answer whatever lies behind; fewer are the answer only if the prefix
+    // was the whole list.  Otherwise the ray goes to the paged BVH traversal (count > K marks it for
+    // qf_bvh_repair_overflow).
+    for (int i = 1; i < held; ++i) {
+        const float t = lt[i * kSelectBlock];
+        const int id = li[i * kSelectBlock];
+        int j = i - 1;
+        while (j >= 0 && hit_less(t, id, lt[j * kSelectBlock], li[j * kSelectBlock])) {
+            lt[(j + 1) * kSelectBlock] = lt[j * kSelectBlock];
+            li[(j + 1) * kSelectBlock] = li[j * kSelectBlock];
+            --j;
+        }
+        lt[(j + 1) * kSelectBlock] = t;
+        li[(j + 1) * kSelectBlock] = id;
+    }
+    float last_t = lt[0];
+    int kept = 1;                            // compacted in place: slot `kept` never runs ahead of slot i
+    for (int i = 1; i < held && kept < max_hits; ++i) {
+        const float t = lt[i * kSelectBlock];
+        if (!(t > last_t + min_sep)) continue;
+        last_t = t;
+        lt[kept * kSelectBlock] = t;
+        li[kept * kSelectBlock] = li[i * kSelectBlock];
+        ++kept;
+    }
+    if (kept < max_hits && cnt > held) return;      // hit_count[r] stays > K
+    for (int i = 0; i < kept; ++i) {
         row_t[i] = lt[i * kSelectBlock];
         row_i[i] = li[i * kSelectBlock];
     }
-    hit_count[r] = max_hits;
+    hit_count[r] = kept;
 }
 
 // In-place ascending (t, tri) sort of every ray's (unordered) list, the re-origin rule (min_sep > 0: keep a hit iff it
@@ -1522,7 +1543,7 @@ extern "C" int qf_raster_intersect_wide(const qf_bvh *bvh, const qf_camera *cam,
     const int rc = raster_launch(bvh, cam, rays_o, rays_d, n_rays, (int)wide_hits, true, wide_tri, wide_t, hit_count, overflow, st);
     if (rc != QF_OK) return rc;
     if (n_rays == 0) return QF_OK;
-    const size_t lds = (size_t)max_hits * kSelectBlock * 2 * sizeof(float);       // <= 32 KB at K = 64
+    const size_t lds = (size_t)select_capacity(max_hits, wide_hits, bvh->min_sep) * kSelectBlock * 2 * sizeof(float);
     hipLaunchKernelGGL(select_nearest_kernel, dim3((unsigned)qf_div_up(n_rays, kSelectBlock)), dim3(kSelectBlock), lds, st,
                        n_rays, (int)wide_hits, (int)max_hits, bvh->min_sep, wide_tri, wide_t, hit_tri, hit_t, hit_count);
     QF_LAUNCH_CHECK();

@@ -63,6 +63,19 @@ def trimesh_ray_offset(vertices) -> float:
     return float(np.clip(1e-4 * (100.0 / diag), 1e-8, np.inf))
 
 
+class _InterView:
+    """``RayIntersector.inter``: the native module's two methods, bound to the adapter's BVH."""
+
+    def __init__(self, owner):
+        self._owner = owner
+
+    def find_intersections(self, rays):
+        return self._owner.find_intersections(rays)
+
+    def update_vertices(self, vertices):
+        self._owner.update_intersector(vertices)
+
+
 class RayIntersector:
     """Multi-hit ray/mesh intersector.  Duck-types trimesh's ``RayMeshIntersector`` and the reference's OptiX
     adapter (``intersects_id``, ``update_intersector``; mesh_utils.py:75-109).
@@ -128,6 +141,24 @@ class RayIntersector:
     @property
     def max_stack(self) -> int:
         return int(_C.lib().qf_bvh_max_stack(self._handle))
+
+    @property
+    def inter(self):
+        """The reference's adapter keeps the native module's object in ``.inter`` and the finetune loop REPLACES it
+        after a vertex update (``rayintersector.inter = intersector.Intersector(vertices[faces].flatten(), K, 0)``,
+        train_finetune.py:716-718).  Reading gives a view with that object's methods; assigning an
+        ``intersector.Intersector`` of the same triangle count adopts its freshly built BVH."""
+        return _InterView(self)
+
+    @inter.setter
+    def inter(self, new) -> None:
+        core = getattr(new, "core", None)
+        if not isinstance(core, RayIntersector):
+            raise TypeError("inter: expected a quadraturefields_amd.intersector.Intersector")
+        if core.mesh.faces.shape[0] != self.mesh.faces.shape[0] or core.device != self.device:
+            raise ValueError("inter: the new intersector must hold the same triangles on the same device")
+        self._handle, core._handle = core._handle, self._handle       # ours is destroyed with ``new``
+        self.set_min_separation(self.min_separation)
 
     def set_min_separation(self, min_separation: float) -> None:
         self.min_separation = max(float(min_separation or 0.0), 0.0)

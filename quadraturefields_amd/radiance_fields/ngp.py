@@ -427,6 +427,14 @@ class NGPRadianceField(_FusedFieldBase):
             network_config={"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": "None",
                             "n_neurons": hidden_size, "n_hidden_layers": 2})
 
+    def _query_rgb(self, dir, embedding, apply_act: bool = True):
+        """SH4((dir + 1) / 2) ++ embedding -> mlp_head (-> sigmoid), ngp.py:781-796.  The two-call form of ``forward``
+        (density and colour in separate launches); ``forward`` itself takes the fused kernel."""
+        d = self.direction_encoding(((dir + 1.0) / 2.0).reshape(-1, dir.shape[-1]))
+        h = torch.cat([d, embedding.reshape(-1, self.geo_feat_dim).to(d.dtype)], dim=-1)
+        rgb = self.mlp_head(h).reshape(list(embedding.shape[:-1]) + [3]).to(embedding)
+        return torch.sigmoid(rgb) if apply_act else rgb
+
     def forward(self, positions: torch.Tensor, directions: torch.Tensor = None, order: torch.Tensor = None):
         """(rgb [..,3], density [..,1]).  ngp.py:798-809.  ``order`` (int32 permutation, optional) only changes the
         order in which points are processed (cache locality), never the result."""
@@ -464,8 +472,6 @@ class NGPRadianceFieldSGNew(_FusedFieldBase):
         if use_viewdirs:
             raise NotImplementedError("the reference scripts build the SG field with use_viewdirs=False "
                                       "(train_finetune.py:374-380); only that form is implemented")
-        if discretize:
-            raise NotImplementedError("discretize=True (quantise-dequantise inside the field) is not on the hot path")
         if hidden_size != 64 or num_layers != 2 or not (1 <= num_g_lobes <= _C.QF_MAX_LOBES):
             raise NotImplementedError("the fused kernel implements hidden_size=64, num_layers=2, 1..8 lobes")
         self.num_g_lobes = num_g_lobes
@@ -479,6 +485,37 @@ class NGPRadianceFieldSGNew(_FusedFieldBase):
         return [_C.f32c(t.detach()) for t in (h.layers[0].weight, h.layers[0].bias, h.layers[1].weight,
                                               h.layers[1].bias, h.lout.weight, h.lout.bias)]
 
+    def spherical_gaussian(self, x, direction):
+        """One lobe [.., 7] = (axis 3, lambda 1, colour 3): c * exp(|lambda| (axis/|axis| . d - 1)), ngp.py:371-383.
+        ``discretize``: axis, sharpness and colour go through their uint8 codecs and back first (what a baked texture
+        would hold).  Plain tensor ops -- the per-lobe form the reference exposes; ``forward`` / ``features_to_rgb``
+        with ``discretize=False`` take the fused kernels instead."""
+        axis = x[..., :3]
+        axis = axis / torch.linalg.norm(axis, dim=-1, keepdim=True)
+        lambda_ = torch.abs(x[..., 3])
+        c = x[..., 4:]
+        if self.discretize:
+            axis = inverse_of_azimuth_and_elevantion_torch(*compress_polar_coordinates_torch(axis))
+            lambda_ = torch_invserse_of_compressed_lambda(compress_lambda_torch(lambda_))
+            c = inverse_of_compressed_colors(compress_colors(c))
+        return c * torch.exp(lambda_ * (torch.sum(axis * direction, -1) - 1))[..., None]
+
+    def spherical_gaussian_mixture(self, x, direction):
+        """Sum of the ``num_g_lobes`` lobes packed along the last axis of ``x`` [n, 7L], ngp.py:385-393."""
+        rgb = torch.zeros((x.shape[0], 3), dtype=x.dtype, device=x.device)
+        for x_ in torch.chunk(x, self.num_g_lobes, dim=-1):
+            rgb = rgb + self.spherical_gaussian(x_, direction)
+        return rgb
+
+    def _query_rgb(self, dir, embedding, apply_act: bool = True):
+        """mlp_head(embedding) -> sigmoid(diffuse + SG mixture), ngp.py:428-443 with use_viewdirs=False (``apply_act``
+        is ignored there too).  The two-call form of ``forward``."""
+        h = embedding.reshape(-1, self.geo_feat_dim)
+        out = self.mlp_head(h).reshape(list(embedding.shape[:-1]) + [self.num_g_lobes * 7 + 3]).to(embedding)
+        if self.discretize:
+            return torch.sigmoid(out[:, :3] + self.spherical_gaussian_mixture(out[:, 3:], dir))
+        return self.features_to_rgb(out, dir)
+
     def features(self, x):
         """[head(3+7L) | density], ngp.py:445-454."""
         width = 3 + 7 * self.num_g_lobes + 1
@@ -490,7 +527,13 @@ class NGPRadianceFieldSGNew(_FusedFieldBase):
         return feats
 
     def features_to_rgb(self, features, dir):
-        """sigmoid(diffuse + SG mixture), ngp.py:456-461.  features [n, >= 3+7L] (extra columns ignored)."""
+        """sigmoid(diffuse + SG mixture), ngp.py:456-461.  features [n, >= 3+7L] (extra columns ignored).
+        ``discretize``: diffuse colour and lobes take the uint8 round trip first (tensor ops, not the fused kernel --
+        the reference's scripts all run with discretize False)."""
+        if self.discretize:
+            diffuse = inverse_of_compressed_colors(compress_colors(features[:, :3]))
+            return torch.sigmoid(diffuse + self.spherical_gaussian_mixture(
+                features[:, 3:3 + 7 * self.num_g_lobes], dir.reshape(-1, 3)))
         if torch.is_grad_enabled() and features.requires_grad and not dir.requires_grad:
             return _SGMixtureFn.apply(features, dir, self.num_g_lobes)
         if torch.is_grad_enabled() and (features.requires_grad or dir.requires_grad):
@@ -514,6 +557,10 @@ class NGPRadianceFieldSGNew(_FusedFieldBase):
         if directions is None:
             raise ValueError("NGPRadianceFieldSGNew.forward needs view directions")
         lead = list(positions.shape[:-1])
+        if self.discretize:           # ngp.py:463-470 through _query_rgb: lobes quantised, diffuse colour not
+            f = self.features(positions.reshape(-1, positions.shape[-1]))
+            rgb = torch.sigmoid(f[:, :3] + self.spherical_gaussian_mixture(f[:, 3:-1], directions.reshape(-1, 3)))
+            return rgb.reshape(lead + [3]), f[:, -1:].reshape(lead + [1])
         if self._recording(positions, directions):
             if self.fused_backward and self.compute_dtype == "fp32" and not directions.requires_grad:
                 h = self.mlp_head

@@ -184,6 +184,9 @@ def gen_sg():
         d = torch.randn(500, 3, generator=g)
         d = d / d.norm(dim=-1, keepdim=True)
         out.update({f"features_{lobes}": feats, f"dirs_{lobes}": d, f"rgb_{lobes}": ns["features_to_rgb"](self, feats, d)})
+        self.discretize = True        # the quantise-dequantise variant (ngp.py:377-382,458-459), same inputs
+        out[f"rgb_disc_{lobes}"] = ns["features_to_rgb"](self, feats, d)
+        out[f"mixture_disc_{lobes}"] = self.spherical_gaussian_mixture(feats[:, 3:], d)
     save("sg_ref.npz", **out)
 
 
@@ -272,6 +275,22 @@ def gen_rays():
         K=torch.tensor([[focal, 0, w / 2.0], [0, focal, h / 2.0], [0, 0, 1]], dtype=torch.float32))
     out = ns["fetch_data"](self, 1)
     save("rays_ref.npz", c2w=c2w[1], focal=focal, width=w, height=h, origins=out["rays"].origins, viewdirs=out["rays"].viewdirs)
+    # random-ray training batches (nerf_synthetic.py:293-309,334-340) and preprocess (:262-284): seeded CPU generator,
+    # so a loader that makes the same draws in the same order reproduces them exactly
+    run(extract("datasets/nerf_synthetic.py", "preprocess", cls="SubjectLoader"), ns)
+    g = torch.Generator().manual_seed(3)
+    images = torch.randint(0, 256, (3, h, w, 4), generator=g, dtype=torch.uint8)
+    out = {"images": images, "c2w_all": c2w, "focal": focal, "seed": 123, "num_rays": 64}
+    for tag, over, noise, up, aug in (("a", True, False, 1, "white"), ("b", False, True, 2, "random"), ("c", True, True, 2, "black")):
+        self = types.SimpleNamespace(
+            num_rays=64, training=True, batch_over_images=over, upsample=up, add_ray_direction_noise=noise, images=images,
+            camtoworlds=c2w, WIDTH=w * up, HEIGHT=h * up, OPENGL_CAMERA=True, color_bkgd_aug=aug,
+            K=torch.tensor([[focal * up, 0, w * up / 2.0], [0, focal * up, h * up / 2.0], [0, 0, 1]], dtype=torch.float32))
+        torch.manual_seed(123)
+        item = ns["preprocess"](self, ns["fetch_data"](self, 2))
+        out.update({f"{tag}_origins": item["rays"].origins, f"{tag}_viewdirs": item["rays"].viewdirs,
+                    f"{tag}_pixels": item["pixels"], f"{tag}_color_bkgd": item["color_bkgd"]})
+    save("train_rays_ref.npz", **out)
 
 
 if __name__ == "__main__":

@@ -84,6 +84,11 @@ def test_oracle_sg_vs_reference():
     z = load("sg_ref.npz")
     for lobes in (3, 6):
         close(ofields.features_to_rgb(z[f"features_{lobes}"], z[f"dirs_{lobes}"], lobes), z[f"rgb_{lobes}"], 1e-7, 1e-6)
+        # discretize=True (ngp.py:377-382,458-459): same torch ops on the same machine -> identical code points
+        assert torch.equal(ofields.features_to_rgb(z[f"features_{lobes}"], z[f"dirs_{lobes}"], lobes, discretize=True),
+                           z[f"rgb_disc_{lobes}"])
+        assert torch.equal(ofields.spherical_gaussian_mixture(z[f"features_{lobes}"][:, 3:], z[f"dirs_{lobes}"], lobes,
+                                                              discretize=True), z[f"mixture_disc_{lobes}"])
 
 
 def test_oracle_texture_vs_reference():
@@ -123,6 +128,30 @@ def test_oracle_and_product_ray_generation_vs_reference():
     for fn in (om.generate_rays, synthetic.camera_rays):
         o, d = fn(z["c2w"], z["focal"], z["width"], z["height"])
         assert torch.equal(o, z["origins"]) and torch.equal(d, z["viewdirs"])
+
+
+def test_training_ray_batches_vs_reference():
+    """SubjectLoader.fetch_data + preprocess in training mode (random pixels of random images, pixel jitter,
+    background augmentation) against the reference's own bodies under the same seeded CPU generator: the loader makes
+    the same draws in the same order, so the batches are identical.  (Host tensors here are the reference's own
+    configuration -- its loaders live on the CPU, train_finetune.py:301 -- not a fallback of a device kernel.)"""
+    from quadraturefields_amd.datasets.nerf_synthetic import SubjectLoader
+    z = load("train_rays_ref.npz")
+    for tag, over, noise, up, aug in (("a", True, False, 1, "white"), ("b", False, True, 2, "random"), ("c", True, True, 2, "black")):
+        ds = SubjectLoader.from_arrays(z["images"].numpy(), z["c2w_all"].numpy(), float(z["focal"]), split="train",
+                                       num_rays=int(z["num_rays"]), batch_over_images=over, add_ray_direction_noise=noise,
+                                       upsample=up, color_bkgd_aug=aug, device="cpu")
+        assert ds.training and len(ds) == 10000000 and len(ds.images) == 3
+        torch.manual_seed(int(z["seed"]))
+        item = ds[2]
+        assert torch.equal(item["rays"].origins, z[f"{tag}_origins"])
+        assert torch.equal(item["rays"].viewdirs, z[f"{tag}_viewdirs"])
+        assert torch.equal(item["pixels"], z[f"{tag}_pixels"]) and torch.equal(item["color_bkgd"], z[f"{tag}_color_bkgd"])
+    ds.update_num_rays(7)
+    assert ds[0]["rays"].origins.shape == (7, 3)
+    # a split outside train / trainval never trains, whatever num_rays says (the scripts' "whole" loader)
+    assert not SubjectLoader.from_arrays(z["images"].numpy(), z["c2w_all"].numpy(), 13.7, split="whole", num_rays=64,
+                                         device="cpu").training
 
 
 def test_product_host_quantisers_vs_reference():
@@ -187,6 +216,15 @@ def test_hip_sg_and_texture_vs_reference(device):
     for lobes in (3, 6):
         f = NGPRadianceFieldSGNew(aabb=[-1] * 3 + [1] * 3, use_viewdirs=False, num_g_lobes=lobes, log2_hashmap_size=8).to(device)
         close(f.features_to_rgb(z[f"features_{lobes}"].to(device), z[f"dirs_{lobes}"].to(device)), z[f"rgb_{lobes}"], 2e-6, 2e-5)
+        close(f.spherical_gaussian_mixture(z[f"features_{lobes}"][:, 3:].to(device), z[f"dirs_{lobes}"].to(device)),
+              ofields.spherical_gaussian_mixture(z[f"features_{lobes}"][:, 3:], z[f"dirs_{lobes}"], lobes), 2e-6, 2e-5)
+        # discretize=True: device atan2 / acos / log may land one uint8 code away from the host's on a handful of
+        # elements (a code step moves rgb by up to ~0.05), everything else agrees to rounding
+        fd = NGPRadianceFieldSGNew(aabb=[-1] * 3 + [1] * 3, use_viewdirs=False, num_g_lobes=lobes, log2_hashmap_size=8,
+                                   discretize=True).to(device)
+        got = fd.features_to_rgb(z[f"features_{lobes}"].to(device), z[f"dirs_{lobes}"].to(device)).cpu()
+        err = (got - z[f"rgb_disc_{lobes}"]).abs().max(dim=1).values
+        assert (err > 2e-5).float().mean() < 0.02 and err.max() < 0.1, (float((err > 2e-5).float().mean()), float(err.max()))
     z = load("texture_ref.npz")
     for codec, thres in (("sigmoid", 7.5), ("linear", 5.0)):
         comp = FeatureCompression.from_arrays(z[f"{codec}_alpha"], z[f"{codec}_diffuse"], [z[f"{codec}_colors{i}"] for i in range(3)],

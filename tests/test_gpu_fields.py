@@ -107,6 +107,49 @@ def test_sg_forward_and_features_match_oracle(device, lobes):
     _close(rgb2, ofields.features_to_rgb(feats_o[:, :-1], d, lobes), 5e-6, 5e-6)
 
 
+def test_two_call_form_matches_forward(device):
+    """query_density(return_feat=True) + _query_rgb (ngp.py:781-796, 428-443) is forward in two launches."""
+    from quadraturefields_amd.radiance_fields.ngp import NGPRadianceField, NGPRadianceFieldSGNew
+    x, d = helpers.random_points(3000, seed=9)
+    xd, dd = x.to(device), d.to(device)
+    f = _make(NGPRadianceField, device)
+    rgb, den = f(xd, dd)
+    den2, emb = f.query_density(xd, return_feat=True)
+    assert torch.equal(den2, den)
+    _close(f._query_rgb(dd, emb), rgb, 5e-6, 5e-6)
+    raw = f._query_rgb(dd, emb, apply_act=False)
+    _close(torch.sigmoid(raw), rgb, 5e-6, 5e-6)
+    w = helpers.oracle_ngp_weights(f)
+    _close(f._query_rgb(dd, emb), ofields.ngp_forward(x, d, w)[0], 2e-5, 2e-5)
+    g = _make(NGPRadianceFieldSGNew, device, use_viewdirs=False, num_g_lobes=3)
+    rgb, den = g(xd, dd)
+    den2, emb = g.query_density(xd, return_feat=True)
+    _close(g._query_rgb(dd, emb), rgb, 2e-5, 2e-5)
+    # per-lobe form (ngp.py:371-393)
+    feats = g.features(xd)
+    mix = g.spherical_gaussian_mixture(feats[:, 3:-1], dd)
+    one = sum(g.spherical_gaussian(c, dd) for c in torch.chunk(feats[:, 3:-1], 3, dim=-1))
+    _close(mix, one, 1e-7, 1e-6)
+    _close(torch.sigmoid(feats[:, :3] + mix), rgb, 2e-5, 2e-5)
+
+
+def test_sg_discretized_forward(device):
+    """discretize=True (ngp.py:377-382): forward = sigmoid(diffuse + mixture of the quantise-dequantised lobes); the
+    diffuse colour is only quantised by features_to_rgb (ngp.py:458-459)."""
+    from quadraturefields_amd.radiance_fields.ngp import NGPRadianceFieldSGNew
+    f = _make(NGPRadianceFieldSGNew, device, use_viewdirs=False, num_g_lobes=3, discretize=True)
+    x, d = helpers.random_points(2000, seed=5)
+    w = helpers.oracle_ngp_weights(f)
+    feats_o = ofields.sg_features(x, w)
+    want = torch.sigmoid(feats_o[:, :3] + ofields.spherical_gaussian_mixture(feats_o[:, 3:-1], d, 3, discretize=True))
+    rgb, den = f(x.to(device), d.to(device))
+    _close(den, feats_o[:, -1:], 1e-7, 5e-5)
+    err = (rgb.cpu() - want).abs().max(dim=1).values       # a code point may flip where a value sits on a step
+    assert (err > 5e-5).float().mean() < 0.02 and err.max() < 0.1
+    plain = _make(NGPRadianceFieldSGNew, device, use_viewdirs=False, num_g_lobes=3)
+    assert (plain(x.to(device), d.to(device))[0] - rgb).abs().max() > 1e-3      # the codecs do change the colour
+
+
 def test_deform_field_matches_oracle(device):
     from quadraturefields_amd import synthetic
     from quadraturefields_amd.field import Field

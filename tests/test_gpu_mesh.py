@@ -64,6 +64,44 @@ def test_find_intersections_shape(device):
     assert np.array_equal(ints.reshape(100, 6), tri_o)
 
 
+def test_native_module_shape(device):
+    """``intersector.Intersector(vertices[faces].flatten(), K, 0)`` / find_intersections / update_vertices, and the
+    finetune loop's replacement of ``rayintersector.inter`` (mesh_utils.py:77-96, train_finetune.py:716-718)."""
+    from quadraturefields_amd import intersector
+    from quadraturefields_amd.mesh_utils import RayIntersector
+    mesh = _scene(2, 3)
+    soup = mesh.vertices[mesh.faces].flatten()
+    o, d = _rays(300, seed=5)
+    rays = np.concatenate([o, d], 1).flatten()
+    it = intersector.Intersector(soup, 8, 0)
+    ints = np.array(it.find_intersections(rays))
+    assert ints.shape == (300 * 8,)
+    tri_o, _, _ = om.BruteForceIntersector(mesh.vertices, mesh.faces, min_separation=0.0).hits(o, d, 8)
+    assert np.array_equal(ints.reshape(300, 8), tri_o)
+    # the adapter's use of it (mesh_utils.py:91-96): hit slots -> (triangle, ray) pairs
+    idx = np.where(ints > -1)[0]
+    assert np.array_equal(idx // 8, np.repeat(np.arange(300), (tri_o >= 0).sum(1)))
+    # new positions, same triangles: in place ...
+    moved = mesh.vertices * np.array([1.0, 0.9, 1.1]) + 0.01
+    soup2 = moved[mesh.faces].flatten()
+    it.update_vertices(soup2)
+    tri_m, _, _ = om.BruteForceIntersector(moved, mesh.faces, min_separation=0.0).hits(o, d, 8)
+    assert np.array_equal(np.array(it.find_intersections(rays)).reshape(300, 8), tri_m)
+    # ... or by replacing the adapter's object, as the finetune loop does
+    ri = RayIntersector(mesh, max_hits=8, min_separation=0.0)
+    assert np.array_equal(np.array(ri.inter.find_intersections(rays)).reshape(300, 8), tri_o)
+    ri.inter = intersector.Intersector(soup2, 8, 0)
+    assert np.array_equal(np.array(ri.inter.find_intersections(rays)).reshape(300, 8), tri_m)
+    ri.inter.update_vertices(soup)
+    assert np.array_equal(ri.find_intersections(rays).reshape(300, 8), tri_o)
+    with pytest.raises(ValueError):
+        it.update_vertices(soup[:-9])
+    with pytest.raises(ValueError):
+        ri.inter = intersector.Intersector(soup[:-9], 8, 0)
+    with pytest.raises(TypeError):
+        ri.inter = object()
+
+
 def test_sampling_raytrace_matches_oracle(device):
     from quadraturefields_amd.mesh_utils import MeshIntersection
     mesh = _scene()

@@ -50,7 +50,7 @@ def test_loader_item_renders_like_the_frame_renderer(device):
     images[..., :3] = 128
     c2w = synthetic.orbit_cameras(2, seed=4).numpy()
     ds = SubjectLoader.from_arrays(images, c2w, synthetic.lego_focal(800) * w / 800.0, mesh_intersect=mi, upsample=2)
-    assert len(ds) == 2 and (ds.WIDTH, ds.HEIGHT) == (80, 80)
+    assert len(ds.images) == 2 and (ds.WIDTH, ds.HEIGHT) == (80, 80) and not ds.training
     item = ds[1]
     assert item["pixels"].shape == (h * w, 3) and item["rays"].origins.shape == (80 * 80, 3)
     out = utils.render_image_finetune_with_occgrid(field, None, None, item["rays"], item["data"], render_step_size=5e-3,
@@ -63,6 +63,36 @@ def test_loader_item_renders_like_the_frame_renderer(device):
     assert (rgb.cpu() - rgb_o).abs().max().item() <= 2e-4
     img = area_downsample(rgb.reshape(80, 80, 3), 2)
     assert img.shape == (40, 40, 3)
+
+
+def test_training_batches_of_the_loader(device):
+    """num_rays set on a training split (train_finetune.py:296-305): random pixels of random images, intersected on
+    the device through the general BVH route; the batch's samples equal the oracle's for the same rays."""
+    from quadraturefields_amd import synthetic
+    from quadraturefields_amd.datasets.nerf_synthetic import SubjectLoader
+    from quadraturefields_amd.mesh_utils import MeshIntersection
+    mesh = synthetic.shell_mesh(n_shells=3, subdivisions=3)
+    mi = MeshIntersection(mesh, simplify_mesh=False, scale=1.0, num_intersections=25)
+    w = h = 40
+    g = torch.Generator().manual_seed(1)
+    images = torch.randint(0, 256, (3, h, w, 4), generator=g, dtype=torch.uint8).numpy()
+    c2w = synthetic.orbit_cameras(3, seed=4).numpy()
+    ds = SubjectLoader.from_arrays(images, c2w, synthetic.lego_focal(800) * w / 800.0, split="train", num_rays=4096,
+                                   mesh_intersect=mi, upsample=2, color_bkgd_aug="random", device=device)
+    assert ds.training and ds.images.is_cuda
+    item = ds[0]
+    o, d = item["rays"].origins, item["rays"].viewdirs
+    assert o.shape == (4096, 3) and item["pixels"].shape == (4096, 3) and "order" not in item
+    assert torch.allclose(d.norm(dim=-1), torch.ones(4096, device=device), atol=1e-6)
+    # every origin is one of the three camera centres
+    centres = torch.from_numpy(c2w[:, :3, 3]).to(device)
+    assert bool(((o[:, None, :] - centres[None]).abs().sum(-1) == 0).any(dim=1).all())
+    xyzs, dirs, index_ray, ts, index_tri, origins = item["data"]
+    want = om.sampling_raytrace_numpy(om.BruteForceIntersector(mesh.vertices, mesh.faces), d.cpu().numpy(), o.cpu().numpy(), 25)
+    assert np.array_equal(index_ray.cpu().numpy(), want[2]) and np.array_equal(index_tri.cpu().numpy(), want[4])
+    assert np.allclose(ts.cpu().numpy(), want[3], rtol=0, atol=2e-6)
+    # pixels = rgb * a + bkgd * (1 - a) with one random background colour for the batch
+    assert item["color_bkgd"].shape == (3,) and float(item["pixels"].min()) >= 0.0 and float(item["pixels"].max()) <= 1.0
 
 
 def test_scatter_max_and_pruning(device):
