@@ -126,9 +126,14 @@ class Stages:
         else:
             inverse = None
             rgbs, sigmas = self._timed("field", lambda: self.field(xyz, dirs, order=order if self.coherent else None), record)
-        out = self._timed("composite", lambda: utils.derive_properties(
-            rgbs, sigmas.reshape(-1), ts, STEP, None, index_ray, bg_color="white", N=n_rays, sample_index=inverse), record)
-        rgb, alpha, _, depth, _ = out
+        if layout is not None:      # ... and compositing streams the field's outputs in that same order
+            frame = ri.last_frame
+            for t in (frame.depth_c, frame.hit_count, frame.tile_base):
+                t.record_stream(here)
+            rgb, alpha, depth, _ = self._timed("composite", lambda: utils.composite_frame(rgbs, sigmas, frame, STEP), record)
+        else:
+            rgb, alpha, _, depth, _ = self._timed("composite", lambda: utils.derive_properties(
+                rgbs, sigmas.reshape(-1), ts, STEP, None, index_ray, bg_color="white", N=n_rays), record)
         if ri.rule_violated():          # some ray had hits closer than the re-origin distance: this frame again, exactly
             self.rule_redone = getattr(self, "rule_redone", 0) + 1
             return self.frame(*frame_in, record)

@@ -431,6 +431,8 @@ int qf_frame_offsets(const int32_t *hit_count, int64_t n_rays, int32_t max_hits,
  * qf_field_forward can stream them (order = NULL) and write its outputs sequentially, and
  * qf_derive_properties picks colour and density back up through sample_index = inverse.  Measured: the indirection
  * through `order` costs the field kernel 10 % (two scattered sector reads and a scattered write per point).
+ * depth_c (with inverse; NULL to skip): the depths in that order too -- with it qf_composite_tiles composites the
+ * frame straight from the field kernel's outputs, and neither the inverse map nor index_ray is read again.
  * xyz / dirs / origins may then be NULL (all three) for a caller that only renders: the ray-major copies of the
  * positions are skipped; index_ray, depth and index_tri are always written.
  * keep_mask / raw_count (both or neither; from qf_bvh_repair_overflow): the stored list of ray r has raw_count[r]
@@ -445,8 +447,8 @@ int qf_pack_samples(const float *rays_o, const float *rays_d, int64_t n_rays, in
                     const int32_t *hit_tri, const float *hit_t, const int32_t *hit_count,
                     const int64_t *ray_offset, float *xyz, float *dirs, int64_t *index_ray,
                     float *depth, int64_t *index_tri, float *origins, const int32_t *inverse,
-                    float *xyz_c, float *dirs_c, const uint64_t *keep_mask, const int32_t *raw_count,
-                    float min_separation, int32_t *close_flag, void *stream);
+                    float *xyz_c, float *dirs_c, float *depth_c /* [n] or NULL */, const uint64_t *keep_mask,
+                    const int32_t *raw_count, float min_separation, int32_t *close_flag, void *stream);
 
 /* Spatially coherent PROCESSING order for qf_field_forward when the rays are a row-major width x height image:
  * (8x8 pixel tile, hit rank, pixel in tile).  Two steps around one exclusive scan the caller does:
@@ -461,6 +463,19 @@ int qf_coherent_order(const int32_t *hit_count, const int64_t *ray_offset, const
  * (a render-only frame streams the coherent copies and only needs the inverse).                  */
 int qf_coherent_layout(const int32_t *hit_count, const int64_t *ray_offset, const int64_t *tile_base,
                        int32_t width, int32_t height, int32_t *order, int32_t *inverse, void *stream);
+
+/* derive_properties (utils.py:863-898; the eval render of train_finetune.py:597-607) on a frame whose per-sample
+ * colours, densities and depths are stored in the coherent order above (rgb_c / sigma_c = qf_field_forward's outputs
+ * on xyz_c / dirs_c, depth_c from qf_pack_samples): one wave per 8x8 tile, every load a contiguous run, pixels
+ * without samples get their background from the same launch.  hit_count [w*h] (pixel r has min(hit_count[r],
+ * max_hits) samples) and tile_base as qf_frame_offsets / qf_coherent_layout took them; constant step delta_const
+ * (find_deltas, mesh_utils.py:225-231).  Same values as qf_derive_properties on the ray-major arrays, bit for bit
+ * (same per-ray operation order).  weights_c: the weights in the coherent order, or NULL.             */
+int qf_composite_tiles(const float *rgb_c /* [n,3] */, const float *sigma_c /* [n] */, const float *depth_c /* [n] */,
+                       float delta_const, const int32_t *hit_count /* [w*h] */, int32_t max_hits,
+                       const int64_t *tile_base, int32_t width, int32_t height, int32_t bg_mode,
+                       const float *bkgd /* [3] or NULL */, float *out_rgb, float *out_alpha, float *out_depth,
+                       float *weights_c, void *stream);
 
 /* Stable per-ray re-sort by depth after deformation (sampling_indexing, mesh_utils.py:394-403):
  * perm[i] = source index of the sample that lands at i.  index_ray must be grouped by ray.   */

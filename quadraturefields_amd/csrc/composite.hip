@@ -28,6 +28,41 @@ __global__ void fill_background_kernel(int64_t n_rays, float bg, float *rgb, flo
     }
 }
 
+// The per-ray arithmetic of derive_properties, with every rounding spelled out (no compiler-chosen contraction), so
+// that the chunked kernel, its long-ray tail and the per-ray kernel give the same bits whatever the optimiser does
+// around them: tau = sigma * delta; w = exp(-cum) * (1 - exp(-tau)); cum += tau; sums accumulate with one fma each.
+struct RayAccum {
+    float cum = 0.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f, cd = 0.0f, ca = 0.0f;
+};
+
+__device__ __forceinline__ float sample_tau(float sigma, float delta) { return __fmul_rn(sigma, delta); }
+__device__ __forceinline__ float sample_alpha(float tau) { return __fsub_rn(1.0f, expf(-tau)); }
+
+__device__ __forceinline__ float composite_step(RayAccum &a, float tau, float alpha, float r, float g, float b, float dep)
+{
+    const float w = __fmul_rn(expf(-a.cum), alpha);
+    a.cum = __fadd_rn(a.cum, tau);
+    a.cr = __fmaf_rn(w, r, a.cr);
+    a.cg = __fmaf_rn(w, g, a.cg);
+    a.cb = __fmaf_rn(w, b, a.cb);
+    a.cd = __fmaf_rn(w, dep, a.cd);
+    a.ca = __fadd_rn(a.ca, w);
+    return w;
+}
+
+__device__ __forceinline__ void composite_blend(const RayAccum &a, int bg_mode, const float *bkgd, float out[3])
+{
+    const float c[3] = {a.cr, a.cg, a.cb};
+    const float rest = __fsub_rn(1.0f, a.ca);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        if (bg_mode == QF_BG_WHITE) out[i] = __fmaf_rn(a.ca, c[i], rest);      // (1 - a) + a * sum(w c): the double-alpha quirk (B-1)
+        else if (bg_mode == QF_BG_BLACK) out[i] = __fmul_rn(a.ca, c[i]);
+        else if (bg_mode == QF_BG_NONE) out[i] = c[i];     // the plain sums (nerfacc's accumulate_along_rays): no blend, no quirk
+        else out[i] = __fmaf_rn(a.ca, c[i], __fmul_rn(rest, bkgd[i]));
+    }
+}
+
 // derive_properties: a block owns DP_CHUNK consecutive samples.  It stages them (plus a halo, so that rays starting
 // near the end of the chunk finish without leaving LDS) with coalesced loads; the lane that sits on a ray's first
 // sample then integrates the whole ray sequentially out of LDS -- same summation order as a plain per-ray loop, so
@@ -64,9 +99,9 @@ __global__ __launch_bounds__(DP_THREADS) void derive_properties_kernel(
         for (int k = threadIdx.x; k < staged; k += DP_THREADS) {
             // sample_index: colour and density live at another position (the field kernel's processing order)
             const int64_t src = sample_index ? (int64_t)sample_index[b0 + k] : b0 + k;
-            const float tau = sigma[src] * (deltas ? deltas[b0 + k] : delta_const);
+            const float tau = sample_tau(sigma[src], deltas ? deltas[b0 + k] : delta_const);
             s_tau[k] = tau;
-            s_alpha[k] = 1.0f - expf(-tau);
+            s_alpha[k] = sample_alpha(tau);
             s_dep[k] = depth_s[b0 + k];
             s_ray[k + 1] = index_ray[b0 + k];
             s_mine[k] = 0;
@@ -86,51 +121,23 @@ __global__ __launch_bounds__(DP_THREADS) void derive_properties_kernel(
         for (int h = threadIdx.x; h < n_heads; h += DP_THREADS) {      // consecutive lanes = different rays: no idle lanes
             const int k = s_heads[h];
             const int64_t ray = s_ray[k + 1];
-            float cum = 0.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f, cd = 0.0f, ca = 0.0f;
+            RayAccum acc;
             int j = k;
             for (; j < staged && s_ray[j + 1] == ray; ++j) {
-                const float w = expf(-cum) * s_alpha[j];
-                cum += s_tau[j];
-                s_w[j] = w;
+                s_w[j] = composite_step(acc, s_tau[j], s_alpha[j], s_rgb[j * 3 + 0], s_rgb[j * 3 + 1], s_rgb[j * 3 + 2], s_dep[j]);
                 s_mine[j] = 1;
-                cr += w * s_rgb[j * 3 + 0];
-                cg += w * s_rgb[j * 3 + 1];
-                cb += w * s_rgb[j * 3 + 2];
-                cd += w * s_dep[j];
-                ca += w;
             }
             if (j == staged) {                       // the ray runs past the staged window
                 for (int64_t g = b0 + staged; g < n && index_ray[g] == ray; ++g) {
                     const int64_t src = sample_index ? (int64_t)sample_index[g] : g;
-                    const float tau = sigma[src] * (deltas ? deltas[g] : delta_const);
-                    const float w = expf(-cum) * (1.0f - expf(-tau));
-                    cum += tau;
-                    weights[g] = w;
-                    cr += w * rgb_s[src * 3 + 0];
-                    cg += w * rgb_s[src * 3 + 1];
-                    cb += w * rgb_s[src * 3 + 2];
-                    cd += w * depth_s[g];
-                    ca += w;
+                    const float tau = sample_tau(sigma[src], deltas ? deltas[g] : delta_const);
+                    weights[g] = composite_step(acc, tau, sample_alpha(tau), rgb_s[src * 3 + 0], rgb_s[src * 3 + 1],
+                                                rgb_s[src * 3 + 2], depth_s[g]);
                 }
             }
-            float r, g, b;
-            if (bg_mode == QF_BG_WHITE) {          // (1 - a) + a * sum(w c): the double-alpha quirk (B-1)
-                r = (1.0f - ca) + ca * cr;
-                g = (1.0f - ca) + ca * cg;
-                b = (1.0f - ca) + ca * cb;
-            } else if (bg_mode == QF_BG_BLACK) {
-                r = ca * cr;
-                g = ca * cg;
-                b = ca * cb;
-            } else if (bg_mode == QF_BG_NONE) {    // the plain sums (nerfacc's accumulate_along_rays): no blend, no quirk
-                r = cr;
-                g = cg;
-                b = cb;
-            } else {
-                r = ca * cr + (1.0f - ca) * bkgd[0];
-                g = ca * cg + (1.0f - ca) * bkgd[1];
-                b = ca * cb + (1.0f - ca) * bkgd[2];
-            }
+            float px[3];
+            composite_blend(acc, bg_mode, bkgd, px);
+            const float r = px[0], g = px[1], b = px[2], ca = acc.ca, cd = acc.cd;
             if (ray >= 0 && ray < n_rays) {         // a ray id outside the image never touches memory (weights are still written)
                 out_rgb[ray * 3 + 0] = r;
                 out_rgb[ray * 3 + 1] = g;
@@ -438,7 +445,75 @@ __global__ __launch_bounds__(64) void coherent_order_kernel(const int32_t *hit_c
     }
 }
 
+// derive_properties on a frame whose colours / densities / depths are in the coherent order above (what the field
+// kernel streams): one wave per 8x8 tile, lane = pixel, step k composites the rank-k samples of the tile's pixels --
+// the same ballots that defined the order give every lane its position, so all loads are contiguous runs and neither
+// the inverse map nor index_ray is read.  The per-ray arithmetic is derive_properties_kernel's (composite_step /
+// composite_blend, rank order = depth order), bit for bit.  Pixels without samples write their own background: one
+// launch instead of fill + chunked kernel.  The loads of step k+1 are issued before the arithmetic of step k.
+__global__ __launch_bounds__(64) void composite_tiles_kernel(
+    const float *__restrict__ rgb_c, const float *__restrict__ sigma_c, const float *__restrict__ depth_c,
+    float delta_const, const int32_t *__restrict__ hit_count, int max_hits, const int64_t *__restrict__ tile_base, int w,
+    int h, int tiles_x, int bg_mode, const float *__restrict__ bkgd, float *__restrict__ out_rgb, float *__restrict__ out_alpha,
+    float *__restrict__ out_depth, float *__restrict__ weights_c)
+{
+    const int tile = blockIdx.x, lane = threadIdx.x;
+    int64_t ray = 0;
+    int cnt = 0;
+    const int inside = tile_lane_ray(tile, lane, w, h, tiles_x, &ray);
+    if (inside) cnt = hit_count[ray] < max_hits ? hit_count[ray] : max_hits;
+    int64_t base = tile_base[tile];
+    const unsigned long long below = (1ull << lane) - 1ull;
+    RayAccum acc;
+    unsigned long long mask = __ballot(cnt > 0);
+    int64_t pos = base + __popcll(mask & below);
+    float sg = 0.0f, r = 0.0f, g = 0.0f, b = 0.0f, dep = 0.0f;
+    if (cnt > 0) { sg = sigma_c[pos]; r = rgb_c[pos * 3]; g = rgb_c[pos * 3 + 1]; b = rgb_c[pos * 3 + 2]; dep = depth_c[pos]; }
+    for (int k = 0; mask != 0ull; ++k) {              // wave-uniform
+        base += __popcll(mask);
+        const unsigned long long next = __ballot(cnt > k + 1);
+        const int64_t npos = base + __popcll(next & below);
+        float nsg = 0.0f, nr = 0.0f, ng = 0.0f, nb = 0.0f, ndep = 0.0f;
+        if (cnt > k + 1) { nsg = sigma_c[npos]; nr = rgb_c[npos * 3]; ng = rgb_c[npos * 3 + 1]; nb = rgb_c[npos * 3 + 2]; ndep = depth_c[npos]; }
+        if (cnt > k) {
+            const float tau = sample_tau(sg, delta_const);
+            const float wt = composite_step(acc, tau, sample_alpha(tau), r, g, b, dep);
+            if (weights_c) weights_c[pos] = wt;
+        }
+        mask = next; pos = npos; sg = nsg; r = nr; g = ng; b = nb; dep = ndep;
+    }
+    if (!inside) return;
+    float px[3];
+    if (cnt > 0) {
+        composite_blend(acc, bg_mode, bkgd, px);
+    } else {                                           // fill_background_kernel's values
+        px[0] = px[1] = px[2] = (bg_mode == QF_BG_BLACK || bg_mode == QF_BG_NONE) ? 0.0f : 1.0f;
+    }
+    out_rgb[ray * 3 + 0] = px[0];
+    out_rgb[ray * 3 + 1] = px[1];
+    out_rgb[ray * 3 + 2] = px[2];
+    out_alpha[ray] = acc.ca;
+    out_depth[ray] = acc.cd;
+}
+
 }  // namespace
+
+extern "C" int qf_composite_tiles(const float *rgb_c, const float *sigma_c, const float *depth_c, float delta_const,
+                                  const int32_t *hit_count, int32_t max_hits, const int64_t *tile_base, int32_t width,
+                                  int32_t height, int32_t bg_mode, const float *bkgd, float *out_rgb, float *out_alpha,
+                                  float *out_depth, float *weights_c, void *stream)
+{
+    if (width < 1 || height < 1 || max_hits < 1 || bg_mode < 0 || bg_mode > 3) return QF_ERR_INVALID_ARGUMENT;
+    if (!rgb_c || !sigma_c || !depth_c || !hit_count || !tile_base || !out_rgb || !out_alpha || !out_depth)
+        return QF_ERR_INVALID_ARGUMENT;
+    if (bg_mode == QF_BG_CUSTOM && !bkgd) return QF_ERR_INVALID_ARGUMENT;
+    const int tiles_x = (width + 7) / 8, tiles_y = (height + 7) / 8;
+    hipLaunchKernelGGL(composite_tiles_kernel, dim3(tiles_x * tiles_y), dim3(64), 0, qf_stream(stream), rgb_c, sigma_c,
+                       depth_c, delta_const, hit_count, (int)max_hits, tile_base, (int)width, (int)height, tiles_x, (int)bg_mode, bkgd,
+                       out_rgb, out_alpha, out_depth, weights_c);
+    QF_LAUNCH_CHECK();
+    return QF_OK;
+}
 
 extern "C" int qf_tile_totals(const int32_t *hit_count, int32_t width, int32_t height, int64_t *tile_total, void *stream)
 {

@@ -767,8 +767,8 @@ __global__ __launch_bounds__(kPackRays) void pack_samples_kernel(
     const int64_t *__restrict__ ray_offset, float *__restrict__ xyz, float *__restrict__ dirs,
     int64_t *__restrict__ index_ray, float *__restrict__ depth, int64_t *__restrict__ index_tri,
     float *__restrict__ origins, const int32_t *__restrict__ inverse, float *__restrict__ xyz_c,
-    float *__restrict__ dirs_c, const uint64_t *__restrict__ keep_mask, const int32_t *__restrict__ raw_count,
-    float min_sep, int32_t *__restrict__ close_flag)
+    float *__restrict__ dirs_c, float *__restrict__ depth_c, const uint64_t *__restrict__ keep_mask,
+    const int32_t *__restrict__ raw_count, float min_sep, int32_t *__restrict__ close_flag)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int K = max_hits, Kp = max_hits | 1;            // odd row stride: conflict-free column access
@@ -882,6 +882,7 @@ __global__ __launch_bounds__(kPackRays) void pack_samples_kernel(
             dirs_c[c * 3 + 0] = dx / nrm;
             dirs_c[c * 3 + 1] = dy / nrm;
             dirs_c[c * 3 + 2] = dz / nrm;
+            if (depth_c) depth_c[c] = (float)dep;
         }
     }
 }
@@ -1356,8 +1357,8 @@ extern "C" int qf_pack_samples(const float *rays_o, const float *rays_d, int64_t
                                const int32_t *hit_tri, const float *hit_t, const int32_t *hit_count,
                                const int64_t *ray_offset, float *xyz, float *dirs, int64_t *index_ray, float *depth,
                                int64_t *index_tri, float *origins, const int32_t *inverse, float *xyz_c, float *dirs_c,
-                               const uint64_t *keep_mask, const int32_t *raw_count, float min_separation,
-                               int32_t *close_flag, void *stream)
+                               float *depth_c, const uint64_t *keep_mask, const int32_t *raw_count,
+                               float min_separation, int32_t *close_flag, void *stream)
 {
     if ((keep_mask == nullptr) != (raw_count == nullptr)) return QF_ERR_INVALID_ARGUMENT;
     if (n_rays < 0 || max_hits < 1 || max_hits > kMaxHits) return QF_ERR_INVALID_ARGUMENT;
@@ -1373,7 +1374,7 @@ extern "C" int qf_pack_samples(const float *rays_o, const float *rays_d, int64_t
     if (blocks > 0x7fffffff) return QF_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(pack_samples_kernel, dim3((unsigned)blocks), dim3(kPackRays), lds, qf_stream(stream), rays_o, rays_d,
                        n_rays, (int)max_hits, hit_tri, hit_t, hit_count, ray_offset, xyz, dirs, index_ray, depth, index_tri,
-                       origins, inverse, xyz_c, dirs_c, keep_mask, raw_count, min_separation, close_flag);
+                       origins, inverse, xyz_c, dirs_c, depth_c, keep_mask, raw_count, min_separation, close_flag);
     QF_LAUNCH_CHECK();
     return QF_OK;
 }

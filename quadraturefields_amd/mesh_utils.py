@@ -8,6 +8,7 @@ one traversal launch that emits every ray's hits already ordered front to back, 
 re-sort after deformation.
 """
 import ctypes
+from types import SimpleNamespace
 from typing import Optional
 
 import numpy as np
@@ -110,6 +111,7 @@ class RayIntersector:
         self._wide_scratch = {}
         self._scratch = {}               # per-ray-count frame scratch, see _frame_scratch
         self.last_layout = None          # (inverse, xyz, dirs) of the most recent image-shaped pack, in the coherent order
+        self.last_frame = None           # what utils.composite_frame needs of that pack (depths in the coherent order, ...)
         self._handle = ctypes.c_void_p()
         tri = np.ascontiguousarray(mesh.vertices.astype(np.float32)[mesh.faces].reshape(-1, 9))
         with torch.cuda.device(self.device):
@@ -384,12 +386,15 @@ class RayIntersector:
         index_ray = torch.empty((cap,), dtype=torch.int64, device=dev)
         index_tri = torch.empty((cap,), dtype=torch.int64, device=dev)
         depth = torch.empty((cap,), dtype=torch.float32, device=dev)
-        order = inverse = xyz_c = dirs_c = layout = None          # (from here on ``layout`` is the result tuple)
+        order = inverse = xyz_c = dirs_c = depth_c = layout = frame = None    # (from here on ``layout`` is the result tuple)
         if image:                             # the coherent order, its inverse, and streamed copies
             order, inverse = self.coherent_layout(hit_count, buf, cap, width, tile_base, want_order=not lean)
             xyz_c = torch.empty((cap, 3), dtype=torch.float32, device=dev)
             dirs_c = torch.empty((cap, 3), dtype=torch.float32, device=dev)
+            depth_c = torch.empty((cap,), dtype=torch.float32, device=dev)
             layout = (inverse, xyz_c, dirs_c)
+            frame = SimpleNamespace(depth_c=depth_c, hit_count=hit_count, max_hits=int(k), tile_base=tile_base,
+                                    width=int(width), height=n // int(width))
         keep = getattr(hit_count, "_qf_keep", None) or (None, None)      # from _repair (re-origin rule decided up front)
         optimistic = keep[0] is None and self.min_separation > 0
         flag = None
@@ -399,14 +404,16 @@ class RayIntersector:
         _C.check(_C.lib().qf_pack_samples(_C.ptr(o), _C.ptr(d), n, k, _C.ptr(hit_tri), _C.ptr(hit_t),
                                           _C.ptr(hit_count), _C.ptr(buf), _C.ptr(xyz), _C.ptr(dirs),
                                           _C.ptr(index_ray), _C.ptr(depth), _C.ptr(index_tri), _C.ptr(org),
-                                          _C.ptr(inverse), _C.ptr(xyz_c), _C.ptr(dirs_c), _C.ptr(keep[0]),
-                                          _C.ptr(keep[1]), float(self.min_separation) if optimistic else 0.0, flag,
-                                          _C.stream()), "qf_pack_samples")
+                                          _C.ptr(inverse), _C.ptr(xyz_c), _C.ptr(dirs_c), _C.ptr(depth_c),
+                                          _C.ptr(keep[0]), _C.ptr(keep[1]),
+                                          float(self.min_separation) if optimistic else 0.0, flag, _C.stream()),
+                 "qf_pack_samples")
         if optimistic:
             ev_flag.record()
         return (o, d, k, width, (lean, want_layout), host, (ev, ev_flag if optimistic else None),
                 [xyz, dirs, index_ray, depth, index_tri, org], order, layout,
-                (hit_tri, hit_t, hit_count, keep))    # the lists stay referenced until the kernels reading them ran
+                (hit_tri, hit_t, hit_count, keep),    # the lists stay referenced until the kernels reading them ran
+                frame)
 
     @_on_device
     def pack_hits_end(self, pending, defer_rule_check=False):
@@ -416,7 +423,7 @@ class RayIntersector:
         the rule decided per ray -- the caller always gets exact samples.  ``defer_rule_check=True`` returns at once
         instead; the caller launches its field / compositing kernels and THEN asks ``rule_violated()`` (by which time
         the verdict is long there); on True it must discard its results and sample again."""
-        o, d, k, width, lean, host, (ev, ev_flag), arrays, order, layout, _lists = pending
+        o, d, k, width, lean, host, (ev, ev_flag), arrays, order, layout, _lists, frame = pending
         ev.synchronize()
         total, ovf = int(host[0]), int(host[1])
         self._rule_pending = None
@@ -435,11 +442,13 @@ class RayIntersector:
                     self.raster_wide = wide    # from the next frame on: wide candidate lists + K-nearest selection
                 else:
                     self.raster_overflowed()   # even the wide lists overflow: the camera-coherent pass is wasted
-        self.last_layout = None
+        self.last_layout = self.last_frame = None
         if total == 0:
             return None, None
         if layout is not None:      # (inverse, xyz, dirs) in the coherent order: see coherent_layout
             self.last_layout = tuple(t[:total] for t in layout)
+            frame.depth_c = frame.depth_c[:total]
+            self.last_frame = frame
         return [None if t is None else t[:total] for t in arrays], (order[:total] if order is not None else None)
 
     def rule_violated(self) -> bool:
@@ -466,7 +475,7 @@ class RayIntersector:
     def _repack_exact(self, pending):
         """The optimistic pack of ``pending`` failed its check: decide the rule per ray (keep masks over the same
         lists) and pack again."""
-        o, d, k, width, (lean, want_layout), _host, _evs, _arrays, _order, _layout, (hit_tri, hit_t, hit_count, _keep) = pending
+        o, d, k, width, (lean, want_layout), _host, _evs, _arrays, _order, _layout, (hit_tri, hit_t, hit_count, _keep), _frame = pending
         self._rule_violation()
         self._repair(o, d, k, width, hit_tri, hit_t, hit_count, with_mask=True)
         return self.pack_hits_end(self.pack_hits_begin(o, d, k, hit_tri, hit_t, hit_count, None, width, lean, want_layout))

@@ -57,9 +57,9 @@ class FrameRenderer:
             # identity, and the field can stream the copies laid out in its processing order (same bits).
             inverse, xyz_c, dirs_c = ri.last_layout
             rgbs, sigmas = self.radiance_field(xyz_c, dirs_c)
-            rgb, alpha, _, depth, _ = utils.derive_properties(
-                rgbs, sigmas.reshape(-1), data[3], self.render_step_size, None, data[2], render_bkgd=render_bkgd,
-                bg_color=self.bg_color, N=n_rays, sample_index=inverse)
+            # ... and compositing streams the field's outputs in that same order (qf_composite_tiles)
+            rgb, alpha, depth, _ = utils.composite_frame(rgbs, sigmas, ri.last_frame, self.render_step_size,
+                                                         render_bkgd=render_bkgd, bg_color=self.bg_color)
             if ri.rule_violated():      # rare (near-coincident faces): these samples are not the reference's; again, exactly
                 return self.render(origins, viewdirs, image_width, scaling, render_bkgd, camera)
             return rgb, alpha, depth, data[2].shape[0]

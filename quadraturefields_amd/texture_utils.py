@@ -106,6 +106,43 @@ class FeatureCompression:
             _write_png(path + "color_{}.png".format(i), self.sg_colors[i].cpu().numpy())
             _write_png(path + "lambda_axis_{}.png".format(i), self.lambdas[i].cpu().numpy())
 
+    def compress_features_and_save(self, features, path):
+        """[N, N, 3+7L+1] float features -> the PNG set, without touching the maps (texture_utils.py:108-117)."""
+        n = features.shape[0]
+        data = self.compress(features.reshape((n * n, -1)))
+        for i in range(self.num_lobes):
+            _write_png(path + "color_{}.png".format(i), data["colors"][i].reshape((n, n, 3)).cpu().numpy())
+            _write_png(path + "lambda_axis_{}.png".format(i), data["lambdas"][i].reshape((n, n, 3)).cpu().numpy())
+        _write_png(path + "alpha.png", data["alpha"].cpu().numpy().reshape((n, n)))
+        _write_png(path + "diffuse.png", data["diffuse"].reshape((n, n, 3)).cpu().numpy())
+
+    @staticmethod
+    def sigma_to_alpha(sigma):
+        return 1 - np.exp(-sigma * 0.005)
+
+    # ------------------------------------------------------------------ shading of fetched features (:126-147)
+    def spherical_gaussian(self, x, direction):
+        axis = x[..., :3]
+        axis = axis / torch.linalg.norm(axis, dim=-1, keepdim=True)
+        return x[..., 4:] * torch.exp(torch.abs(x[..., 3]) * (torch.sum(axis * direction, -1) - 1))[..., None]
+
+    def spherical_gaussian_mixture(self, x, direction):
+        rgb = torch.zeros((x.shape[0], 3), dtype=x.dtype, device=x.device)
+        for x_ in torch.chunk(x, self.num_lobes, dim=-1):
+            rgb = rgb + self.spherical_gaussian(x_, direction)
+        return rgb
+
+    def features_to_rgb(self, features, dir):
+        """sigmoid(diffuse + SG mixture) of ``get_features_from_texture_map`` rows (extra columns ignored): the
+        two-call form of ``shade``, one HIP launch (``qf_sg_features_to_rgb``)."""
+        features = _C.f32c(features)
+        dir = _C.f32c(dir.reshape(-1, 3))
+        n = features.shape[0]
+        rgb = torch.empty((n, 3), dtype=torch.float32, device=features.device)
+        _C.check(_C.lib().qf_sg_features_to_rgb(_C.ptr(features), features.shape[1], _C.ptr(dir), n, self.num_lobes,
+                                                _C.ptr(rgb), _C.stream()), "qf_sg_features_to_rgb")
+        return rgb
+
     # ------------------------------------------------------------------ decode side (texture_utils.py:149-175)
     def texture_set(self) -> _C.TextureSet:
         t = _C.TextureSet()

@@ -131,6 +131,34 @@ def derive_properties(color, density, depths, deltas, boundary, index_ray, rende
     return rgb, alpha, hit_rays, depth_out, weights
 
 
+@torch.no_grad()
+def composite_frame(color_c, density_c, frame, render_step_size: float, render_bkgd=None, bg_color="white",
+                    want_weights: bool = False):
+    """``derive_properties`` for a whole frame whose colours / densities come straight from the field kernel, i.e. in the
+    intersector's coherent order: ``frame`` = ``RayIntersector.last_frame`` (depths in that order, per-pixel sample
+    counts, tile bases, image size).  One launch (``qf_composite_tiles``), every load a contiguous run; the same
+    values as ``derive_properties(..., sample_index=inverse)`` bit for bit.  Returns (rgb [N,3], alpha [N,1],
+    depth [N,1], weights in the coherent order [S,1] or None).  Inference only."""
+    color_c = _C.f32c(color_c.reshape(-1, 3))
+    density_c = _C.f32c(density_c.reshape(-1))
+    dev = color_c.device
+    n = frame.depth_c.shape[0]
+    if color_c.shape[0] != n or density_c.shape[0] != n:
+        raise ValueError(f"composite_frame: {n} samples in the frame, {color_c.shape[0]} colours, {density_c.shape[0]} densities")
+    n_rays = frame.width * frame.height
+    mode = _BG.get(bg_color, _C.BG_CUSTOM)
+    bk = _C.f32c(render_bkgd.detach().reshape(3).to(dev)) if mode == _C.BG_CUSTOM else None
+    rgb = torch.empty((n_rays, 3), dtype=torch.float32, device=dev)
+    alpha = torch.empty((n_rays, 1), dtype=torch.float32, device=dev)
+    depth = torch.empty((n_rays, 1), dtype=torch.float32, device=dev)
+    weights = torch.empty((n, 1), dtype=torch.float32, device=dev) if want_weights else None
+    _C.check(_C.lib().qf_composite_tiles(
+        _C.ptr(color_c), _C.ptr(density_c), _C.ptr(frame.depth_c), float(render_step_size), _C.ptr(frame.hit_count),
+        frame.max_hits, _C.ptr(frame.tile_base), frame.width, frame.height, mode, _C.ptr(bk), _C.ptr(rgb), _C.ptr(alpha),
+        _C.ptr(depth), _C.ptr(weights), _C.stream()), "qf_composite_tiles")
+    return rgb, alpha, depth, weights
+
+
 def _flatten_rays(rays: Rays):
     rays_shape = rays.origins.shape
     if len(rays_shape) == 3:

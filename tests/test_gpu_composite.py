@@ -202,6 +202,51 @@ def test_derive_properties_chunking_long_rays_and_sample_index(device):
         assert torch.equal(got2[k], got[k])
 
 
+@pytest.mark.parametrize("bg", ["white", "black", "random"])
+@pytest.mark.parametrize("w,h", [(50, 37), (64, 8), (8, 8), (3, 2)])
+def test_tile_compositor_equals_the_chunked_kernel(device, bg, w, h):
+    """qf_composite_tiles (colours / densities / depths in the coherent tile-rank-pixel order) against
+    qf_derive_properties on the ray-major samples: pixels bit for bit -- with and without samples, image sizes that
+    are not multiples of the 8x8 tile -- and the weights, through the inverse map."""
+    import ctypes
+    from types import SimpleNamespace
+    from quadraturefields_amd import _C, utils
+    rng = np.random.default_rng(w * 100 + h)
+    n_rays, k = w * h, 25
+    counts = rng.integers(0, 40, size=n_rays).astype(np.int32)       # some above K: clamped like the pack does
+    counts[rng.random(n_rays) < 0.3] = 0
+    counts[0] = 31
+    counts[-1] = 0
+    used = np.minimum(counts, k)
+    ridx = torch.from_numpy(np.repeat(np.arange(n_rays), used)).long()
+    offsets = torch.from_numpy(np.concatenate([[0], np.cumsum(used)])).long().to(device)
+    n = ridx.shape[0]
+    hit_count = torch.from_numpy(counts).to(device)
+    clamped = torch.from_numpy(used.astype(np.int32)).to(device)
+    tiles = ((w + 7) // 8) * ((h + 7) // 8)
+    totals = torch.empty((tiles,), dtype=torch.int64, device=device)
+    _C.check(_C.lib().qf_tile_totals(_C.ptr(clamped), w, h, _C.ptr(totals), _C.stream()), "qf_tile_totals")
+    tile_base = (torch.cumsum(totals, 0) - totals).contiguous()
+    inverse = torch.empty((n,), dtype=torch.int32, device=device)
+    _C.check(_C.lib().qf_coherent_layout(_C.ptr(clamped), _C.ptr(offsets), _C.ptr(tile_base), w, h, None, _C.ptr(inverse),
+                                         _C.stream()), "qf_coherent_layout")
+    g = torch.Generator().manual_seed(4)
+    color, density = torch.rand(n, 3, generator=g).to(device), (torch.rand(n, generator=g) * 300).to(device)
+    depth = (torch.rand(n, generator=g) * 5).to(device)
+    bk = torch.rand(3, generator=g).to(device)
+    inv = inverse.long()
+    color_c, density_c, depth_c = torch.empty_like(color), torch.empty_like(density), torch.empty_like(depth)
+    color_c[inv], density_c[inv], depth_c[inv] = color, density, depth
+    frame = SimpleNamespace(depth_c=depth_c, hit_count=hit_count, max_hits=k, tile_base=tile_base, width=w, height=h)
+    a = utils.derive_properties(color, density, depth, 5e-3, None, ridx.to(device), render_bkgd=bk, bg_color=bg, N=n_rays)
+    rgb, alpha, dep, wts = utils.composite_frame(color_c, density_c, frame, 5e-3, render_bkgd=bk, bg_color=bg, want_weights=True)
+    assert torch.equal(rgb, a[0]) and torch.equal(alpha, a[1]) and torch.equal(dep, a[3])
+    assert torch.equal(wts[inv], a[4])
+    assert utils.composite_frame(color_c, density_c, frame, 5e-3, render_bkgd=bk, bg_color=bg)[3] is None
+    with pytest.raises(ValueError):
+        utils.composite_frame(color_c[:-1], density_c, frame, 5e-3)
+
+
 def test_derive_properties_ray_ids_outside_the_image(device):
     """N = 0 (the reference signature's default) with samples raises like the reference's index error instead of
     writing through a NULL / too small buffer, and a ray id >= N contributes to no pixel (forward and backward)."""

@@ -94,6 +94,16 @@ def test_compress_roundtrip_through_textures(device):
     data = oq.compress_features(feats, lobes, "linear", 7.5)
     assert torch.equal(comp.alpha.cpu().reshape(-1), data["alpha"])
     assert torch.equal(comp.diffuse.cpu().reshape(-1, 3), data["diffuse"])
+    # compress_features_and_save (texture_utils.py:108-117) writes the same PNG set as filling the maps and saving them
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        comp.save_to_file(td + "/a_")
+        comp.compress_features_and_save(feats.to(device).reshape(t, t, -1), td + "/b_")
+        a = FeatureCompression(lobes, path=td + "/a_", compression_type="linear")
+        b = FeatureCompression(lobes, path=td + "/b_", compression_type="linear")
+        assert torch.equal(a.alpha, b.alpha) and torch.equal(a.diffuse, b.diffuse) and torch.equal(a.alpha, comp.alpha)
+        for i in range(lobes):
+            assert torch.equal(a.sg_colors[i], b.sg_colors[i]) and torch.equal(a.lambdas[i], b.lambdas[i])
 
 
 @pytest.mark.gpu
@@ -123,6 +133,12 @@ def test_packed_texel_records_equal_planes(device, lobes):
     assert torch.equal(rec[:, 4:7].reshape(size, size, 3), comp.lambdas[0])
     assert torch.equal(rec[:, 7:10].reshape(size, size, 3), comp.sg_colors[0])
     assert int(rec[:, 4 + 6 * lobes:].max()) == 0
+    # two-call form (texture_utils.py:144-147 on the fetched rows) = the fused shade, to rounding
+    feats = comp.get_features_from_texture_map(idx)
+    assert (comp.features_to_rgb(feats[:, :-1], d) - rgb_p).abs().max() <= 2e-6
+    assert (comp.features_to_rgb(feats, d) - rgb_p).abs().max() <= 2e-6
+    mix = comp.spherical_gaussian_mixture(feats[:, 3:-1], d)
+    assert (torch.sigmoid(feats[:, :3] + mix) - rgb_p).abs().max() <= 2e-6
     comp.alpha[idx[:, 0], idx[:, 1]] = 77                 # in-place edit: the records follow
     rgb2, sig2 = comp.shade(idx, d)
     assert torch.equal(sig2, comp.shade(idx, d, packed=False)[1]) and not torch.equal(sig2, sig_p)
