@@ -117,14 +117,13 @@ class Stages:
             self.fallbacks = getattr(self, "fallbacks", 0) + 1
         xyz, dirs, index_ray, ts, index_tri, org = data
         layout = ri.last_layout if self.coherent else None
-        for t in (xyz, dirs, index_ray, ts) + (tuple(layout) if layout is not None else ()) + ((order,) if order is not None else ()):
+        for t in (xyz, dirs, index_ray, ts) + (tuple(layout) if layout is not None else ()) + (order,):
             if t is not None:
                 t.record_stream(here)     # allocated on the front-half stream, read here: keep the allocator from reusing them early
-        if layout is not None:      # stream the coherent copies; compositing picks colour / density up through the inverse map
-            inverse, xyz_c, dirs_c = layout
+        if layout is not None:      # stream the coherent copies
+            _, xyz_c, dirs_c = layout
             rgbs, sigmas = self._timed("field", lambda: self.field(xyz_c, dirs_c), record)
         else:
-            inverse = None
             rgbs, sigmas = self._timed("field", lambda: self.field(xyz, dirs, order=order if self.coherent else None), record)
         if layout is not None:      # ... and compositing streams the field's outputs in that same order
             frame = ri.last_frame
@@ -137,7 +136,7 @@ class Stages:
         if ri.rule_violated():          # some ray had hits closer than the re-origin distance: this frame again, exactly
             self.rule_redone = getattr(self, "rule_redone", 0) + 1
             return self.frame(*frame_in, record)
-        return rgb, alpha, depth, index_ray.shape[0]
+        return rgb, alpha, depth, ri.last_frame.total if layout is not None else index_ray.shape[0]
 
     def _pack(self, hits):
         """(tools/field_bench.py) hits = (hit_tri, hit_t, hit_count, overflow, o, d) -> packed samples; sets .order."""

@@ -450,6 +450,16 @@ int qf_pack_samples(const float *rays_o, const float *rays_d, int64_t n_rays, in
                     float *xyz_c, float *dirs_c, float *depth_c /* [n] or NULL */, const uint64_t *keep_mask,
                     const int32_t *raw_count, float min_separation, int32_t *close_flag, void *stream);
 
+/* qf_pack_samples for a frame that is only rendered (rays = a row-major width x height image): writes the positions,
+ * unit directions and depths of the samples DIRECTLY in the coherent order below -- the order qf_field_forward streams
+ * and qf_composite_tiles composites -- one wave per 8x8 tile, and nothing else: no ray-major arrays, no order, no
+ * inverse map.  tile_base from qf_frame_offsets; keep_mask / raw_count / min_separation / close_flag as in
+ * qf_pack_samples.  Values equal qf_pack_samples' xyz_c / dirs_c / depth_c bit for bit.                */
+int qf_pack_tiles(const float *rays_o, const float *rays_d, int32_t width, int32_t height, int32_t max_hits,
+                  const int32_t *hit_tri, const float *hit_t, const int32_t *hit_count, const int64_t *tile_base,
+                  float *xyz_c, float *dirs_c, float *depth_c, const uint64_t *keep_mask, const int32_t *raw_count,
+                  float min_separation, int32_t *close_flag, void *stream);
+
 /* Spatially coherent PROCESSING order for qf_field_forward when the rays are a row-major width x height image:
  * (8x8 pixel tile, hit rank, pixel in tile).  Two steps around one exclusive scan the caller does:
  *   qf_tile_totals    : tile_total[tile] = sum of hit_count over the tile's pixels (tiles row-major, ceil(w/8) per row)

@@ -887,6 +887,120 @@ __global__ __launch_bounds__(kPackRays) void pack_samples_kernel(
     }
 }
 
+// The same packing for a frame that is only going to be RENDERED (row-major width x height image, no ray-major
+// arrays wanted): one wave per 8x8 pixel tile, lane = pixel.  The tile's hit lists are staged and sorted exactly as in
+// pack_samples_kernel (same comparisons, same re-origin handling, same float64 depth order); then step k writes the
+// rank-k samples of the tile's pixels -- position, direction, depth -- at tile_base[tile] + (slots of the ranks
+// before) + (pixels before this one that also have a rank-k hit): the coherent order of qf_coherent_layout, produced
+// by the ballots directly, so neither the order, nor its inverse, nor index_ray / index_tri / ray-major depths exist
+// for such a frame.  Values are pack_samples_kernel's bit for bit (tests).
+__global__ __launch_bounds__(64) void pack_tiles_kernel(
+    const float *__restrict__ rays_o, const float *__restrict__ rays_d, int w, int h, int tiles_x, int max_hits,
+    const int32_t *__restrict__ hit_tri, const float *__restrict__ hit_t, const int32_t *__restrict__ hit_count,
+    const int64_t *__restrict__ tile_base, float *__restrict__ xyz_c, float *__restrict__ dirs_c,
+    float *__restrict__ depth_c, const uint64_t *__restrict__ keep_mask, const int32_t *__restrict__ raw_count,
+    float min_sep, int32_t *__restrict__ close_flag)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int K = max_hits, Kp = max_hits | 1;            // odd row stride: conflict-free column access
+    float *s_t = reinterpret_cast<float *>(smem);
+    int32_t *s_tri = reinterpret_cast<int32_t *>(s_t + 64 * Kp);
+    const int tile = blockIdx.x, lane = threadIdx.x;
+    const int px0 = (tile % tiles_x) * 8, py0 = (tile / tiles_x) * 8;
+    const int cols = (w - px0) < 8 ? (w - px0) : 8, rows = (h - py0) < 8 ? (h - py0) : 8;
+    // stage: the K-lists of a tile row's pixels are one contiguous run
+    for (int yy = 0; yy < rows; ++yy) {
+        const int64_t row_ray0 = (int64_t)(py0 + yy) * w + px0;
+        for (int i = lane; i < cols * K; i += 64) {
+            const int r = i / K, k = i - r * K;
+            s_t[(yy * 8 + r) * Kp + k] = hit_t[row_ray0 * K + i];
+            s_tri[(yy * 8 + r) * Kp + k] = hit_tri[row_ray0 * K + i];
+        }
+    }
+    __syncthreads();
+
+    const int px = px0 + (lane & 7), py = py0 + (lane >> 3);
+    const bool inside = px < w && py < h;
+    const int64_t ray = inside ? (int64_t)py * w + px : 0;
+    int cnt = 0;
+    float *row_t = s_t + lane * Kp;
+    int32_t *row_i = s_tri + lane * Kp;
+    double o64[3] = {0.0, 0.0, 0.0}, d64[3] = {0.0, 0.0, 0.0};
+    float dn[3] = {0.0f, 0.0f, 0.0f};
+    if (inside) {
+        cnt = keep_mask ? raw_count[ray] : hit_count[ray];
+        if (cnt > K) cnt = K;
+        for (int i = 1; i < cnt; ++i) {                       // (t, tri) ascending
+            const float t = row_t[i];
+            const int id = row_i[i];
+            int j = i - 1;
+            while (j >= 0 && hit_less(t, id, row_t[j], row_i[j])) { row_t[j + 1] = row_t[j]; row_i[j + 1] = row_i[j]; --j; }
+            row_t[j + 1] = t;
+            row_i[j + 1] = id;
+        }
+        if (keep_mask) {                                      // the re-origin rule, decided by qf_bvh_repair_overflow
+            const uint64_t mask = keep_mask[ray];
+            int kept = 0;
+            for (int i = 0; i < cnt; ++i)
+                if ((mask >> i) & 1ull) { row_t[kept] = row_t[i]; row_i[kept] = row_i[i]; ++kept; }
+            cnt = kept;
+        } else if (close_flag && min_sep > 0.0f) {            // optimistic route: see pack_samples_kernel
+            bool drop = false;
+            for (int i = 1; i < cnt; ++i) drop |= !(row_t[i] > row_t[i - 1] + min_sep);
+            if (drop) *close_flag = 1;
+        }
+        if (cnt > 0) {
+            const float ox = rays_o[ray * 3], oy = rays_o[ray * 3 + 1], oz = rays_o[ray * 3 + 2];
+            const float dx = rays_d[ray * 3], dy = rays_d[ray * 3 + 1], dz = rays_d[ray * 3 + 2];
+            o64[0] = (double)ox; o64[1] = (double)oy; o64[2] = (double)oz;
+            d64[0] = (double)dx; d64[1] = (double)dy; d64[2] = (double)dz;
+            // vectors / (|vectors| + 1e-7) in float32 (mesh_utils.py:369-370)
+            const float nrm = sqrtf((dx * dx + dy * dy) + dz * dz) + 1e-7f;
+            dn[0] = dx / nrm; dn[1] = dy / nrm; dn[2] = dz / nrm;
+        }
+        if (cnt > 1) {
+            double p[3];
+            double prev = sample_depth64(row_t[0], o64, d64, p);
+            bool sorted = true;
+            for (int k = 1; k < cnt; ++k) {
+                const double dk = sample_depth64(row_t[k], o64, d64, p);
+                sorted = sorted && !(prev > dk);
+                prev = dk;
+            }
+            if (!sorted) {                                     // rare: stable insertion by depth, depths recomputed
+                for (int i = 1; i < cnt; ++i) {
+                    const float t = row_t[i];
+                    const int id = row_i[i];
+                    const double di = sample_depth64(t, o64, d64, p);
+                    int j = i - 1;
+                    while (j >= 0 && sample_depth64(row_t[j], o64, d64, p) > di) { row_t[j + 1] = row_t[j]; row_i[j + 1] = row_i[j]; --j; }
+                    row_t[j + 1] = t;
+                    row_i[j + 1] = id;
+                }
+            }
+        }
+    }
+    int64_t base = tile_base[tile];
+    const unsigned long long below = (1ull << lane) - 1ull;
+    for (int k = 0;; ++k) {
+        const unsigned long long mask = __ballot(cnt > k);
+        if (mask == 0ull) break;                              // wave-uniform exit
+        if (cnt > k) {
+            const int64_t c = base + __popcll(mask & below);
+            double p[3];
+            const double dep = sample_depth64(row_t[k], o64, d64, p);
+            xyz_c[c * 3 + 0] = (float)p[0];
+            xyz_c[c * 3 + 1] = (float)p[1];
+            xyz_c[c * 3 + 2] = (float)p[2];
+            dirs_c[c * 3 + 0] = dn[0];
+            dirs_c[c * 3 + 1] = dn[1];
+            dirs_c[c * 3 + 2] = dn[2];
+            depth_c[c] = (float)dep;
+        }
+        base += __popcll(mask);
+    }
+}
+
 // Stable per-ray insertion sort of sample indices by fp32 depth (np.lexsort((depth, index_ray)) on grouped rays).
 __global__ void resort_kernel(const int64_t *index_ray, const float *depth, int64_t n, int64_t *perm)
 {
@@ -1375,6 +1489,24 @@ extern "C" int qf_pack_samples(const float *rays_o, const float *rays_d, int64_t
     hipLaunchKernelGGL(pack_samples_kernel, dim3((unsigned)blocks), dim3(kPackRays), lds, qf_stream(stream), rays_o, rays_d,
                        n_rays, (int)max_hits, hit_tri, hit_t, hit_count, ray_offset, xyz, dirs, index_ray, depth, index_tri,
                        origins, inverse, xyz_c, dirs_c, depth_c, keep_mask, raw_count, min_separation, close_flag);
+    QF_LAUNCH_CHECK();
+    return QF_OK;
+}
+
+extern "C" int qf_pack_tiles(const float *rays_o, const float *rays_d, int32_t width, int32_t height, int32_t max_hits,
+                             const int32_t *hit_tri, const float *hit_t, const int32_t *hit_count, const int64_t *tile_base,
+                             float *xyz_c, float *dirs_c, float *depth_c, const uint64_t *keep_mask,
+                             const int32_t *raw_count, float min_separation, int32_t *close_flag, void *stream)
+{
+    if ((keep_mask == nullptr) != (raw_count == nullptr)) return QF_ERR_INVALID_ARGUMENT;
+    if (width < 1 || height < 1 || max_hits < 1 || max_hits > kMaxHits) return QF_ERR_INVALID_ARGUMENT;
+    if (!rays_o || !rays_d || !hit_tri || !hit_t || !hit_count || !tile_base || !xyz_c || !dirs_c || !depth_c)
+        return QF_ERR_INVALID_ARGUMENT;
+    const int tiles_x = (width + 7) / 8, tiles_y = (height + 7) / 8;
+    const size_t lds = (size_t)64 * (max_hits | 1) * 8;
+    hipLaunchKernelGGL(pack_tiles_kernel, dim3((unsigned)(tiles_x * tiles_y)), dim3(64), lds, qf_stream(stream), rays_o, rays_d,
+                       (int)width, (int)height, tiles_x, (int)max_hits, hit_tri, hit_t, hit_count, tile_base, xyz_c, dirs_c,
+                       depth_c, keep_mask, raw_count, min_separation, close_flag);
     QF_LAUNCH_CHECK();
     return QF_OK;
 }

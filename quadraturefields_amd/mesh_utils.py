@@ -359,9 +359,10 @@ class RayIntersector:
     @_on_device
     def pack_hits_begin(self, o, d, k, hit_tri, hit_t, hit_count, overflow, width, lean=False, layout=True):
         """Enqueue scan, readback, pack and ordering on the current stream; no host wait.  ``lean`` (image-shaped
-        batches only): skip the ray-major xyz / dirs / origins arrays -- a caller that only renders reads the copies
-        in ``last_layout`` -- and return None in their places.  ``layout=False``: no processing order at all (callers that
-        do not evaluate a field on the samples, e.g. the baked-texture render)."""
+        batches only): a caller that only renders reads the streamed copies in ``last_layout`` / ``last_frame``, so the
+        tile kernel (``qf_pack_tiles``) writes just those and the six ray-major arrays come back as None.
+        ``layout=False``: no processing order at all (callers that do not evaluate a field on the samples, e.g. the
+        baked-texture render)."""
         n = o.shape[0]
         dev = self.device
         buf, temp, host, (ev, ev_flag) = self._frame_scratch(n)
@@ -378,36 +379,45 @@ class RayIntersector:
         ev.record()                           # (total, overflow) are in pinned memory once this event has passed
         lean = bool(lean) and image
         want_layout = layout
-        xyz = dirs = org = None
-        if not lean:
-            xyz = torch.empty((cap, 3), dtype=torch.float32, device=dev)
-            dirs = torch.empty((cap, 3), dtype=torch.float32, device=dev)
-            org = torch.empty((cap, 3), dtype=torch.float32, device=dev)
-        index_ray = torch.empty((cap,), dtype=torch.int64, device=dev)
-        index_tri = torch.empty((cap,), dtype=torch.int64, device=dev)
-        depth = torch.empty((cap,), dtype=torch.float32, device=dev)
-        order = inverse = xyz_c = dirs_c = depth_c = layout = frame = None    # (from here on ``layout`` is the result tuple)
-        if image:                             # the coherent order, its inverse, and streamed copies
-            order, inverse = self.coherent_layout(hit_count, buf, cap, width, tile_base, want_order=not lean)
-            xyz_c = torch.empty((cap, 3), dtype=torch.float32, device=dev)
-            dirs_c = torch.empty((cap, 3), dtype=torch.float32, device=dev)
-            depth_c = torch.empty((cap,), dtype=torch.float32, device=dev)
-            layout = (inverse, xyz_c, dirs_c)
-            frame = SimpleNamespace(depth_c=depth_c, hit_count=hit_count, max_hits=int(k), tile_base=tile_base,
-                                    width=int(width), height=n // int(width))
         keep = getattr(hit_count, "_qf_keep", None) or (None, None)      # from _repair (re-origin rule decided up front)
         optimistic = keep[0] is None and self.min_separation > 0
         flag = None
         if optimistic:                        # the pack kernel verifies "nothing dropped" and raises host[2] otherwise
             host[2] = 0
             flag = ctypes.c_void_p(host.data_ptr() + 16)
-        _C.check(_C.lib().qf_pack_samples(_C.ptr(o), _C.ptr(d), n, k, _C.ptr(hit_tri), _C.ptr(hit_t),
-                                          _C.ptr(hit_count), _C.ptr(buf), _C.ptr(xyz), _C.ptr(dirs),
-                                          _C.ptr(index_ray), _C.ptr(depth), _C.ptr(index_tri), _C.ptr(org),
-                                          _C.ptr(inverse), _C.ptr(xyz_c), _C.ptr(dirs_c), _C.ptr(depth_c),
-                                          _C.ptr(keep[0]), _C.ptr(keep[1]),
-                                          float(self.min_separation) if optimistic else 0.0, flag, _C.stream()),
-                 "qf_pack_samples")
+        min_sep = float(self.min_separation) if optimistic else 0.0
+        xyz = dirs = org = index_ray = index_tri = depth = None
+        order = inverse = xyz_c = dirs_c = depth_c = layout = frame = None    # (from here on ``layout`` is the result tuple)
+        if image:                             # streamed copies in the coherent order (+ what composite_frame needs)
+            xyz_c = torch.empty((cap, 3), dtype=torch.float32, device=dev)
+            dirs_c = torch.empty((cap, 3), dtype=torch.float32, device=dev)
+            depth_c = torch.empty((cap,), dtype=torch.float32, device=dev)
+            frame = SimpleNamespace(depth_c=depth_c, hit_count=hit_count, max_hits=int(k), tile_base=tile_base,
+                                    width=int(width), height=n // int(width), total=0)
+        if lean:
+            # render-only frame: the tile kernel writes the coherent copies directly; no ray-major arrays, no order,
+            # no inverse map exist for it (the six sample arrays come back as None)
+            layout = (None, xyz_c, dirs_c)
+            _C.check(_C.lib().qf_pack_tiles(_C.ptr(o), _C.ptr(d), int(width), n // int(width), k, _C.ptr(hit_tri),
+                                            _C.ptr(hit_t), _C.ptr(hit_count), _C.ptr(tile_base), _C.ptr(xyz_c),
+                                            _C.ptr(dirs_c), _C.ptr(depth_c), _C.ptr(keep[0]), _C.ptr(keep[1]), min_sep,
+                                            flag, _C.stream()), "qf_pack_tiles")
+        else:
+            xyz = torch.empty((cap, 3), dtype=torch.float32, device=dev)
+            dirs = torch.empty((cap, 3), dtype=torch.float32, device=dev)
+            org = torch.empty((cap, 3), dtype=torch.float32, device=dev)
+            index_ray = torch.empty((cap,), dtype=torch.int64, device=dev)
+            index_tri = torch.empty((cap,), dtype=torch.int64, device=dev)
+            depth = torch.empty((cap,), dtype=torch.float32, device=dev)
+            if image:                         # the coherent order and its inverse
+                order, inverse = self.coherent_layout(hit_count, buf, cap, width, tile_base, want_order=True)
+                layout = (inverse, xyz_c, dirs_c)
+            _C.check(_C.lib().qf_pack_samples(_C.ptr(o), _C.ptr(d), n, k, _C.ptr(hit_tri), _C.ptr(hit_t),
+                                              _C.ptr(hit_count), _C.ptr(buf), _C.ptr(xyz), _C.ptr(dirs),
+                                              _C.ptr(index_ray), _C.ptr(depth), _C.ptr(index_tri), _C.ptr(org),
+                                              _C.ptr(inverse), _C.ptr(xyz_c), _C.ptr(dirs_c), _C.ptr(depth_c),
+                                              _C.ptr(keep[0]), _C.ptr(keep[1]), min_sep, flag, _C.stream()),
+                     "qf_pack_samples")
         if optimistic:
             ev_flag.record()
         return (o, d, k, width, (lean, want_layout), host, (ev, ev_flag if optimistic else None),
@@ -445,9 +455,10 @@ class RayIntersector:
         self.last_layout = self.last_frame = None
         if total == 0:
             return None, None
-        if layout is not None:      # (inverse, xyz, dirs) in the coherent order: see coherent_layout
-            self.last_layout = tuple(t[:total] for t in layout)
+        if layout is not None:      # (inverse or None, xyz, dirs) in the coherent order: see coherent_layout
+            self.last_layout = tuple(None if t is None else t[:total] for t in layout)
             frame.depth_c = frame.depth_c[:total]
+            frame.total = total
             self.last_frame = frame
         return [None if t is None else t[:total] for t in arrays], (order[:total] if order is not None else None)
 

@@ -55,14 +55,14 @@ class FrameRenderer:
         if (self.field_net is None or scaling == 0) and ri.last_layout is not None:
             # No deformation: the samples are already sorted by (ray, depth), the re-sort of sampling_indexing is the
             # identity, and the field can stream the copies laid out in its processing order (same bits).
-            inverse, xyz_c, dirs_c = ri.last_layout
+            _, xyz_c, dirs_c = ri.last_layout
             rgbs, sigmas = self.radiance_field(xyz_c, dirs_c)
             # ... and compositing streams the field's outputs in that same order (qf_composite_tiles)
             rgb, alpha, depth, _ = utils.composite_frame(rgbs, sigmas, ri.last_frame, self.render_step_size,
                                                          render_bkgd=render_bkgd, bg_color=self.bg_color)
             if ri.rule_violated():      # rare (near-coincident faces): these samples are not the reference's; again, exactly
                 return self.render(origins, viewdirs, image_width, scaling, render_bkgd, camera)
-            return rgb, alpha, depth, data[2].shape[0]
+            return rgb, alpha, depth, ri.last_frame.total
         if ri.rule_violated():
             return self.render(origins, viewdirs, image_width, scaling, render_bkgd, camera)
         rays = Rays(origins=origins, viewdirs=viewdirs)

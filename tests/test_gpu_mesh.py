@@ -645,6 +645,39 @@ def test_device_refit_equals_a_fresh_intersector(device):
         assert torch.equal(x, y)
 
 
+@pytest.mark.parametrize("dup,w,h", [(False, 96, 64), (True, 52, 45)])
+def test_tile_pack_equals_the_ray_major_pack(device, dup, w, h):
+    """qf_pack_tiles (render-only frames: coherent copies only) writes exactly what qf_pack_samples writes through the
+    inverse map: positions, unit directions, depths -- on a plain scene (optimistic rule) and on a mesh whose faces
+    exist twice (keep masks decided up front), image sizes that are not multiples of the tile."""
+    from quadraturefields_amd import synthetic
+    from quadraturefields_amd.mesh_io import TriMesh
+    from quadraturefields_amd.mesh_utils import RayIntersector, make_camera
+    mesh = _scene(3, 4)
+    if dup:
+        nv = mesh.vertices.shape[0]
+        mesh = TriMesh(np.concatenate([mesh.vertices, mesh.vertices]), np.concatenate([mesh.faces, mesh.faces + nv]))
+    ri = RayIntersector(mesh, max_hits=25)
+    if dup:
+        ri._rule_upfront = 8                      # decide the re-origin rule per ray (keep masks), as after a refuted frame
+    focal = synthetic.lego_focal(800) * w / 800.0
+    c2w = synthetic.orbit_cameras(2, seed=3)[1]
+    o, d = synthetic.camera_rays(c2w, focal, w, h, device=device)
+    cam = make_camera(c2w, focal, w, h)
+    hit_tri, hit_t, hit_count, overflow = ri._hits_raster_frame(o, d, 25, cam)
+    full, order = ri.pack_hits(o, d, 25, hit_tri, hit_t, hit_count, overflow, w, lean=False)
+    inverse, xyz_c, dirs_c = ri.last_layout
+    depth_c, total = ri.last_frame.depth_c, ri.last_frame.total
+    assert total == full[0].shape[0] and torch.equal(xyz_c[inverse.long()], full[0]) and torch.equal(depth_c[inverse.long()], full[3])
+    lean, order2 = ri.pack_hits(o, d, 25, hit_tri, hit_t, hit_count, overflow, w, lean=True)
+    assert order2 is None and all(t is None for t in lean)
+    none, xyz_t, dirs_t = ri.last_layout
+    assert none is None and ri.last_frame.total == total
+    assert torch.equal(xyz_t, xyz_c) and torch.equal(dirs_t, dirs_c) and torch.equal(ri.last_frame.depth_c, depth_c)
+    if dup:
+        assert getattr(hit_count, "_qf_keep", None) is not None and total > 0
+
+
 def test_frame_offsets_equal_a_cumsum(device):
     """qf_frame_offsets (ray offsets + tile bases in three launches, total and overflow written to pinned memory)
     against torch.cumsum, for image-shaped and plain batches, sizes that are not multiples of the block, empty input."""
