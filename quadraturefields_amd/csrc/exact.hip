@@ -908,28 +908,39 @@ __global__ __launch_bounds__(64) void pack_tiles_kernel(
     const int tile = blockIdx.x, lane = threadIdx.x;
     const int px0 = (tile % tiles_x) * 8, py0 = (tile / tiles_x) * 8;
     const int cols = (w - px0) < 8 ? (w - px0) : 8, rows = (h - py0) < 8 ? (h - py0) : 8;
-    // stage: the K-lists of a tile row's pixels are one contiguous run
-    for (int yy = 0; yy < rows; ++yy) {
-        const int64_t row_ray0 = (int64_t)(py0 + yy) * w + px0;
-        for (int i = lane; i < cols * K; i += 64) {
-            const int r = i / K, k = i - r * K;
-            s_t[(yy * 8 + r) * Kp + k] = hit_t[row_ray0 * K + i];
-            s_tri[(yy * 8 + r) * Kp + k] = hit_tri[row_ray0 * K + i];
-        }
-    }
-    __syncthreads();
-
     const int px = px0 + (lane & 7), py = py0 + (lane >> 3);
     const bool inside = px < w && py < h;
     const int64_t ray = inside ? (int64_t)py * w + px : 0;
     int cnt = 0;
+    if (inside) {
+        cnt = keep_mask ? raw_count[ray] : hit_count[ray];
+        if (cnt > K) cnt = K;
+    }
+    // the longest list of the tile bounds what is staged: background tiles (40 % of an orbit frame) leave at once, the
+    // others read their first `deepest` slots instead of all K
+    int deepest = cnt;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const int other = __shfl_xor(deepest, off, 64);
+        deepest = other > deepest ? other : deepest;
+    }
+    if (deepest == 0) return;                                 // wave-uniform
+    // stage: the lists of a tile row's pixels lie K apart
+    for (int yy = 0; yy < rows; ++yy) {
+        const int64_t row_ray0 = (int64_t)(py0 + yy) * w + px0;
+        for (int i = lane; i < cols * deepest; i += 64) {
+            const int r = i / deepest, k = i - r * deepest;
+            s_t[(yy * 8 + r) * Kp + k] = hit_t[(row_ray0 + r) * K + k];
+            s_tri[(yy * 8 + r) * Kp + k] = hit_tri[(row_ray0 + r) * K + k];
+        }
+    }
+    __syncthreads();
+
     float *row_t = s_t + lane * Kp;
     int32_t *row_i = s_tri + lane * Kp;
     double o64[3] = {0.0, 0.0, 0.0}, d64[3] = {0.0, 0.0, 0.0};
     float dn[3] = {0.0f, 0.0f, 0.0f};
     if (inside) {
-        cnt = keep_mask ? raw_count[ray] : hit_count[ray];
-        if (cnt > K) cnt = K;
         for (int i = 1; i < cnt; ++i) {                       // (t, tri) ascending
             const float t = row_t[i];
             const int id = row_i[i];
