@@ -136,7 +136,7 @@ class Stages:
         if ri.rule_violated():          # some ray had hits closer than the re-origin distance: this frame again, exactly
             self.rule_redone = getattr(self, "rule_redone", 0) + 1
             return self.frame(*frame_in, record)
-        return rgb, alpha, depth, ri.last_frame.total if layout is not None else index_ray.shape[0]
+        return rgb, alpha, depth, ri.frame_samples() if layout is not None else index_ray.shape[0]
 
     def _pack(self, hits):
         """(tools/field_bench.py) hits = (hit_tri, hit_t, hit_count, overflow, o, d) -> packed samples; sets .order."""

@@ -453,12 +453,20 @@ int qf_pack_samples(const float *rays_o, const float *rays_d, int64_t n_rays, in
 /* qf_pack_samples for a frame that is only rendered (rays = a row-major width x height image): writes the positions,
  * unit directions and depths of the samples DIRECTLY in the coherent order below -- the order qf_field_forward streams
  * and qf_composite_tiles composites -- one wave per 8x8 tile, and nothing else: no ray-major arrays, no order, no
- * inverse map.  tile_base from qf_frame_offsets; keep_mask / raw_count / min_separation / close_flag as in
- * qf_pack_samples.  Values equal qf_pack_samples' xyz_c / dirs_c / depth_c bit for bit.                */
+ * inverse map.  tile_base and total (= ray_offset + n_rays) from qf_frame_offsets on the same hit_count.
+ * The re-origin rule: with keep_mask / raw_count (from qf_bvh_repair_overflow) as in qf_pack_samples; otherwise, with
+ * min_separation > 0, it is applied HERE, on the sorted list (what qf_filter_hits does) -- no optimistic guess, no
+ * second pass.  The hits it drops leave unused slots at the end of their tile (filled with a copy of a real sample so
+ * that qf_field_forward can stream [0, *total) blindly): final_count [w*h] receives every pixel's kept count -- hand
+ * THAT to qf_composite_tiles -- and *dropped (device int32, zeroed by this call) the frame's number of dropped hits
+ * (samples of the frame = *total - *dropped).  host_out (or NULL): pinned host int64[3]; host_out[2] = *dropped after
+ * the call's kernels, for a caller that wants the count without a copy.  final_count may be given without the rule.
+ * Values equal qf_pack_samples' xyz_c / dirs_c / depth_c bit for bit (position for position when nothing is dropped). */
 int qf_pack_tiles(const float *rays_o, const float *rays_d, int32_t width, int32_t height, int32_t max_hits,
                   const int32_t *hit_tri, const float *hit_t, const int32_t *hit_count, const int64_t *tile_base,
-                  float *xyz_c, float *dirs_c, float *depth_c, const uint64_t *keep_mask, const int32_t *raw_count,
-                  float min_separation, int32_t *close_flag, void *stream);
+                  const int64_t *total, float *xyz_c, float *dirs_c, float *depth_c, const uint64_t *keep_mask,
+                  const int32_t *raw_count, float min_separation, int32_t *final_count, int32_t *dropped,
+                  int64_t *host_out, void *stream);
 
 /* Spatially coherent PROCESSING order for qf_field_forward when the rays are a row-major width x height image:
  * (8x8 pixel tile, hit rank, pixel in tile).  Two steps around one exclusive scan the caller does:

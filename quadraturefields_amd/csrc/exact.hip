@@ -895,11 +895,11 @@ __global__ __launch_bounds__(kPackRays) void pack_samples_kernel(
 // by the ballots directly, so neither the order, nor its inverse, nor index_ray / index_tri / ray-major depths exist
 // for such a frame.  Values are pack_samples_kernel's bit for bit (tests).
 __global__ __launch_bounds__(64) void pack_tiles_kernel(
-    const float *__restrict__ rays_o, const float *__restrict__ rays_d, int w, int h, int tiles_x, int max_hits,
+    const float *__restrict__ rays_o, const float *__restrict__ rays_d, int w, int h, int tiles_x, int n_tiles, int max_hits,
     const int32_t *__restrict__ hit_tri, const float *__restrict__ hit_t, const int32_t *__restrict__ hit_count,
-    const int64_t *__restrict__ tile_base, float *__restrict__ xyz_c, float *__restrict__ dirs_c,
-    float *__restrict__ depth_c, const uint64_t *__restrict__ keep_mask, const int32_t *__restrict__ raw_count,
-    float min_sep, int32_t *__restrict__ close_flag)
+    const int64_t *__restrict__ tile_base, const int64_t *__restrict__ total, float *__restrict__ xyz_c,
+    float *__restrict__ dirs_c, float *__restrict__ depth_c, const uint64_t *__restrict__ keep_mask,
+    const int32_t *__restrict__ raw_count, float min_sep, int32_t *__restrict__ final_count, int32_t *__restrict__ dropped)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int K = max_hits, Kp = max_hits | 1;            // odd row stride: conflict-free column access
@@ -924,7 +924,10 @@ __global__ __launch_bounds__(64) void pack_tiles_kernel(
         const int other = __shfl_xor(deepest, off, 64);
         deepest = other > deepest ? other : deepest;
     }
-    if (deepest == 0) return;                                 // wave-uniform
+    if (deepest == 0) {                                       // wave-uniform
+        if (final_count && inside) final_count[ray] = 0;
+        return;
+    }
     // stage: the lists of a tile row's pixels lie K apart
     for (int yy = 0; yy < rows; ++yy) {
         const int64_t row_ray0 = (int64_t)(py0 + yy) * w + px0;
@@ -940,6 +943,7 @@ __global__ __launch_bounds__(64) void pack_tiles_kernel(
     int32_t *row_i = s_tri + lane * Kp;
     double o64[3] = {0.0, 0.0, 0.0}, d64[3] = {0.0, 0.0, 0.0};
     float dn[3] = {0.0f, 0.0f, 0.0f};
+    int n_dropped = 0;
     if (inside) {
         for (int i = 1; i < cnt; ++i) {                       // (t, tri) ascending
             const float t = row_t[i];
@@ -955,10 +959,18 @@ __global__ __launch_bounds__(64) void pack_tiles_kernel(
             for (int i = 0; i < cnt; ++i)
                 if ((mask >> i) & 1ull) { row_t[kept] = row_t[i]; row_i[kept] = row_i[i]; ++kept; }
             cnt = kept;
-        } else if (close_flag && min_sep > 0.0f) {            // optimistic route: see pack_samples_kernel
-            bool drop = false;
-            for (int i = 1; i < cnt; ++i) drop |= !(row_t[i] > row_t[i - 1] + min_sep);
-            if (drop) *close_flag = 1;
+        } else if (min_sep > 0.0f && cnt > 1) {
+            // the re-origin rule on the sorted list, as filter_hits_kernel applies it: a hit is kept iff it is the first
+            // or lies more than min_sep behind the last kept one.  The tile's slots were allotted from the counts before
+            // the rule; what it drops leaves a gap at the end of the tile (filled below).
+            float last_t = row_t[0];
+            int kept = 1;
+            for (int i = 1; i < cnt; ++i) {
+                const float t = row_t[i];
+                if (t > last_t + min_sep) { row_t[kept] = t; row_i[kept] = row_i[i]; ++kept; last_t = t; }
+            }
+            n_dropped = cnt - kept;
+            cnt = kept;
         }
         if (cnt > 0) {
             const float ox = rays_o[ray * 3], oy = rays_o[ray * 3 + 1], oz = rays_o[ray * 3 + 2];
@@ -991,8 +1003,10 @@ __global__ __launch_bounds__(64) void pack_tiles_kernel(
             }
         }
     }
+    if (final_count && inside) final_count[ray] = cnt;
     int64_t base = tile_base[tile];
     const unsigned long long below = (1ull << lane) - 1ull;
+    float first_xyz[3] = {0.0f, 0.0f, 0.0f};                  // this lane's nearest sample, for the gap fill
     for (int k = 0;; ++k) {
         const unsigned long long mask = __ballot(cnt > k);
         if (mask == 0ull) break;                              // wave-uniform exit
@@ -1007,10 +1021,32 @@ __global__ __launch_bounds__(64) void pack_tiles_kernel(
             dirs_c[c * 3 + 1] = dn[1];
             dirs_c[c * 3 + 2] = dn[2];
             depth_c[c] = (float)dep;
+            if (k == 0) { first_xyz[0] = (float)p[0]; first_xyz[1] = (float)p[1]; first_xyz[2] = (float)p[2]; }
         }
         base += __popcll(mask);
     }
+    // Slots the rule emptied: the field kernel streams [0, total) and must find finite points everywhere, nobody reads
+    // what it computes there (qf_composite_tiles walks the kept counts).  They get a copy of the tile's first sample.
+    const unsigned long long any_drop = __ballot(n_dropped > 0);
+    if (any_drop) {
+        const int64_t end = tile + 1 < n_tiles ? tile_base[tile + 1] : *total;
+        const int src = __ffsll((long long)__ballot(cnt > 0)) - 1;       // a tile that dropped something kept something
+        const float gx = __shfl(first_xyz[0], src, 64), gy = __shfl(first_xyz[1], src, 64), gz = __shfl(first_xyz[2], src, 64);
+        const float hx = __shfl(dn[0], src, 64), hy = __shfl(dn[1], src, 64), hz = __shfl(dn[2], src, 64);
+        for (int64_t c = base + lane; c < end; c += 64) {
+            xyz_c[c * 3 + 0] = gx; xyz_c[c * 3 + 1] = gy; xyz_c[c * 3 + 2] = gz;
+            dirs_c[c * 3 + 0] = hx; dirs_c[c * 3 + 1] = hy; dirs_c[c * 3 + 2] = hz;
+            depth_c[c] = 0.0f;
+        }
+        int sum = n_dropped;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+        if (lane == 0 && dropped) atomicAdd(dropped, sum);
+    }
 }
+
+// the frame's dropped-hit count -> pinned host memory (host_out[2]), one thread
+__global__ void publish_dropped_kernel(const int32_t *dropped, int64_t *host_out) { host_out[2] = (int64_t)*dropped; }
 
 // Stable per-ray insertion sort of sample indices by fp32 depth (np.lexsort((depth, index_ray)) on grouped rays).
 __global__ void resort_kernel(const int64_t *index_ray, const float *depth, int64_t n, int64_t *perm)
@@ -1506,18 +1542,25 @@ extern "C" int qf_pack_samples(const float *rays_o, const float *rays_d, int64_t
 
 extern "C" int qf_pack_tiles(const float *rays_o, const float *rays_d, int32_t width, int32_t height, int32_t max_hits,
                              const int32_t *hit_tri, const float *hit_t, const int32_t *hit_count, const int64_t *tile_base,
-                             float *xyz_c, float *dirs_c, float *depth_c, const uint64_t *keep_mask,
-                             const int32_t *raw_count, float min_separation, int32_t *close_flag, void *stream)
+                             const int64_t *total, float *xyz_c, float *dirs_c, float *depth_c, const uint64_t *keep_mask,
+                             const int32_t *raw_count, float min_separation, int32_t *final_count, int32_t *dropped,
+                             int64_t *host_out, void *stream)
 {
     if ((keep_mask == nullptr) != (raw_count == nullptr)) return QF_ERR_INVALID_ARGUMENT;
     if (width < 1 || height < 1 || max_hits < 1 || max_hits > kMaxHits) return QF_ERR_INVALID_ARGUMENT;
-    if (!rays_o || !rays_d || !hit_tri || !hit_t || !hit_count || !tile_base || !xyz_c || !dirs_c || !depth_c)
+    if (!rays_o || !rays_d || !hit_tri || !hit_t || !hit_count || !tile_base || !total || !xyz_c || !dirs_c || !depth_c)
         return QF_ERR_INVALID_ARGUMENT;
+    const bool rule_here = !keep_mask && min_separation > 0.0f;
+    if (rule_here && (!final_count || !dropped)) return QF_ERR_INVALID_ARGUMENT;     // the counts change: they must go somewhere
+    if (host_out && !dropped) return QF_ERR_INVALID_ARGUMENT;
+    hipStream_t st = qf_stream(stream);
+    if (dropped) QF_HIP_TRY(hipMemsetAsync(dropped, 0, sizeof(int32_t), st));
     const int tiles_x = (width + 7) / 8, tiles_y = (height + 7) / 8;
     const size_t lds = (size_t)64 * (max_hits | 1) * 8;
-    hipLaunchKernelGGL(pack_tiles_kernel, dim3((unsigned)(tiles_x * tiles_y)), dim3(64), lds, qf_stream(stream), rays_o, rays_d,
-                       (int)width, (int)height, tiles_x, (int)max_hits, hit_tri, hit_t, hit_count, tile_base, xyz_c, dirs_c,
-                       depth_c, keep_mask, raw_count, min_separation, close_flag);
+    hipLaunchKernelGGL(pack_tiles_kernel, dim3((unsigned)(tiles_x * tiles_y)), dim3(64), lds, st, rays_o, rays_d, (int)width,
+                       (int)height, tiles_x, tiles_x * tiles_y, (int)max_hits, hit_tri, hit_t, hit_count, tile_base, total,
+                       xyz_c, dirs_c, depth_c, keep_mask, raw_count, rule_here ? min_separation : 0.0f, final_count, dropped);
+    if (host_out) hipLaunchKernelGGL(publish_dropped_kernel, dim3(1), dim3(1), 0, st, dropped, host_out);
     QF_LAUNCH_CHECK();
     return QF_OK;
 }

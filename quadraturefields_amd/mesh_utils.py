@@ -271,8 +271,9 @@ class RayIntersector:
         return hit_tri.reshape(-1).cpu().numpy()
 
     def _frame_scratch(self, n):
-        """Per-ray-count scratch reused across frames: [n+2] int64 = sample offsets | total | raster overflow counter,
-        the scan's temp storage, a pinned (device-writable) host block [total, overflow, close-pair flag, -] that the
+        """Per-ray-count scratch reused across frames: [n+3] int64 = sample offsets | total | raster overflow counter |
+        hits dropped by the tile pack's re-origin rule,
+        the scan's temp storage, a pinned (device-writable) host block [total, overflow, close-pair flag or dropped hits, -] that the
         kernels write directly, and the two events that guard it (after the offsets; after the pack)."""
         # frames in flight on different streams, or two consecutive frames of a front / back pipeline (``scratch_slot``
         # alternates: the next frame's offsets kernel must not overwrite the pinned block the host has not read yet),
@@ -280,7 +281,7 @@ class RayIntersector:
         key = (n, torch.cuda.current_stream().cuda_stream, self.scratch_slot)
         s = self._scratch.get(key)
         if s is None:
-            buf = torch.zeros((n + 2,), dtype=torch.int64, device=self.device)
+            buf = torch.zeros((n + 3,), dtype=torch.int64, device=self.device)
             nbytes = int(_C.lib().qf_frame_offsets_temp_bytes(n))
             if nbytes < 0:
                 raise _C.QFError("qf_frame_offsets_temp_bytes failed")
@@ -396,12 +397,21 @@ class RayIntersector:
                                     width=int(width), height=n // int(width), total=0)
         if lean:
             # render-only frame: the tile kernel writes the coherent copies directly; no ray-major arrays, no order,
-            # no inverse map exist for it (the six sample arrays come back as None)
+            # no inverse map exist for it (the six sample arrays come back as None).  It also applies the re-origin
+            # rule itself, on the sorted lists (unless _repair already decided it): nothing optimistic about such a
+            # frame, it is never packed twice; host[2] receives the number of hits the rule dropped.
             layout = (None, xyz_c, dirs_c)
+            optimistic = False
+            final_count = torch.empty((n,), dtype=torch.int32, device=dev)
+            dropped = buf[n + 2:].view(torch.int32)[:1]
             _C.check(_C.lib().qf_pack_tiles(_C.ptr(o), _C.ptr(d), int(width), n // int(width), k, _C.ptr(hit_tri),
-                                            _C.ptr(hit_t), _C.ptr(hit_count), _C.ptr(tile_base), _C.ptr(xyz_c),
-                                            _C.ptr(dirs_c), _C.ptr(depth_c), _C.ptr(keep[0]), _C.ptr(keep[1]), min_sep,
-                                            flag, _C.stream()), "qf_pack_tiles")
+                                            _C.ptr(hit_t), _C.ptr(hit_count), _C.ptr(tile_base), _C.ptr(buf[n:]),
+                                            _C.ptr(xyz_c), _C.ptr(dirs_c), _C.ptr(depth_c), _C.ptr(keep[0]),
+                                            _C.ptr(keep[1]), float(self.min_separation) if keep[0] is None else 0.0,
+                                            _C.ptr(final_count), _C.ptr(dropped), ctypes.c_void_p(host.data_ptr()),
+                                            _C.stream()), "qf_pack_tiles")
+            frame.hit_count = final_count
+            ev_flag.record()
         else:
             xyz = torch.empty((cap, 3), dtype=torch.float32, device=dev)
             dirs = torch.empty((cap, 3), dtype=torch.float32, device=dev)
@@ -420,7 +430,7 @@ class RayIntersector:
                      "qf_pack_samples")
         if optimistic:
             ev_flag.record()
-        return (o, d, k, width, (lean, want_layout), host, (ev, ev_flag if optimistic else None),
+        return (o, d, k, width, (lean, want_layout), host, (ev, ev_flag if (optimistic or lean) else None),
                 [xyz, dirs, index_ray, depth, index_tri, org], order, layout,
                 (hit_tri, hit_t, hit_count, keep),    # the lists stay referenced until the kernels reading them ran
                 frame)
@@ -437,7 +447,7 @@ class RayIntersector:
         ev.synchronize()
         total, ovf = int(host[0]), int(host[1])
         self._rule_pending = None
-        if ev_flag is not None:
+        if ev_flag is not None and not lean[0]:
             if defer_rule_check:
                 self._rule_pending = (ev_flag, host)
             else:
@@ -458,9 +468,26 @@ class RayIntersector:
         if layout is not None:      # (inverse or None, xyz, dirs) in the coherent order: see coherent_layout
             self.last_layout = tuple(None if t is None else t[:total] for t in layout)
             frame.depth_c = frame.depth_c[:total]
-            frame.total = total
+            frame.total = total               # slots of the coherent arrays (what the field kernel streams)
+            # a render-only frame's tile pack applied the re-origin rule itself: its samples are the slots minus the
+            # hits that dropped (host[2], there once ev_flag has passed -- read on demand by frame_samples())
+            frame.samples = None if lean[0] else total
+            frame.dropped_src = (ev_flag, host) if lean[0] else None
             self.last_frame = frame
         return [None if t is None else t[:total] for t in arrays], (order[:total] if order is not None else None)
+
+    def frame_samples(self) -> int:
+        """Quadrature points of the most recent image-shaped pack (``last_frame``): for a render-only frame the slots
+        of the coherent arrays minus the hits its re-origin rule dropped."""
+        f = self.last_frame
+        if f is None:
+            return 0
+        if f.samples is None:
+            ev_flag, host = f.dropped_src
+            ev_flag.synchronize()
+            f.samples = f.total - int(host[2])
+            f.dropped_src = None
+        return f.samples
 
     def rule_violated(self) -> bool:
         """After ``pack_hits_end(..., defer_rule_check=True)``: did the optimistic pack of that frame find a ray whose

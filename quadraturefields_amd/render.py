@@ -62,7 +62,7 @@ class FrameRenderer:
                                                          render_bkgd=render_bkgd, bg_color=self.bg_color)
             if ri.rule_violated():      # rare (near-coincident faces): these samples are not the reference's; again, exactly
                 return self.render(origins, viewdirs, image_width, scaling, render_bkgd, camera)
-            return rgb, alpha, depth, ri.last_frame.total
+            return rgb, alpha, depth, ri.frame_samples()
         if ri.rule_violated():
             return self.render(origins, viewdirs, image_width, scaling, render_bkgd, camera)
         rays = Rays(origins=origins, viewdirs=viewdirs)

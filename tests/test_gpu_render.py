@@ -271,11 +271,10 @@ def test_config5_baked_render_at_full_texture_size(device):
     assert float((rgb.cpu()[idx] - rgb_o).abs().max()) <= 2e-4
 
 
-def test_frame_on_duplicated_shells_takes_the_exact_rule_route(device):
+def test_frame_on_duplicated_shells_applies_the_rule_in_the_tile_pack(device):
     """A mesh whose every face exists twice (the reference concatenates two iso-surfaces, marching_cubes.py:81): the
-    frame renderer's optimistic re-origin pack is refuted by the pack kernel's check, the frame is sampled again with
-    the rule decided per ray, and the pixels are the oracle's (which skips the second copy of every crossing); the
-    following frames decide the rule up front and are not redone."""
+    frame renderer's tile pack applies the re-origin rule on its sorted lists, the pixels and the sample count are the
+    oracle's (which skips the second copy of every crossing), and no frame is packed twice."""
     from quadraturefields_amd import synthetic
     from quadraturefields_amd.mesh_io import TriMesh
     from quadraturefields_amd.mesh_utils import MeshIntersection, make_camera
@@ -301,7 +300,7 @@ def test_frame_on_duplicated_shells_takes_the_exact_rule_route(device):
         rgb_o = om.render_image_finetune(wts, None, data, w * h)[0]
         assert n == data[0].shape[0]
         assert float((rgb.cpu() - rgb_o).abs().max()) <= 2e-4 and psnr(rgb.cpu(), rgb_o) >= 70.0
-        assert ri.rule_redone_frames == 1                      # frame 0 was redone, frames 1-2 went the exact way at once
+        assert ri.rule_redone_frames == 0 and ri.last_frame.total > 1.5 * n      # slots of both copies, samples of one
     every = om.to_loader_tensors(om.sampling_raytrace_numpy(
         om.BVHIntersector(mesh.vertices, mesh.faces, min_separation=0.0), d.numpy(), o.numpy(), 25))
     assert every[0].shape[0] > 1.5 * data[0].shape[0]          # the rule did remove the second copies
