@@ -903,8 +903,8 @@ __global__ __launch_bounds__(64) void pack_tiles_kernel(
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int K = max_hits, Kp = max_hits | 1;            // odd row stride: conflict-free column access
-    float *s_t = reinterpret_cast<float *>(smem);
-    int32_t *s_tri = reinterpret_cast<int32_t *>(s_t + 64 * Kp);
+    float *s_t = reinterpret_cast<float *>(smem);             // distances only: the triangle ids are not part of the output,
+                                                              // and hits with equal t are the same sample in either order
     const int tile = blockIdx.x, lane = threadIdx.x;
     const int px0 = (tile % tiles_x) * 8, py0 = (tile / tiles_x) * 8;
     const int cols = (w - px0) < 8 ? (w - px0) : 8, rows = (h - py0) < 8 ? (h - py0) : 8;
@@ -934,30 +934,26 @@ __global__ __launch_bounds__(64) void pack_tiles_kernel(
         for (int i = lane; i < cols * deepest; i += 64) {
             const int r = i / deepest, k = i - r * deepest;
             s_t[(yy * 8 + r) * Kp + k] = hit_t[(row_ray0 + r) * K + k];
-            s_tri[(yy * 8 + r) * Kp + k] = hit_tri[(row_ray0 + r) * K + k];
         }
     }
     __syncthreads();
 
     float *row_t = s_t + lane * Kp;
-    int32_t *row_i = s_tri + lane * Kp;
     double o64[3] = {0.0, 0.0, 0.0}, d64[3] = {0.0, 0.0, 0.0};
     float dn[3] = {0.0f, 0.0f, 0.0f};
     int n_dropped = 0;
     if (inside) {
-        for (int i = 1; i < cnt; ++i) {                       // (t, tri) ascending
+        for (int i = 1; i < cnt; ++i) {                       // t ascending (ties: equal samples)
             const float t = row_t[i];
-            const int id = row_i[i];
             int j = i - 1;
-            while (j >= 0 && hit_less(t, id, row_t[j], row_i[j])) { row_t[j + 1] = row_t[j]; row_i[j + 1] = row_i[j]; --j; }
+            while (j >= 0 && t < row_t[j]) { row_t[j + 1] = row_t[j]; --j; }
             row_t[j + 1] = t;
-            row_i[j + 1] = id;
         }
         if (keep_mask) {                                      // the re-origin rule, decided by qf_bvh_repair_overflow
             const uint64_t mask = keep_mask[ray];
             int kept = 0;
             for (int i = 0; i < cnt; ++i)
-                if ((mask >> i) & 1ull) { row_t[kept] = row_t[i]; row_i[kept] = row_i[i]; ++kept; }
+                if ((mask >> i) & 1ull) { row_t[kept] = row_t[i]; ++kept; }
             cnt = kept;
         } else if (min_sep > 0.0f && cnt > 1) {
             // the re-origin rule on the sorted list, as filter_hits_kernel applies it: a hit is kept iff it is the first
@@ -967,7 +963,7 @@ __global__ __launch_bounds__(64) void pack_tiles_kernel(
             int kept = 1;
             for (int i = 1; i < cnt; ++i) {
                 const float t = row_t[i];
-                if (t > last_t + min_sep) { row_t[kept] = t; row_i[kept] = row_i[i]; ++kept; last_t = t; }
+                if (t > last_t + min_sep) { row_t[kept] = t; ++kept; last_t = t; }
             }
             n_dropped = cnt - kept;
             cnt = kept;
@@ -993,12 +989,10 @@ __global__ __launch_bounds__(64) void pack_tiles_kernel(
             if (!sorted) {                                     // rare: stable insertion by depth, depths recomputed
                 for (int i = 1; i < cnt; ++i) {
                     const float t = row_t[i];
-                    const int id = row_i[i];
                     const double di = sample_depth64(t, o64, d64, p);
                     int j = i - 1;
-                    while (j >= 0 && sample_depth64(row_t[j], o64, d64, p) > di) { row_t[j + 1] = row_t[j]; row_i[j + 1] = row_i[j]; --j; }
+                    while (j >= 0 && sample_depth64(row_t[j], o64, d64, p) > di) { row_t[j + 1] = row_t[j]; --j; }
                     row_t[j + 1] = t;
-                    row_i[j + 1] = id;
                 }
             }
         }
@@ -1556,7 +1550,7 @@ extern "C" int qf_pack_tiles(const float *rays_o, const float *rays_d, int32_t w
     hipStream_t st = qf_stream(stream);
     if (dropped) QF_HIP_TRY(hipMemsetAsync(dropped, 0, sizeof(int32_t), st));
     const int tiles_x = (width + 7) / 8, tiles_y = (height + 7) / 8;
-    const size_t lds = (size_t)64 * (max_hits | 1) * 8;
+    const size_t lds = (size_t)64 * (max_hits | 1) * 4;
     hipLaunchKernelGGL(pack_tiles_kernel, dim3((unsigned)(tiles_x * tiles_y)), dim3(64), lds, st, rays_o, rays_d, (int)width,
                        (int)height, tiles_x, tiles_x * tiles_y, (int)max_hits, hit_tri, hit_t, hit_count, tile_base, total,
                        xyz_c, dirs_c, depth_c, keep_mask, raw_count, rule_here ? min_separation : 0.0f, final_count, dropped);
