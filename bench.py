@@ -286,7 +286,8 @@ def config5_line(device, scene, steps=8, warm=3, texture_size=4096, lobes=6):
     achieved = ppl * alg / (shade_ms * 1e-3) / 1e9
     return {
         "workload": f"configs[4]: baked SG textures {texture_size}^2 uint8 x (2+2L) planes, L={lobes}, 800x800 frames, "
-                    "render_image_bake_texture_images_with_occgrid",
+                    "FrameRenderer.render_baked (tile pack with triangle ids -> texel lookup -> decode + SG shading -> tile "
+                    "compositor; pixels equal render_image_bake_texture_images_with_occgrid bit for bit)",
         "dtype": "u8 codes -> f32", "rays_per_frame": W * H, "ms_per_frame": el / steps * 1e3,
         "rays_per_s": W * H * steps / el, "quadrature_points_per_frame": ppl,
         "dominant_kernel": "texture_shade_packed_kernel",

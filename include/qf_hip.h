@@ -461,12 +461,14 @@ int qf_pack_samples(const float *rays_o, const float *rays_d, int64_t n_rays, in
  * THAT to qf_composite_tiles -- and *dropped (device int32, zeroed by this call) the frame's number of dropped hits
  * (samples of the frame = *total - *dropped).  host_out (or NULL): pinned host int64[3]; host_out[2] = *dropped after
  * the call's kernels, for a caller that wants the count without a copy.  final_count may be given without the rule.
+ * tri_c (or NULL): the samples' triangle ids in the same order (the baked-texture render looks its texels up by
+ * triangle, utils.py:1055-1063); without it hit_tri is not read at all (may be NULL).
  * Values equal qf_pack_samples' xyz_c / dirs_c / depth_c bit for bit (position for position when nothing is dropped). */
 int qf_pack_tiles(const float *rays_o, const float *rays_d, int32_t width, int32_t height, int32_t max_hits,
                   const int32_t *hit_tri, const float *hit_t, const int32_t *hit_count, const int64_t *tile_base,
-                  const int64_t *total, float *xyz_c, float *dirs_c, float *depth_c, const uint64_t *keep_mask,
-                  const int32_t *raw_count, float min_separation, int32_t *final_count, int32_t *dropped,
-                  int64_t *host_out, void *stream);
+                  const int64_t *total, float *xyz_c, float *dirs_c, float *depth_c, int64_t *tri_c /* or NULL */,
+                  const uint64_t *keep_mask, const int32_t *raw_count, float min_separation, int32_t *final_count,
+                  int32_t *dropped, int64_t *host_out, void *stream);
 
 /* Spatially coherent PROCESSING order for qf_field_forward when the rays are a row-major width x height image:
  * (8x8 pixel tile, hit rank, pixel in tile).  Two steps around one exclusive scan the caller does:

@@ -894,17 +894,21 @@ __global__ __launch_bounds__(kPackRays) void pack_samples_kernel(
 // before) + (pixels before this one that also have a rank-k hit): the coherent order of qf_coherent_layout, produced
 // by the ballots directly, so neither the order, nor its inverse, nor index_ray / index_tri / ray-major depths exist
 // for such a frame.  Values are pack_samples_kernel's bit for bit (tests).
+template <bool kTri>
 __global__ __launch_bounds__(64) void pack_tiles_kernel(
     const float *__restrict__ rays_o, const float *__restrict__ rays_d, int w, int h, int tiles_x, int n_tiles, int max_hits,
     const int32_t *__restrict__ hit_tri, const float *__restrict__ hit_t, const int32_t *__restrict__ hit_count,
     const int64_t *__restrict__ tile_base, const int64_t *__restrict__ total, float *__restrict__ xyz_c,
-    float *__restrict__ dirs_c, float *__restrict__ depth_c, const uint64_t *__restrict__ keep_mask,
+    float *__restrict__ dirs_c, float *__restrict__ depth_c, int64_t *__restrict__ tri_c, const uint64_t *__restrict__ keep_mask,
     const int32_t *__restrict__ raw_count, float min_sep, int32_t *__restrict__ final_count, int32_t *__restrict__ dropped)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int K = max_hits, Kp = max_hits | 1;            // odd row stride: conflict-free column access
-    float *s_t = reinterpret_cast<float *>(smem);             // distances only: the triangle ids are not part of the output,
-                                                              // and hits with equal t are the same sample in either order
+    // kTri = false: distances only -- the triangle ids are not part of the output then, and hits with equal t are the
+    // same sample in either order.  kTri = true (tri_c wanted: baked-texture frames look their texels up by triangle):
+    // ids staged too and the lists sorted by (t, tri) like everywhere else, so that ties resolve to the same triangle.
+    float *s_t = reinterpret_cast<float *>(smem);
+    int32_t *s_tri = reinterpret_cast<int32_t *>(s_t + 64 * Kp);
     const int tile = blockIdx.x, lane = threadIdx.x;
     const int px0 = (tile % tiles_x) * 8, py0 = (tile / tiles_x) * 8;
     const int cols = (w - px0) < 8 ? (w - px0) : 8, rows = (h - py0) < 8 ? (h - py0) : 8;
@@ -934,26 +938,34 @@ __global__ __launch_bounds__(64) void pack_tiles_kernel(
         for (int i = lane; i < cols * deepest; i += 64) {
             const int r = i / deepest, k = i - r * deepest;
             s_t[(yy * 8 + r) * Kp + k] = hit_t[(row_ray0 + r) * K + k];
+            if (kTri) s_tri[(yy * 8 + r) * Kp + k] = hit_tri[(row_ray0 + r) * K + k];
         }
     }
     __syncthreads();
 
     float *row_t = s_t + lane * Kp;
+    int32_t *row_i = s_tri + lane * Kp;                       // only touched when kTri
     double o64[3] = {0.0, 0.0, 0.0}, d64[3] = {0.0, 0.0, 0.0};
     float dn[3] = {0.0f, 0.0f, 0.0f};
     int n_dropped = 0;
     if (inside) {
-        for (int i = 1; i < cnt; ++i) {                       // t ascending (ties: equal samples)
+        for (int i = 1; i < cnt; ++i) {                       // t (or (t, tri)) ascending
             const float t = row_t[i];
+            const int id = kTri ? row_i[i] : 0;
             int j = i - 1;
-            while (j >= 0 && t < row_t[j]) { row_t[j + 1] = row_t[j]; --j; }
+            while (j >= 0 && (kTri ? hit_less(t, id, row_t[j], row_i[j]) : t < row_t[j])) {
+                row_t[j + 1] = row_t[j];
+                if (kTri) row_i[j + 1] = row_i[j];
+                --j;
+            }
             row_t[j + 1] = t;
+            if (kTri) row_i[j + 1] = id;
         }
         if (keep_mask) {                                      // the re-origin rule, decided by qf_bvh_repair_overflow
             const uint64_t mask = keep_mask[ray];
             int kept = 0;
             for (int i = 0; i < cnt; ++i)
-                if ((mask >> i) & 1ull) { row_t[kept] = row_t[i]; ++kept; }
+                if ((mask >> i) & 1ull) { row_t[kept] = row_t[i]; if (kTri) row_i[kept] = row_i[i]; ++kept; }
             cnt = kept;
         } else if (min_sep > 0.0f && cnt > 1) {
             // the re-origin rule on the sorted list, as filter_hits_kernel applies it: a hit is kept iff it is the first
@@ -963,7 +975,7 @@ __global__ __launch_bounds__(64) void pack_tiles_kernel(
             int kept = 1;
             for (int i = 1; i < cnt; ++i) {
                 const float t = row_t[i];
-                if (t > last_t + min_sep) { row_t[kept] = t; ++kept; last_t = t; }
+                if (t > last_t + min_sep) { row_t[kept] = t; if (kTri) row_i[kept] = row_i[i]; ++kept; last_t = t; }
             }
             n_dropped = cnt - kept;
             cnt = kept;
@@ -989,10 +1001,16 @@ __global__ __launch_bounds__(64) void pack_tiles_kernel(
             if (!sorted) {                                     // rare: stable insertion by depth, depths recomputed
                 for (int i = 1; i < cnt; ++i) {
                     const float t = row_t[i];
+                    const int id = kTri ? row_i[i] : 0;
                     const double di = sample_depth64(t, o64, d64, p);
                     int j = i - 1;
-                    while (j >= 0 && sample_depth64(row_t[j], o64, d64, p) > di) { row_t[j + 1] = row_t[j]; --j; }
+                    while (j >= 0 && sample_depth64(row_t[j], o64, d64, p) > di) {
+                        row_t[j + 1] = row_t[j];
+                        if (kTri) row_i[j + 1] = row_i[j];
+                        --j;
+                    }
                     row_t[j + 1] = t;
+                    if (kTri) row_i[j + 1] = id;
                 }
             }
         }
@@ -1015,6 +1033,7 @@ __global__ __launch_bounds__(64) void pack_tiles_kernel(
             dirs_c[c * 3 + 1] = dn[1];
             dirs_c[c * 3 + 2] = dn[2];
             depth_c[c] = (float)dep;
+            if (kTri) tri_c[c] = (int64_t)row_i[k];
             if (k == 0) { first_xyz[0] = (float)p[0]; first_xyz[1] = (float)p[1]; first_xyz[2] = (float)p[2]; }
         }
         base += __popcll(mask);
@@ -1027,10 +1046,12 @@ __global__ __launch_bounds__(64) void pack_tiles_kernel(
         const int src = __ffsll((long long)__ballot(cnt > 0)) - 1;       // a tile that dropped something kept something
         const float gx = __shfl(first_xyz[0], src, 64), gy = __shfl(first_xyz[1], src, 64), gz = __shfl(first_xyz[2], src, 64);
         const float hx = __shfl(dn[0], src, 64), hy = __shfl(dn[1], src, 64), hz = __shfl(dn[2], src, 64);
+        const int gtri = kTri ? __shfl((int)row_i[0], src, 64) : 0;
         for (int64_t c = base + lane; c < end; c += 64) {
             xyz_c[c * 3 + 0] = gx; xyz_c[c * 3 + 1] = gy; xyz_c[c * 3 + 2] = gz;
             dirs_c[c * 3 + 0] = hx; dirs_c[c * 3 + 1] = hy; dirs_c[c * 3 + 2] = hz;
             depth_c[c] = 0.0f;
+            if (kTri) tri_c[c] = (int64_t)gtri;
         }
         int sum = n_dropped;
 #pragma unroll
@@ -1536,24 +1557,33 @@ extern "C" int qf_pack_samples(const float *rays_o, const float *rays_d, int64_t
 
 extern "C" int qf_pack_tiles(const float *rays_o, const float *rays_d, int32_t width, int32_t height, int32_t max_hits,
                              const int32_t *hit_tri, const float *hit_t, const int32_t *hit_count, const int64_t *tile_base,
-                             const int64_t *total, float *xyz_c, float *dirs_c, float *depth_c, const uint64_t *keep_mask,
-                             const int32_t *raw_count, float min_separation, int32_t *final_count, int32_t *dropped,
-                             int64_t *host_out, void *stream)
+                             const int64_t *total, float *xyz_c, float *dirs_c, float *depth_c, int64_t *tri_c,
+                             const uint64_t *keep_mask, const int32_t *raw_count, float min_separation,
+                             int32_t *final_count, int32_t *dropped, int64_t *host_out, void *stream)
 {
     if ((keep_mask == nullptr) != (raw_count == nullptr)) return QF_ERR_INVALID_ARGUMENT;
     if (width < 1 || height < 1 || max_hits < 1 || max_hits > kMaxHits) return QF_ERR_INVALID_ARGUMENT;
-    if (!rays_o || !rays_d || !hit_tri || !hit_t || !hit_count || !tile_base || !total || !xyz_c || !dirs_c || !depth_c)
+    if (!rays_o || !rays_d || !hit_t || !hit_count || !tile_base || !total || !xyz_c || !dirs_c || !depth_c)
         return QF_ERR_INVALID_ARGUMENT;
+    if (tri_c && !hit_tri) return QF_ERR_INVALID_ARGUMENT;
     const bool rule_here = !keep_mask && min_separation > 0.0f;
     if (rule_here && (!final_count || !dropped)) return QF_ERR_INVALID_ARGUMENT;     // the counts change: they must go somewhere
     if (host_out && !dropped) return QF_ERR_INVALID_ARGUMENT;
     hipStream_t st = qf_stream(stream);
     if (dropped) QF_HIP_TRY(hipMemsetAsync(dropped, 0, sizeof(int32_t), st));
     const int tiles_x = (width + 7) / 8, tiles_y = (height + 7) / 8;
-    const size_t lds = (size_t)64 * (max_hits | 1) * 4;
-    hipLaunchKernelGGL(pack_tiles_kernel, dim3((unsigned)(tiles_x * tiles_y)), dim3(64), lds, st, rays_o, rays_d, (int)width,
-                       (int)height, tiles_x, tiles_x * tiles_y, (int)max_hits, hit_tri, hit_t, hit_count, tile_base, total,
-                       xyz_c, dirs_c, depth_c, keep_mask, raw_count, rule_here ? min_separation : 0.0f, final_count, dropped);
+    const float sep = rule_here ? min_separation : 0.0f;
+    if (tri_c) {
+        hipLaunchKernelGGL(pack_tiles_kernel<true>, dim3((unsigned)(tiles_x * tiles_y)), dim3(64), (size_t)64 * (max_hits | 1) * 8, st,
+                           rays_o, rays_d, (int)width, (int)height, tiles_x, tiles_x * tiles_y, (int)max_hits, hit_tri, hit_t,
+                           hit_count, tile_base, total, xyz_c, dirs_c, depth_c, tri_c, keep_mask, raw_count, sep, final_count,
+                           dropped);
+    } else {
+        hipLaunchKernelGGL(pack_tiles_kernel<false>, dim3((unsigned)(tiles_x * tiles_y)), dim3(64), (size_t)64 * (max_hits | 1) * 4, st,
+                           rays_o, rays_d, (int)width, (int)height, tiles_x, tiles_x * tiles_y, (int)max_hits, hit_tri, hit_t,
+                           hit_count, tile_base, total, xyz_c, dirs_c, depth_c, tri_c, keep_mask, raw_count, sep, final_count,
+                           dropped);
+    }
     if (host_out) hipLaunchKernelGGL(publish_dropped_kernel, dim3(1), dim3(1), 0, st, dropped, host_out);
     QF_LAUNCH_CHECK();
     return QF_OK;

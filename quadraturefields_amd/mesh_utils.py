@@ -344,7 +344,7 @@ class RayIntersector:
         hit_count._qf_keep = (mask, raw) if mask is not None else None
 
     def pack_hits(self, o, d, k, hit_tri, hit_t, hit_count, overflow, width, lean=False, layout=True,
-                  defer_rule_check=False):
+                  defer_rule_check=False, want_tri=False):
         """Per-ray hit lists -> ([xyzs, dirs, index_ray, ts, index_tri, origins] or None, coherent order or None).
 
         The output size is data dependent.  Instead of stalling on it, the offsets are scanned on the device, the
@@ -354,16 +354,17 @@ class RayIntersector:
         ``overflow`` (from ``_hits_raster_frame``) counts candidates beyond K; those rays were already repaired on the
         device, the count only steers the intersector policy.  ``pack_hits_begin`` / ``pack_hits_end`` are the two halves, for callers
         that keep several frames in flight on different streams."""
-        return self.pack_hits_end(self.pack_hits_begin(o, d, k, hit_tri, hit_t, hit_count, overflow, width, lean, layout),
-                                  defer_rule_check)
+        return self.pack_hits_end(self.pack_hits_begin(o, d, k, hit_tri, hit_t, hit_count, overflow, width, lean, layout,
+                                                       want_tri), defer_rule_check)
 
     @_on_device
-    def pack_hits_begin(self, o, d, k, hit_tri, hit_t, hit_count, overflow, width, lean=False, layout=True):
+    def pack_hits_begin(self, o, d, k, hit_tri, hit_t, hit_count, overflow, width, lean=False, layout=True,
+                        want_tri=False):
         """Enqueue scan, readback, pack and ordering on the current stream; no host wait.  ``lean`` (image-shaped
         batches only): a caller that only renders reads the streamed copies in ``last_layout`` / ``last_frame``, so the
         tile kernel (``qf_pack_tiles``) writes just those and the six ray-major arrays come back as None.
-        ``layout=False``: no processing order at all (callers that do not evaluate a field on the samples, e.g. the
-        baked-texture render)."""
+        ``want_tri`` (lean frames): also the samples' triangle ids in that order (``last_frame.tri_c``; the baked-texture
+        render looks its texels up by triangle).  ``layout=False``: no processing order at all."""
         n = o.shape[0]
         dev = self.device
         buf, temp, host, (ev, ev_flag) = self._frame_scratch(n)
@@ -394,7 +395,7 @@ class RayIntersector:
             dirs_c = torch.empty((cap, 3), dtype=torch.float32, device=dev)
             depth_c = torch.empty((cap,), dtype=torch.float32, device=dev)
             frame = SimpleNamespace(depth_c=depth_c, hit_count=hit_count, max_hits=int(k), tile_base=tile_base,
-                                    width=int(width), height=n // int(width), total=0)
+                                    width=int(width), height=n // int(width), total=0, tri_c=None)
         if lean:
             # render-only frame: the tile kernel writes the coherent copies directly; no ray-major arrays, no order,
             # no inverse map exist for it (the six sample arrays come back as None).  It also applies the re-origin
@@ -404,10 +405,12 @@ class RayIntersector:
             optimistic = False
             final_count = torch.empty((n,), dtype=torch.int32, device=dev)
             dropped = buf[n + 2:].view(torch.int32)[:1]
+            frame.tri_c = torch.empty((cap,), dtype=torch.int64, device=dev) if want_tri else None
             _C.check(_C.lib().qf_pack_tiles(_C.ptr(o), _C.ptr(d), int(width), n // int(width), k, _C.ptr(hit_tri),
                                             _C.ptr(hit_t), _C.ptr(hit_count), _C.ptr(tile_base), _C.ptr(buf[n:]),
-                                            _C.ptr(xyz_c), _C.ptr(dirs_c), _C.ptr(depth_c), _C.ptr(keep[0]),
-                                            _C.ptr(keep[1]), float(self.min_separation) if keep[0] is None else 0.0,
+                                            _C.ptr(xyz_c), _C.ptr(dirs_c), _C.ptr(depth_c), _C.ptr(frame.tri_c),
+                                            _C.ptr(keep[0]), _C.ptr(keep[1]),
+                                            float(self.min_separation) if keep[0] is None else 0.0,
                                             _C.ptr(final_count), _C.ptr(dropped), ctypes.c_void_p(host.data_ptr()),
                                             _C.stream()), "qf_pack_tiles")
             frame.hit_count = final_count
@@ -468,6 +471,8 @@ class RayIntersector:
         if layout is not None:      # (inverse or None, xyz, dirs) in the coherent order: see coherent_layout
             self.last_layout = tuple(None if t is None else t[:total] for t in layout)
             frame.depth_c = frame.depth_c[:total]
+            if frame.tri_c is not None:
+                frame.tri_c = frame.tri_c[:total]
             frame.total = total               # slots of the coherent arrays (what the field kernel streams)
             # a render-only frame's tile pack applied the re-origin rule itself: its samples are the slots minus the
             # hits that dropped (host[2], there once ev_flag has passed -- read on demand by frame_samples())
@@ -520,10 +525,11 @@ class RayIntersector:
 
     @_on_device
     def sample_device(self, origins, vectors, max_hits: Optional[int] = None, image_width: int = 0, camera=None,
-                      lean: bool = False, layout: bool = True, defer_rule_check: bool = False):
+                      lean: bool = False, layout: bool = True, defer_rule_check: bool = False, want_tri: bool = False):
         """Packed, sorted samples on the device: [xyzs, dirs, index_ray, ts, index_tri, origins] -- the six
         tensors the reference's DataLoader hands to the renderers (nerf_synthetic.py:256-257) -- or None
-        when no ray hits anything."""
+        when no ray hits anything.  ``lean`` with a camera: a render-only frame -- six Nones; the samples are in
+        ``last_layout`` / ``last_frame`` (see ``pack_hits_begin``)."""
         k = self.max_hits if max_hits is None else int(max_hits)
         o = _as_device_f32(origins, self.device).reshape(-1, 3)
         d = _as_device_f32(vectors, self.device).reshape(-1, 3)
@@ -538,7 +544,7 @@ class RayIntersector:
             hit_tri, hit_t, hit_count = self._hits_bvh(o, d, k, image_width)
             overflow = None
         data, self.last_order = self.pack_hits(o, d, k, hit_tri, hit_t, hit_count, overflow, int(image_width), lean,
-                                               layout, defer_rule_check)
+                                               layout, defer_rule_check, want_tri)
         return data
 
     @_on_device

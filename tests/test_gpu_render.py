@@ -132,6 +132,25 @@ def test_baked_texture_render_matches_oracle(device):
         field, rays, data, uv=torch.from_numpy(uv).to(device), render_step_size=5e-3, mesh_intersect=mi,
         compressor=comp, discretize=True)
     assert torch.isfinite(out2[0]).all()
+    # the whole-frame driver keeps a camera frame in the intersector's tile order (tile pack with triangle ids, texel
+    # lookup, shading, tile compositor): the same pixels and sample count as the reference-shaped function, bit for bit
+    from quadraturefields_amd.mesh_utils import make_camera
+    from quadraturefields_amd.render import FrameRenderer
+    c2w = synthetic.orbit_cameras(1, seed=4)[0]
+    focal = synthetic.lego_focal(800) * w / 800.0
+    o2, d2 = synthetic.camera_rays(c2w, focal, w, h)
+    rays2 = Rays(origins=o2, viewdirs=d2)
+    data2 = mi.sampling_raytrace_device(d2, o2)
+    ref = utils.render_image_bake_texture_images_with_occgrid(
+        field, rays2, data2, uv=torch.from_numpy(uv).to(device), render_step_size=5e-3, mesh_intersect=mi, compressor=comp)
+    fr = FrameRenderer(mi, field)
+    rgb_f, alpha_f, depth_f, n_f = fr.render_baked(o2.to(device), d2.to(device), torch.from_numpy(uv).to(device), comp,
+                                                   camera=make_camera(c2w, focal, w, h))
+    assert n_f == ref[3] and mi.rayintersector.last_frame.tri_c is not None
+    assert torch.equal(rgb_f, ref[0].reshape(-1, 3)) and torch.equal(alpha_f, ref[1].reshape(-1, 1))
+    assert torch.equal(depth_f, ref[2].reshape(-1, 1))
+    rgb_g = fr.render_baked(o2.to(device), d2.to(device), torch.from_numpy(uv).to(device), comp, image_width=w)[0]
+    assert torch.equal(rgb_g, rgb_f)                       # without a camera: the ray-major route
 
 
 def test_frame_renderer_and_upsample(device):
