@@ -497,6 +497,17 @@ int qf_composite_tiles(const float *rgb_c /* [n,3] */, const float *sigma_c /* [
                        const float *bkgd /* [3] or NULL */, float *out_rgb, float *out_alpha, float *out_depth,
                        float *weights_c, void *stream);
 
+/* The "before" evaluation of a frame in the coherent order (train_finetune.py:696; utils.py:555-572 + the re-sort of
+ * mesh_utils.py:389-403): every sample is displaced along its ray by tanh(f) * scaling -- f_c [n] = the deformation
+ * field's output at xyz_c (qf_deform_field_forward) -- and each ray's samples are put back in depth order (stable by
+ * the new fp32 depth), all inside the tile layout: xyz_out / depth_out [n] take the place of xyz_c / depth_c for
+ * qf_field_forward and qf_composite_tiles (directions do not change; out of place).  hit_count = the kept counts
+ * (final_count of qf_pack_tiles), tile_base as there, total = the arrays' slot count (host value).  The displacement is qf_apply_deformation's, bit for bit. */
+int qf_deform_resort_tiles(const float *f_c, float scaling, const float *xyz_c, const float *dirs_c,
+                           const float *depth_c, const int32_t *hit_count, int32_t max_hits, const int64_t *tile_base,
+                           int64_t total /* slots of the arrays */, int32_t width, int32_t height, float *xyz_out,
+                           float *depth_out, void *stream);
+
 /* Stable per-ray re-sort by depth after deformation (sampling_indexing, mesh_utils.py:394-403):
  * perm[i] = source index of the sample that lands at i.  index_ray must be grouped by ray.   */
 int qf_resort_by_depth(const int64_t *index_ray, const float *depth, int64_t n, int64_t *perm,

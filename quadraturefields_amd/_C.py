@@ -74,6 +74,7 @@ _SIGNATURES = {
     "qf_exponential_integration": (c_int, [_P, c_int32, _P, _P, c_int64, c_int64, c_int32, _P, _P, _P]),
     "qf_sum_reduce": (c_int, [_P, c_int32, _P, c_int64, c_int64, _P, _P]),
     "qf_derive_properties": (c_int, [_P, _P, _P, _P, c_float, _P, c_int64, c_int64, c_int32, _P, _P, _P, _P, _P, _P, _P]),
+    "qf_deform_resort_tiles": (c_int, [_P, c_float, _P, _P, _P, _P, c_int32, _P, c_int64, c_int32, c_int32, _P, _P, _P]),
     "qf_composite_tiles": (c_int, [_P, _P, _P, c_float, _P, c_int32, _P, c_int32, c_int32, c_int32, _P, _P, _P, _P, _P, _P]),
     "qf_derive_properties_backward": (c_int, [_P, _P, _P, _P, c_float, _P, c_int64, c_int64, c_int32, _P, _P, _P, _P, _P, _P, _P, _P]),
     "qf_pack_info": (c_int, [_P, c_int64, c_int64, _P, _P]),

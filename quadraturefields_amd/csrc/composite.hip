@@ -28,38 +28,54 @@ __global__ void fill_background_kernel(int64_t n_rays, float bg, float *rgb, flo
     }
 }
 
-// The per-ray arithmetic of derive_properties, with every rounding spelled out (no compiler-chosen contraction), so
-// that the chunked kernel, its long-ray tail and the per-ray kernel give the same bits whatever the optimiser does
-// around them: tau = sigma * delta; w = exp(-cum) * (1 - exp(-tau)); cum += tau; sums accumulate with one fma each.
+// The per-ray arithmetic of derive_properties with every rounding fixed, so that the chunked kernel, its long-ray tail
+// and the tile kernel give the same bits whatever the optimiser does around them: tau = sigma * delta;
+// w = exp(-cum) * (1 - exp(-tau)); cum += tau; the sums accumulate with one fma each.  (`#pragma clang fp contract(off)`
+// inside the bodies: HIP's __fmul_rn / __fadd_rn are plain operators, which the default -ffp-contract=fast may still
+// fuse with their neighbours after inlining; the fmas that are wanted are written as __builtin_fmaf.)
 struct RayAccum {
     float cum = 0.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f, cd = 0.0f, ca = 0.0f;
 };
 
-__device__ __forceinline__ float sample_tau(float sigma, float delta) { return __fmul_rn(sigma, delta); }
-__device__ __forceinline__ float sample_alpha(float tau) { return __fsub_rn(1.0f, expf(-tau)); }
+__device__ __forceinline__ float sample_tau(float sigma, float delta)
+{
+#pragma clang fp contract(off)
+    return sigma * delta;
+}
+
+__device__ __forceinline__ float sample_alpha(float tau)
+{
+#pragma clang fp contract(off)
+    return 1.0f - expf(-tau);
+}
 
 __device__ __forceinline__ float composite_step(RayAccum &a, float tau, float alpha, float r, float g, float b, float dep)
 {
-    const float w = __fmul_rn(expf(-a.cum), alpha);
-    a.cum = __fadd_rn(a.cum, tau);
-    a.cr = __fmaf_rn(w, r, a.cr);
-    a.cg = __fmaf_rn(w, g, a.cg);
-    a.cb = __fmaf_rn(w, b, a.cb);
-    a.cd = __fmaf_rn(w, dep, a.cd);
-    a.ca = __fadd_rn(a.ca, w);
+#pragma clang fp contract(off)
+    const float w = expf(-a.cum) * alpha;
+    a.cum = a.cum + tau;
+    a.cr = __builtin_fmaf(w, r, a.cr);
+    a.cg = __builtin_fmaf(w, g, a.cg);
+    a.cb = __builtin_fmaf(w, b, a.cb);
+    a.cd = __builtin_fmaf(w, dep, a.cd);
+    a.ca = a.ca + w;
     return w;
 }
 
 __device__ __forceinline__ void composite_blend(const RayAccum &a, int bg_mode, const float *bkgd, float out[3])
 {
+#pragma clang fp contract(off)
     const float c[3] = {a.cr, a.cg, a.cb};
-    const float rest = __fsub_rn(1.0f, a.ca);
+    const float rest = 1.0f - a.ca;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        if (bg_mode == QF_BG_WHITE) out[i] = __fmaf_rn(a.ca, c[i], rest);      // (1 - a) + a * sum(w c): the double-alpha quirk (B-1)
-        else if (bg_mode == QF_BG_BLACK) out[i] = __fmul_rn(a.ca, c[i]);
+        if (bg_mode == QF_BG_WHITE) out[i] = __builtin_fmaf(a.ca, c[i], rest);      // (1 - a) + a * sum(w c): the double-alpha quirk (B-1)
+        else if (bg_mode == QF_BG_BLACK) out[i] = a.ca * c[i];
         else if (bg_mode == QF_BG_NONE) out[i] = c[i];     // the plain sums (nerfacc's accumulate_along_rays): no blend, no quirk
-        else out[i] = __fmaf_rn(a.ca, c[i], __fmul_rn(rest, bkgd[i]));
+        else {
+            const float back = rest * bkgd[i];
+            out[i] = __builtin_fmaf(a.ca, c[i], back);
+        }
     }
 }
 
@@ -265,16 +281,32 @@ __global__ void render_from_density_kernel(const float *ts, const float *te, con
     }
 }
 
+// The displacement of one sample along its ray (utils.py:566-571), every operation rounded on its own as the
+// reference's tensor ops are (no contraction, see composite_step): v = tanh(f) * scaling; dd = (v dx + v dy) + v dz;
+// p += dd * d; t += dd.
+__device__ __forceinline__ void deform_sample(float f, float scaling, float dx, float dy, float dz, float &x, float &y,
+                                              float &z, float &t)
+{
+#pragma clang fp contract(off)
+    const float v = tanhf(f) * scaling;
+    const float vx = v * dx, vy = v * dy, vz = v * dz;
+    const float dd = (vx + vy) + vz;
+    const float mx = dd * dx, my = dd * dy, mz = dd * dz;
+    x = x + mx;
+    y = y + my;
+    z = z + mz;
+    t = t + dd;
+}
+
 __global__ void apply_deformation_kernel(const float *f, float scaling, const float *dirs, float *xyz, float *ts, int64_t n)
 {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const float v = tanhf(f[i]) * scaling;
-        const float dx = dirs[i * 3], dy = dirs[i * 3 + 1], dz = dirs[i * 3 + 2];
-        const float dd = (v * dx + v * dy) + v * dz;     // (del_vector * dirs).sum(-1), utils.py:567
-        xyz[i * 3 + 0] += dd * dx;
-        xyz[i * 3 + 1] += dd * dy;
-        xyz[i * 3 + 2] += dd * dz;
-        ts[i] += dd;
+        float x = xyz[i * 3], y = xyz[i * 3 + 1], z = xyz[i * 3 + 2], t = ts[i];
+        deform_sample(f[i], scaling, dirs[i * 3], dirs[i * 3 + 1], dirs[i * 3 + 2], x, y, z, t);
+        xyz[i * 3 + 0] = x;
+        xyz[i * 3 + 1] = y;
+        xyz[i * 3 + 2] = z;
+        ts[i] = t;
     }
 }
 
@@ -496,7 +528,102 @@ __global__ __launch_bounds__(64) void composite_tiles_kernel(
     out_depth[ray] = acc.cd;
 }
 
+// The "before" evaluation of a frame in the coherent order (train_finetune.py:696 -> utils.py:555-572 and the re-sort of
+// mesh_utils.py:389-403): displace every sample along its ray by the deformation field's output, then put each ray's
+// samples back in depth order -- a stable sort by the new fp32 depth, which is what np.lexsort((depth, ray)) does to a
+// ray's run.  One wave per 8x8 tile, lane = pixel: a ray's samples sit at the slots the ballots give its ranks, the
+// lane computes its <= K new depths into an LDS column, sorts (source rank, depth) there -- almost always already in
+// order -- and writes rank k's slot from the source it drew.  Out of place (xyz_out / depth_out); directions do not
+// change.  Slots past a tile's kept samples (re-origin gaps) are copied through.
+__global__ __launch_bounds__(64) void deform_resort_tiles_kernel(
+    const float *__restrict__ f_c, float scaling, const float *__restrict__ xyz_c, const float *__restrict__ dirs_c,
+    const float *__restrict__ depth_c, const int32_t *__restrict__ hit_count, int max_hits,
+    const int64_t *__restrict__ tile_base, int64_t total, int w, int h, int tiles_x, int n_tiles,
+    float *__restrict__ xyz_out, float *__restrict__ depth_out)
+{
+    extern __shared__ float dr_lds[];
+    const int K = max_hits;
+    float *col_t = dr_lds + threadIdx.x;                                  // [K][64] new depth of source rank k
+    int *col_s = reinterpret_cast<int *>(dr_lds + (size_t)K * 64) + threadIdx.x;      // [K][64] source rank at sorted place k
+    const int tile = blockIdx.x, lane = threadIdx.x;
+    int64_t ray = 0;
+    int cnt = 0;
+    if (tile_lane_ray(tile, lane, w, h, tiles_x, &ray)) cnt = hit_count[ray] < K ? hit_count[ray] : K;
+    const int64_t base0 = tile_base[tile];
+    const unsigned long long below = (1ull << lane) - 1ull;
+    // slot of rank k = base0 + (slots of the ranks before) + (pixels before this one that have a rank k): the per-rank
+    // offsets are wave-uniform, keep them in SGPR-like registers by recomputing the ballots in both passes
+    int64_t base = base0;
+    for (int k = 0;; ++k) {
+        const unsigned long long mask = __ballot(cnt > k);
+        if (mask == 0ull) break;
+        if (cnt > k) {
+            const int64_t c = base + __popcll(mask & below);
+            float x = xyz_c[c * 3], y = xyz_c[c * 3 + 1], z = xyz_c[c * 3 + 2], t = depth_c[c];
+            deform_sample(f_c[c], scaling, dirs_c[c * 3], dirs_c[c * 3 + 1], dirs_c[c * 3 + 2], x, y, z, t);
+            col_t[k * 64] = t;
+            col_s[k * 64] = k;
+        }
+        base += __popcll(mask);
+    }
+    const int64_t written_end = base;
+    for (int i = 1; i < cnt; ++i) {                           // stable insertion by the new depth
+        const float t = col_t[i * 64];
+        const int src = col_s[i * 64];
+        int j = i - 1;
+        while (j >= 0 && col_t[j * 64] > t) { col_t[(j + 1) * 64] = col_t[j * 64]; col_s[(j + 1) * 64] = col_s[j * 64]; --j; }
+        col_t[(j + 1) * 64] = t;
+        col_s[(j + 1) * 64] = src;
+    }
+    // second pass over the ranks: sorted place k lands in rank k's slot.  The depths go out first; their column then
+    // holds the ranks' slots (relative to the tile), which the sources are looked up through.
+    int *col_slot = reinterpret_cast<int *>(col_t);
+    base = base0;
+    for (int k = 0;; ++k) {
+        const unsigned long long mask = __ballot(cnt > k);
+        if (mask == 0ull) break;
+        if (cnt > k) {
+            const int64_t c = base + __popcll(mask & below);
+            depth_out[c] = col_t[k * 64];
+            col_slot[k * 64] = (int)(c - base0);
+        }
+        base += __popcll(mask);
+    }
+    for (int k = 0; k < cnt; ++k) {
+        const int64_t dst = base0 + col_slot[k * 64], src = base0 + col_slot[col_s[k * 64] * 64];
+        float x = xyz_c[src * 3], y = xyz_c[src * 3 + 1], z = xyz_c[src * 3 + 2], t = depth_c[src];
+        deform_sample(f_c[src], scaling, dirs_c[src * 3], dirs_c[src * 3 + 1], dirs_c[src * 3 + 2], x, y, z, t);
+        xyz_out[dst * 3 + 0] = x;
+        xyz_out[dst * 3 + 1] = y;
+        xyz_out[dst * 3 + 2] = z;
+    }
+    const int64_t end = tile + 1 < n_tiles ? tile_base[tile + 1] : total;
+    for (int64_t c = written_end + lane; c < end; c += 64) {  // re-origin gaps: finite points nobody composites
+        xyz_out[c * 3 + 0] = xyz_c[c * 3 + 0];
+        xyz_out[c * 3 + 1] = xyz_c[c * 3 + 1];
+        xyz_out[c * 3 + 2] = xyz_c[c * 3 + 2];
+        depth_out[c] = depth_c[c];
+    }
+}
+
 }  // namespace
+
+extern "C" int qf_deform_resort_tiles(const float *f_c, float scaling, const float *xyz_c, const float *dirs_c,
+                                      const float *depth_c, const int32_t *hit_count, int32_t max_hits,
+                                      const int64_t *tile_base, int64_t total, int32_t width, int32_t height,
+                                      float *xyz_out, float *depth_out, void *stream)
+{
+    if (width < 1 || height < 1 || max_hits < 1 || max_hits > 64) return QF_ERR_INVALID_ARGUMENT;
+    if (!f_c || !xyz_c || !dirs_c || !depth_c || !hit_count || !tile_base || total < 0 || !xyz_out || !depth_out)
+        return QF_ERR_INVALID_ARGUMENT;
+    if (xyz_out == xyz_c || depth_out == depth_c) return QF_ERR_INVALID_ARGUMENT;          // out of place
+    const int tiles_x = (width + 7) / 8, tiles_y = (height + 7) / 8;
+    hipLaunchKernelGGL(deform_resort_tiles_kernel, dim3(tiles_x * tiles_y), dim3(64), (size_t)max_hits * 64 * 8, qf_stream(stream),
+                       f_c, scaling, xyz_c, dirs_c, depth_c, hit_count, (int)max_hits, tile_base, total, (int)width, (int)height,
+                       tiles_x, tiles_x * tiles_y, xyz_out, depth_out);
+    QF_LAUNCH_CHECK();
+    return QF_OK;
+}
 
 extern "C" int qf_composite_tiles(const float *rgb_c, const float *sigma_c, const float *depth_c, float delta_const,
                                   const int32_t *hit_count, int32_t max_hits, const int64_t *tile_base, int32_t width,

@@ -5,12 +5,14 @@ This is the loop body of ``test()`` in ``examples/train_finetune.py:574-629`` (a
 intersection folded in: every stage is a device launch on the current stream, nothing returns to the host
 between the rays and the finished image except one 8-byte sample count.
 """
+import copy
 from typing import Optional
 
 import torch
 
 from . import utils
 from .datasets.utils import Rays
+from .field import Field as _Field
 
 
 class FrameRenderer:
@@ -40,9 +42,25 @@ class FrameRenderer:
         n_rays = origins.shape[0]
         if camera is not None:
             image_width = camera.width
+        ri = self.mesh_intersect.rayintersector
+        if self.field_net is not None and scaling != 0 and camera is not None and isinstance(self.field_net, _Field):
+            # the "before" evaluation of a camera frame, in the tile order throughout: tile pack -> deformation field
+            # (streams) -> displacement + per-ray re-sort inside the tiles -> field -> tile compositor.  Same pixels
+            # as render_image_finetune_with_occgrid on the ray-major samples, bit for bit (tested).
+            data = ri.sample_device(origins, viewdirs, self.mesh_intersect.num_intersections, image_width, camera, lean=True)
+            if data is not None and ri.last_frame is not None:
+                frame = ri.last_frame
+                _, xyz_c, dirs_c = ri.last_layout
+                f = self.field_net(xyz_c, return_grad=False)[0]
+                xyz_s, depth_s = utils.deform_frame(f, scaling, xyz_c, dirs_c, frame)
+                rgbs, sigmas = self.radiance_field(xyz_s, dirs_c)
+                moved = copy.copy(frame)
+                moved.depth_c = depth_s
+                rgb, alpha, depth, _ = utils.composite_frame(rgbs, sigmas, moved, self.render_step_size,
+                                                             render_bkgd=render_bkgd, bg_color=self.bg_color)
+                return rgb, alpha, depth, ri.frame_samples()
         # without deformation only the streamed copies are read: skip the ray-major position arrays
         lean = self.field_net is None or scaling == 0
-        ri = self.mesh_intersect.rayintersector
         # lean frames let the intersector verify its optimistic re-origin rule AFTER the field / compositing launches
         data = ri.sample_device(origins, viewdirs, self.mesh_intersect.num_intersections, image_width, camera, lean=lean,
                                 defer_rule_check=lean)

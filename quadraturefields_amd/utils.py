@@ -159,6 +159,25 @@ def composite_frame(color_c, density_c, frame, render_step_size: float, render_b
     return rgb, alpha, depth, weights
 
 
+@torch.no_grad()
+def deform_frame(f_c, scaling: float, xyz_c, dirs_c, frame):
+    """The "before" evaluation's displacement + re-sort (utils.py:555-572, mesh_utils.py:389-403) on a frame in the
+    intersector's coherent order: ``f_c`` = the deformation field's output at ``xyz_c``; returns (xyz, depth) in the
+    same order, every ray's samples displaced by ``tanh(f) * scaling`` along the ray and back in depth order
+    (``qf_deform_resort_tiles``).  Inference only."""
+    f_c = _C.f32c(f_c.detach().reshape(-1))
+    n = frame.total
+    if f_c.shape[0] != n or xyz_c.shape[0] != n:
+        raise ValueError(f"deform_frame: {n} slots in the frame, {f_c.shape[0]} field outputs, {xyz_c.shape[0]} positions")
+    xyz_out = torch.empty_like(xyz_c)
+    depth_out = torch.empty_like(frame.depth_c)
+    _C.check(_C.lib().qf_deform_resort_tiles(
+        _C.ptr(f_c), float(scaling), _C.ptr(_C.f32c(xyz_c)), _C.ptr(_C.f32c(dirs_c)), _C.ptr(frame.depth_c),
+        _C.ptr(frame.hit_count), frame.max_hits, _C.ptr(frame.tile_base), n, frame.width, frame.height, _C.ptr(xyz_out),
+        _C.ptr(depth_out), _C.stream()), "qf_deform_resort_tiles")
+    return xyz_out, depth_out
+
+
 def _flatten_rays(rays: Rays):
     rays_shape = rays.origins.shape
     if len(rays_shape) == 3:

@@ -100,6 +100,29 @@ def test_deformed_render_matches_oracle(device):
     assert torch.allclose(out[5].cpu(), pts_o, atol=2e-6)
     assert (out[0].cpu() - rgb_o).abs().max().item() <= 3e-4
     assert out[7].shape == (1,)
+    # the frame driver runs the same evaluation inside the intersector's tile order (tile pack, streamed deformation
+    # field, displacement + re-sort within the tiles, field, tile compositor): bit-identical pixels, for the script's
+    # scaling and for one large enough to swap neighbours
+    from quadraturefields_amd.mesh_utils import make_camera
+    from quadraturefields_amd.render import FrameRenderer
+    c2w = synthetic.orbit_cameras(1, seed=2)[0]
+    focal = synthetic.lego_focal(800) * w / 800.0
+    o2, d2 = synthetic.camera_rays(c2w, focal, w, h)
+    fr = FrameRenderer(mi, field, field_net=net)
+    for sc in (0.0434, scaling, 1.5):
+        data2 = mi.sampling_raytrace_device(d2, o2)
+        ref = utils.render_image_finetune_with_occgrid(field, net, None, Rays(origins=o2, viewdirs=d2), data2,
+                                                       render_step_size=5e-3, mesh_intersect=mi, scaling=sc)
+        rgb_f, alpha_f, depth_f, n_f = fr.render(o2.to(device), d2.to(device), scaling=sc, camera=make_camera(c2w, focal, w, h))
+        assert n_f == ref[3]
+        assert torch.equal(rgb_f, ref[0].reshape(-1, 3)) and torch.equal(alpha_f, ref[1].reshape(-1, 1))
+        assert torch.equal(depth_f, ref[2].reshape(-1, 1))
+    # (1.5 moves samples by up to a whole scene radius: the per-ray order does change)
+    pts = ref[5]
+    ridx = ref[6]
+    t_before = (data2[0] - data2[5]).norm(dim=-1)
+    same = data2[2][1:] == data2[2][:-1]
+    assert bool((torch.diff(t_before)[same] >= 0).all())
 
 
 def test_baked_texture_render_matches_oracle(device):
