@@ -619,32 +619,49 @@ __global__ __launch_bounds__(kSelectBlock) void select_nearest_kernel(int64_t n_
         }
         return;
     }
-    // the `held` nearest candidates under (t, tri); all of them when cnt <= cap
+    // the `held` nearest candidates under (t, tri) (all of them when cnt <= cap), kept SORTED in the column as they
+    // arrive: an insertion shifts half the column on average, about what re-finding the maximum after a replacement
+    // cost, and there is no sort left to do afterwards.  The candidates are read eight slots at a time: one slot per
+    // pass is a dependent global load per pass, eight independent loads in flight cost the same latency once.
     const int held = cnt < cap ? cnt : cap;
-    float worst_t = -INFINITY;
-    int worst_i = -1, worst_slot = 0;
-    for (int i = 0; i < held; ++i) {
-        const float t = wide_t[(int64_t)i * n_rays + r];
-        const int id = wide_tri[(int64_t)i * n_rays + r];
-        lt[i * kSelectBlock] = t;
-        li[i * kSelectBlock] = id;
-        if (hit_less(worst_t, worst_i, t, id)) { worst_t = t; worst_i = id; worst_slot = i; }
-    }
-    for (int i = held; i < cnt; ++i) {
-        const float t = wide_t[(int64_t)i * n_rays + r];
-        const int id = wide_tri[(int64_t)i * n_rays + r];
-        if (!hit_less(t, id, worst_t, worst_i)) continue;
-        lt[worst_slot * kSelectBlock] = t;
-        li[worst_slot * kSelectBlock] = id;
-        worst_t = -INFINITY;
-        worst_i = -1;
-        for (int s = 0; s < held; ++s) {
-            const float ts = lt[s * kSelectBlock];
-            const int is = li[s * kSelectBlock];
-            if (hit_less(worst_t, worst_i, ts, is)) { worst_t = ts; worst_i = is; worst_slot = s; }
+    constexpr int kBatch = 8;
+    int n = 0;
+    float max_t = -INFINITY;                 // the column's last (largest) entry, in registers for the common reject
+    int max_i = -1;
+    for (int i0 = 0; i0 < cnt; i0 += kBatch) {
+        float tb[kBatch];
+        int ib[kBatch];
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u) {
+            const int i = i0 + u < cnt ? i0 + u : cnt - 1;
+            tb[u] = wide_t[(int64_t)i * n_rays + r];
+            ib[u] = wide_tri[(int64_t)i * n_rays + r];
+        }
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u) {
+            if (i0 + u >= cnt) break;
+            const float t = tb[u];
+            const int id = ib[u];
+            int j;
+            if (n < held) {
+                j = n - 1;
+                ++n;
+            } else {
+                if (!hit_less(t, id, max_t, max_i)) continue;
+                j = n - 2;                   // the last entry falls out
+            }
+            while (j >= 0 && hit_less(t, id, lt[j * kSelectBlock], li[j * kSelectBlock])) {
+                lt[(j + 1) * kSelectBlock] = lt[j * kSelectBlock];
+                li[(j + 1) * kSelectBlock] = li[j * kSelectBlock];
+                --j;
+            }
+            lt[(j + 1) * kSelectBlock] = t;
+            li[(j + 1) * kSelectBlock] = id;
+            max_t = lt[(n - 1) * kSelectBlock];
+            max_i = li[(n - 1) * kSelectBlock];
         }
     }
-    if (min_sep <= 0.0f) {                   // held == K: arrival order, qf_pack_samples sorts
+    if (min_sep <= 0.0f) {                   // held == K: any order will do, qf_pack_samples sorts (this one is sorted)
         for (int i = 0; i < max_hits; ++i) {
             row_t[i] = lt[i * kSelectBlock];
             row_i[i] = li[i * kSelectBlock];
@@ -653,22 +670,9 @@ __global__ __launch_bounds__(kSelectBlock) void select_nearest_kernel(int64_t n_
         return;
     }
     // The re-origin rule (bvh8_traverse_kernel) runs over a ray's hits in ascending order, so the K nearest alone do
-    // not decide it: every hit the chain drops lets a farther one in.  Sort the held prefix of the ray's hits and run
-    // the chain over it.  K kept hits are the answer whatever lies behind; fewer are the answer only if the prefix
-    // was the whole list.  Otherwise the ray goes to the paged BVH traversal (count > K marks it for
-    // qf_bvh_repair_overflow).
-    for (int i = 1; i < held; ++i) {
-        const float t = lt[i * kSelectBlock];
-        const int id = li[i * kSelectBlock];
-        int j = i - 1;
-        while (j >= 0 && hit_less(t, id, lt[j * kSelectBlock], li[j * kSelectBlock])) {
-            lt[(j + 1) * kSelectBlock] = lt[j * kSelectBlock];
-            li[(j + 1) * kSelectBlock] = li[j * kSelectBlock];
-            --j;
-        }
-        lt[(j + 1) * kSelectBlock] = t;
-        li[(j + 1) * kSelectBlock] = id;
-    }
+    // not decide it: every hit the chain drops lets a farther one in.  Run the chain over the held prefix of the
+    // ray's hits.  K kept hits are the answer whatever lies behind; fewer are the answer only if the prefix was the
+    // whole list.  Otherwise the ray goes to the paged BVH traversal (count > K marks it for qf_bvh_repair_overflow).
     float last_t = lt[0];
     int kept = 1;                            // compacted in place: slot `kept` never runs ahead of slot i
     for (int i = 1; i < held && kept < max_hits; ++i) {
