@@ -27,10 +27,11 @@ import torch.distributed as dist
 
 TILE = 8
 BAND_ALIGN = 8
-#: relative cost of a row: COST_RAY per pixel + COST_OBJECT per pixel that hit the object (alpha > 0).  From the
-#: single-GPU stage times: ~10 quadrature points x 0.39 ns of field + compositing per object ray, ~0.15 ns of
-#: pack / compositing set-up per ray.
-COST_RAY, COST_OBJECT = 0.15, 3.9
+#: relative cost of a row: COST_RAY per pixel + COST_SAMPLE per quadrature point of the row (the bands report their
+#: per-row sample counts along with their pixels).  From the single-GPU stage times: 0.39 ns of pack + field +
+#: compositing per point, ~0.15 ns of set-up per ray.  COST_OBJECT per pixel that hit the object (alpha > 0) stands in
+#: for the points (~10 per object ray) when a renderer reports no counts.
+COST_RAY, COST_SAMPLE, COST_OBJECT = 0.15, 0.39, 3.9
 
 
 # ----------------------------------------------------------------------------------------------------------
@@ -80,20 +81,30 @@ def band_camera(c2w, focal: float, width: int, height: int, y0: int, y1: int):
 
 
 def gather_bands(local: torch.Tensor, cuts: Sequence[int], width: int, rank: int, world_size: int,
-                 async_op: bool = False):
+                 async_op: bool = False, meta: Optional[torch.Tensor] = None):
     """local [rows_r * width, C] (this rank's band, row-major) -> the full frame [H * width, C] on every rank with
     one ``all_gather_into_tensor`` of the bands padded to the tallest band.  ``async_op``: returns a zero-argument
     callable instead; the collective runs on the backend's own stream (RCCL) beside whatever is launched next, and
-    calling the callable makes the current stream wait for it and assembles the frame."""
+    calling the callable makes the current stream wait for it and assembles the frame.
+    ``meta`` (every rank or none): float32 [rows_r], one number per row of the band (the band's per-row sample counts);
+    it rides in a few extra padded rows of the same collective and comes back as [H]: the result is then
+    ``(frame, meta_of_every_row)``."""
     rows = [cuts[r + 1] - cuts[r] for r in range(world_size)]
     if local.shape[0] != rows[rank] * width:
         raise ValueError(f"rank {rank}: band has {local.shape[0]} rays, expected {rows[rank] * width}")
+    if meta is not None and meta.numel() != rows[rank]:
+        raise ValueError(f"rank {rank}: meta has {meta.numel()} entries, expected {rows[rank]}")
     if world_size == 1:
-        return (lambda: local) if async_op else local
+        result = local if meta is None else (local, meta.to(torch.float32).reshape(-1))
+        return (lambda: result) if async_op else result
     c = local.shape[1]
-    cap = max(rows) * width
-    send = local if local.shape[0] == cap else torch.cat(
-        [local, torch.zeros((cap - local.shape[0], c), dtype=local.dtype, device=local.device)])
+    band_cap = max(rows) * width
+    meta_rays = 0 if meta is None else ((max(rows) + c - 1) // c + width - 1) // width * width      # whole padded rows
+    cap = band_cap + meta_rays
+    send = torch.zeros((cap, c), dtype=local.dtype, device=local.device)
+    send[:local.shape[0]] = local
+    if meta is not None:
+        send[band_cap:].view(-1)[:rows[rank]] = meta.to(device=local.device, dtype=local.dtype).reshape(-1)
     staged = local.is_cuda and dist.get_backend() == "gloo"     # rehearsal on one GPU: gloo moves host memory
     if staged:
         send = send.cpu()
@@ -106,7 +117,11 @@ def gather_bands(local: torch.Tensor, cuts: Sequence[int], width: int, rank: int
             work.wait()                       # current stream waits for the collective; send / buf stay referenced here
         b = buf.view(world_size, cap, c)
         frame = torch.cat([b[r, :rows[r] * width] for r in range(world_size)], dim=0)
-        return frame.to(local.device) if staged else frame
+        frame = frame.to(local.device) if staged else frame
+        if meta is None:
+            return frame
+        m = torch.cat([b[r, band_cap:].reshape(-1)[:rows[r]] for r in range(world_size)], dim=0)
+        return frame, (m.to(local.device) if staged else m)
 
     return finish if async_op else finish()
 
@@ -142,6 +157,9 @@ class ShardedFrameRenderer:
         cam = band_camera(c2w, focal, width, height, y0, y1)
         o, d = origins[y0 * width:y1 * width], viewdirs[y0 * width:y1 * width]
         rgb, alpha, depth, _ = self.renderer.render(o, d, camera=cam)
+        # the band's quadrature points per row, for the next frames' cuts (a renderer without the hook reports none)
+        hook = getattr(self.renderer, "row_samples", None)
+        self._band_samples = hook() if callable(hook) else None
         return torch.cat([rgb, alpha, depth], dim=1)
 
     def render(self, origins, viewdirs, c2w, focal, width: int, height: int) -> torch.Tensor:
@@ -154,37 +172,52 @@ class ShardedFrameRenderer:
         if origins.shape[0] != width * height:
             raise ValueError("origins / viewdirs must be the frame's full row-major ray arrays")
         cuts = self.last_cuts = self.cuts_for(height)
+        self._band_samples = None
+        rows = cuts[self.rank + 1] - cuts[self.rank]
         local = self.render_band(origins, viewdirs, c2w, focal, width, height, cuts[self.rank], cuts[self.rank + 1])
-        pending = gather_bands(local, cuts, width, self.rank, self.world, async_op=True)
+        meta = None
+        if self.balance:                      # every rank sends its counts (zeros when its renderer reports none)
+            meta = self._band_samples
+            if meta is None or meta.numel() != rows:
+                meta = torch.full((rows,), -1.0, dtype=torch.float32, device=local.device)
+        pending = gather_bands(local, cuts, width, self.rank, self.world, async_op=True, meta=meta)
 
         def finish():
-            frame = pending()
-            if self.balance:
-                self._push_profile(frame, width, height)
+            if not self.balance:
+                return pending()
+            frame, row_samples = pending()
+            self._push_profile(frame, width, height, row_samples)
             return frame
 
         return finish
 
-    def _push_profile(self, frame, width, height):
-        rows = (frame[:, 3] > 0).view(height, width).sum(dim=1, dtype=torch.float32)
-        if rows.is_cuda:
+    def _push_profile(self, frame, width, height, row_samples=None):
+        """Per-row cost inputs of this frame -> pinned host memory; the profile of the frame rendered ``PROFILE_LAG``
+        calls earlier becomes ``row_cost``.  Row 0 of the pair: pixels with alpha > 0; row 1: quadrature points
+        (negative where a band's renderer reported none)."""
+        obj = (frame[:, 3] > 0).view(height, width).sum(dim=1, dtype=torch.float32)
+        smp = row_samples.to(torch.float32).reshape(-1) if row_samples is not None else torch.full_like(obj, -1.0)
+        both = torch.stack([obj, smp])
+        if both.is_cuda:
             ring = self._ring.get(height)
             if ring is None:      # PROFILE_LAG + 1 pinned buffers, reused round-robin (pinning per frame is slow)
-                ring = self._ring[height] = [[torch.empty((height,), dtype=torch.float32).pin_memory()
+                ring = self._ring[height] = [[torch.empty((2, height), dtype=torch.float32).pin_memory()
                                               for _ in range(self.PROFILE_LAG + 1)], 0]
             host = ring[0][ring[1] % len(ring[0])]
             ring[1] += 1
-            host.copy_(rows, non_blocking=True)
+            host.copy_(both, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record()
         else:
-            host, ev = rows.clone(), None
+            host, ev = both.clone(), None
         self._profiles.append((host, ev))
         if len(self._profiles) >= self.PROFILE_LAG:       # deterministic: the same frame's profile on every rank
             host, ev = self._profiles.pop(0)
             if ev is not None:
                 ev.synchronize()
-            self.row_cost = COST_RAY * width + COST_OBJECT * host.numpy().astype(np.float64)
+            obj_h, smp_h = host.numpy().astype(np.float64)
+            cost = COST_RAY * width + np.where(smp_h >= 0, COST_SAMPLE * smp_h, COST_OBJECT * obj_h)
+            self.row_cost = cost
 
 
 # ----------------------------------------------------------------------------------------------------------

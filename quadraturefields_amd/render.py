@@ -31,6 +31,16 @@ class FrameRenderer:
         self.bg_color = bg_color
 
     @torch.no_grad()
+    def row_samples(self):
+        """float32 [H]: quadrature points per pixel row of the frame (band) ``render`` just drew with a camera, or None
+        (no camera frame / nothing hit).  ``parallel.ShardedFrameRenderer`` balances its row bands with it."""
+        frame = self.mesh_intersect.rayintersector.last_frame
+        if frame is None:
+            return None
+        counts = frame.hit_count.clamp(max=frame.max_hits)
+        return counts.view(frame.height, frame.width).sum(dim=1, dtype=torch.float32)
+
+    @torch.no_grad()
     def quadrature_points(self, origins: torch.Tensor, viewdirs: torch.Tensor, image_width: int = 0, camera=None):
         """[xyzs, dirs, index_ray, ts, index_tri, origins] on the device (None if no hit)."""
         return self.mesh_intersect.sampling_raytrace_device(viewdirs, origins, image_width=image_width, camera=camera)

@@ -113,12 +113,20 @@ def _band_worker(rank, world, port, w, h, q):
         frame = sr.render(o, d, c2w, 50.0, w, h)
         ok = ok and torch.equal(frame, ref)
         cuts.append(list(sr.last_cuts))
+    # per-row numbers ride in the same collective (the bands' sample counts): uneven bands, more rows than one padded
+    # row of the payload holds
+    uneven = [0, 8 * (h // 24 + 1), h]
+    rows = uneven[rank + 1] - uneven[rank]
+    local = torch.full((rows * w, 5), float(rank))
+    fr, m = parallel.gather_bands(local, uneven, w, rank, world, meta=torch.arange(uneven[rank], uneven[rank + 1]).float())
+    ok = ok and torch.equal(m, torch.arange(h).float()) and fr.shape == (h * w, 5)
+    ok = ok and bool((fr[:uneven[1] * w] == 0).all()) and bool((fr[uneven[1] * w:] == 1).all())
     q.put((rank, ok, cuts))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("w,h", [(24, 64), (17, 43)])
+@pytest.mark.parametrize("w,h", [(24, 64), (17, 43), (2, 80)])
 def test_two_rank_band_render_and_gather(w, h):
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
