@@ -111,7 +111,8 @@ class Stages:
         here = torch.cuda.current_stream()
         here.wait_event(packed)           # no-op when begin() ran on this stream
         before = ri._raster_backoff
-        # the intersector's optimistic re-origin check is read after the field / compositing launches (rule_violated)
+        # (ray-major frames only: their optimistic re-origin check is read after the field / compositing launches --
+        # rule_violated below; the tile pack of a coherent frame applies the rule itself)
         data, order = ri.pack_hits_end(pending, defer_rule_check=True)
         if rastered and ri._raster_backoff > before:
             self.fallbacks = getattr(self, "fallbacks", 0) + 1

@@ -319,10 +319,11 @@ class RayIntersector:
         # round trip (afterwards every count is <= K).  With the reference's re-origin rule on, the same launch decides
         # it for every other ray as a keep-mask over its sorted list (the lists are not rewritten); the mask rides on
         # the count tensor to qf_pack_samples.
-        # The rule for the OTHER rays (complete lists) is applied optimistically: pack_hits packs as if it dropped
-        # nothing and verifies that exactly on the sorted lists (qf_pack_samples close_flag).  Only after a frame that
+        # The rule for the OTHER rays (complete lists): a render-only frame's tile pack applies it on its own sorted
+        # lists (qf_pack_tiles).  The ray-major pack applies it optimistically: pack_hits packs as if it dropped
+        # nothing and verifies that exactly on the sorted lists (qf_pack_samples close_flag); only after such a frame
         # did have a close pair (duplicated / near-coincident faces) the following RULE_UPFRONT_FRAMES frames decide it
-        # up front, per ray, in the repair launch (keep mask; ~0.05 ms per 800x800 frame).
+        # up front, per ray, in the repair launch (keep mask; ~0.03 ms per 800x800 frame).
         upfront = self.min_separation > 0 and self._rule_upfront > 0
         if upfront:
             self._rule_upfront -= 1

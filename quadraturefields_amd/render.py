@@ -71,7 +71,8 @@ class FrameRenderer:
                 return rgb, alpha, depth, ri.frame_samples()
         # without deformation only the streamed copies are read: skip the ray-major position arrays
         lean = self.field_net is None or scaling == 0
-        # lean frames let the intersector verify its optimistic re-origin rule AFTER the field / compositing launches
+        # a lean (render-only) frame's tile pack applies the re-origin rule itself; only the ray-major route below can
+        # come back with rule_violated() (its optimistic pack is verified after the field / compositing launches)
         data = ri.sample_device(origins, viewdirs, self.mesh_intersect.num_intersections, image_width, camera, lean=lean,
                                 defer_rule_check=lean)
         if data is None:
