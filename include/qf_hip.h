@@ -542,6 +542,15 @@ typedef struct qf_texture_set {
 int qf_texel_indices(const double *vertices, const int64_t *faces, const float *uv,
                      const float *points, const int64_t *index_tri, int64_t n,
                      int32_t texture_size, int64_t *texel, void *stream);
+/* The same lookup from a per-mesh table of 128-byte TRIANGLE RECORDS (corner, edges, their dot products and reciprocal
+ * determinant in float64, the three corners' uv): qf_texel_records_pack builds records [n_faces * 128 bytes] once per
+ * (mesh, uv); qf_texel_indices_packed then reads one line per sample instead of faces -> 3 vertices -> 3 uv.  Same
+ * texels (the per-triangle values are the ones qf_texel_indices recomputes for every sample).             */
+#define QF_TEXEL_TRIANGLE_RECORD_BYTES 128
+int qf_texel_records_pack(const double *vertices, const int64_t *faces, const float *uv, int64_t n_faces,
+                          void *records, void *stream);
+int qf_texel_indices_packed(const void *records, const float *points, const int64_t *index_tri, int64_t n,
+                            int32_t texture_size, int64_t *texel, void *stream);
 /* texel [n,2] -> features [n, 3+7L+1] = [diffuse3 | (axis3, lambda, colour3)*L | sigma].      */
 int qf_texture_fetch(const qf_texture_set *tex /* host */, const int64_t *texel, int64_t n,
                      float *features, void *stream);

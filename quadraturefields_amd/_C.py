@@ -16,6 +16,7 @@ QF_MAX_LEVELS = 16
 QF_MAX_LOBES = 8
 QF_BVH_MAX_HITS = 64
 QF_TEXEL_RECORD_BYTES = 64
+QF_TEXEL_TRIANGLE_RECORD_BYTES = 128
 HEAD_NONE, HEAD_NGP, HEAD_SG, HEAD_SG_FEATURES = 0, 1, 2, 3
 BG_WHITE, BG_BLACK, BG_CUSTOM, BG_NONE = 0, 1, 2, 3
 
@@ -119,6 +120,8 @@ _SIGNATURES = {
     "qf_resort_by_depth": (c_int, [_P, _P, c_int64, _P, _P]),
     "qf_resort_samples": (c_int, [_P, _P, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "qf_texel_indices": (c_int, [_P, _P, _P, _P, _P, c_int64, c_int32, _P, _P]),
+    "qf_texel_records_pack": (c_int, [_P, _P, _P, c_int64, _P, _P]),
+    "qf_texel_indices_packed": (c_int, [_P, _P, _P, c_int64, c_int32, _P, _P]),
     "qf_texture_fetch": (c_int, [POINTER(TextureSet), _P, c_int64, _P, _P]),
     "qf_texture_shade": (c_int, [POINTER(TextureSet), _P, _P, c_int64, _P, _P, _P]),
     "qf_texture_pack": (c_int, [POINTER(TextureSet), _P, _P]),

@@ -1228,6 +1228,68 @@ __global__ void texel_indices_kernel(const double *vertices, const int64_t *face
     }
 }
 
+// The same lookup with everything that depends on the triangle alone computed once per mesh: a 128-byte record per
+// triangle -- corner a, edges e0 / e1, their three dot products and the reciprocal determinant (13 doubles), the three
+// corners' uv (6 floats) -- so that a sample reads ONE line instead of following faces -> 3 vertices -> 3 uv, and
+// evaluates two dot products instead of five and no division.  The values are the ones the kernel above computes per
+// sample (same operations on the same inputs), so the texels are identical.
+struct TexelRecord {
+    double ax, ay, az, e0x, e0y, e0z, e1x, e1y, e1z, d00, d01, d11, inv;
+    float uv[6];                     // (u, v) of corners a, b, c
+};
+static_assert(sizeof(TexelRecord) == 128, "one 128-byte line per triangle");
+
+__global__ void texel_records_kernel(const double *vertices, const int64_t *faces, const float *uv, int64_t n_faces,
+                                     TexelRecord *records)
+{
+    for (int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; f < n_faces; f += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t ia = faces[f * 3], ib = faces[f * 3 + 1], ic = faces[f * 3 + 2];
+        TexelRecord r;
+        r.ax = vertices[ia * 3]; r.ay = vertices[ia * 3 + 1]; r.az = vertices[ia * 3 + 2];
+        r.e0x = vertices[ib * 3] - r.ax; r.e0y = vertices[ib * 3 + 1] - r.ay; r.e0z = vertices[ib * 3 + 2] - r.az;
+        r.e1x = vertices[ic * 3] - r.ax; r.e1y = vertices[ic * 3 + 1] - r.ay; r.e1z = vertices[ic * 3 + 2] - r.az;
+        r.d00 = (r.e0x * r.e0x + r.e0y * r.e0y) + r.e0z * r.e0z;
+        r.d01 = (r.e0x * r.e1x + r.e0y * r.e1y) + r.e0z * r.e1z;
+        r.d11 = (r.e1x * r.e1x + r.e1y * r.e1y) + r.e1z * r.e1z;
+        r.inv = 1.0 / (r.d00 * r.d11 - r.d01 * r.d01);
+        r.uv[0] = uv[ia * 2]; r.uv[1] = uv[ia * 2 + 1];
+        r.uv[2] = uv[ib * 2]; r.uv[3] = uv[ib * 2 + 1];
+        r.uv[4] = uv[ic * 2]; r.uv[5] = uv[ic * 2 + 1];
+        records[f] = r;
+    }
+}
+
+__global__ void texel_indices_packed_kernel(const TexelRecord *__restrict__ records, const float *__restrict__ points,
+                                            const int64_t *__restrict__ index_tri, int64_t n, int texture_size,
+                                            int64_t *__restrict__ texel)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const TexelRecord r = records[index_tri[i]];
+        const double wx = (double)points[i * 3] - r.ax, wy = (double)points[i * 3 + 1] - r.ay, wz = (double)points[i * 3 + 2] - r.az;
+        const double d02 = (r.e0x * wx + r.e0y * wy) + r.e0z * wz;
+        const double d12 = (r.e1x * wx + r.e1y * wy) + r.e1z * wz;
+        const double b2d = (r.d00 * d12 - r.d01 * d02) * r.inv;
+        const double b1d = (r.d11 * d02 - r.d01 * d12) * r.inv;
+        const double b0d = 1.0 - b1d - b2d;
+        float b0 = fminf(fmaxf((float)b0d, 0.0f), 1.0f);
+        float b1 = fminf(fmaxf((float)b1d, 0.0f), 1.0f);
+        float b2 = fminf(fmaxf((float)b2d, 0.0f), 1.0f);
+        const float s = (b0 + b1) + b2;
+        b0 = b0 / s;
+        b1 = b1 / s;
+        b2 = b2 / s;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const float u = (r.uv[k] * b0 + r.uv[2 + k] * b1) + r.uv[4 + k] * b2;
+            float fl = floorf(u);
+            int64_t q = (fl != fl) ? 0 : (fl <= -9.2e18f ? INT64_MIN : (fl >= 9.2e18f ? INT64_MAX : (int64_t)fl));
+            if (q < 0) q = 0;
+            if (q > texture_size - 1) q = texture_size - 1;
+            texel[i * 2 + k] = q;
+        }
+    }
+}
+
 struct TexArgs {
     const uint8_t *alpha, *diffuse;
     const uint8_t *colors[QF_MAX_LOBES];
@@ -1627,6 +1689,27 @@ extern "C" int qf_texel_indices(const double *vertices, const int64_t *faces, co
     if (n == 0) return QF_OK;
     if (!vertices || !faces || !uv || !points || !index_tri || !texel) return QF_ERR_INVALID_ARGUMENT;
     QF_SIMPLE_LAUNCH(texel_indices_kernel, n, vertices, faces, uv, points, index_tri, n, (int)texture_size, texel);
+    return QF_OK;
+}
+
+extern "C" int qf_texel_records_pack(const double *vertices, const int64_t *faces, const float *uv, int64_t n_faces,
+                                     void *records, void *stream)
+{
+    if (n_faces < 0) return QF_ERR_INVALID_ARGUMENT;
+    if (n_faces == 0) return QF_OK;
+    if (!vertices || !faces || !uv || !records) return QF_ERR_INVALID_ARGUMENT;
+    QF_SIMPLE_LAUNCH(texel_records_kernel, n_faces, vertices, faces, uv, n_faces, static_cast<TexelRecord *>(records));
+    return QF_OK;
+}
+
+extern "C" int qf_texel_indices_packed(const void *records, const float *points, const int64_t *index_tri, int64_t n,
+                                       int32_t texture_size, int64_t *texel, void *stream)
+{
+    if (n < 0 || texture_size < 1) return QF_ERR_INVALID_ARGUMENT;
+    if (n == 0) return QF_OK;
+    if (!records || !points || !index_tri || !texel) return QF_ERR_INVALID_ARGUMENT;
+    QF_SIMPLE_LAUNCH(texel_indices_packed_kernel, n, static_cast<const TexelRecord *>(records), points, index_tri, n,
+                     (int)texture_size, texel);
     return QF_OK;
 }
 

@@ -341,21 +341,33 @@ def render_image_fit_sg_with_occgrid(
             xyzs.shape[0], weights, xyzs, index_ray, index_tri)
 
 
-def texel_indices(mesh_intersect, uv, points, index_tri, texture_size: int) -> torch.Tensor:
-    """Nearest-texel lookup of utils.py:1055-1063 on the device (float64 barycentrics, fp32 UV blend)."""
+def texel_indices(mesh_intersect, uv, points, index_tri, texture_size: int, packed: bool = True) -> torch.Tensor:
+    """Nearest-texel lookup of utils.py:1055-1063 on the device (float64 barycentrics, fp32 UV blend).  ``packed``: from
+    the per-(mesh, uv) table of 128-byte triangle records (built on first use, rebuilt when the vertices or the uv
+    change); ``packed=False``: following faces -> vertices -> uv per sample.  Same texels."""
     cache = getattr(mesh_intersect, "_texel_cache", None)
     if cache is None or cache[0] is not mesh_intersect.mesh.vertices:
         v64 = torch.from_numpy(np.ascontiguousarray(mesh_intersect.mesh.vertices, dtype=np.float64)).to(mesh_intersect.device)
         faces = torch.from_numpy(np.ascontiguousarray(mesh_intersect.mesh.faces, dtype=np.int64)).to(mesh_intersect.device)
-        mesh_intersect._texel_cache = (mesh_intersect.mesh.vertices, v64, faces)
-    _, v64, faces = mesh_intersect._texel_cache
+        cache = mesh_intersect._texel_cache = [mesh_intersect.mesh.vertices, v64, faces, None, None]
+    _, v64, faces = cache[:3]
     uv = _C.f32c(torch.as_tensor(uv).to(mesh_intersect.device))
     points = _C.f32c(points)
     index_tri = _C.i64c(index_tri)
     n = points.shape[0]
     texel = torch.empty((n, 2), dtype=torch.int64, device=points.device)
-    _C.check(_C.lib().qf_texel_indices(_C.ptr(v64), _C.ptr(faces), _C.ptr(uv), _C.ptr(points), _C.ptr(index_tri), n,
-                                       int(texture_size), _C.ptr(texel), _C.stream()), "qf_texel_indices")
+    if not packed:
+        _C.check(_C.lib().qf_texel_indices(_C.ptr(v64), _C.ptr(faces), _C.ptr(uv), _C.ptr(points), _C.ptr(index_tri), n,
+                                           int(texture_size), _C.ptr(texel), _C.stream()), "qf_texel_indices")
+        return texel
+    key = (uv.data_ptr(), uv._version, tuple(uv.shape))
+    if cache[3] != key:
+        records = torch.empty((faces.shape[0], _C.QF_TEXEL_TRIANGLE_RECORD_BYTES), dtype=torch.uint8, device=points.device)
+        _C.check(_C.lib().qf_texel_records_pack(_C.ptr(v64), _C.ptr(faces), _C.ptr(uv), faces.shape[0], _C.ptr(records),
+                                                _C.stream()), "qf_texel_records_pack")
+        cache[3], cache[4] = key, (records, uv)             # the uv tensor stays referenced: its address is the key
+    _C.check(_C.lib().qf_texel_indices_packed(_C.ptr(cache[4][0]), _C.ptr(points), _C.ptr(index_tri), n, int(texture_size),
+                                              _C.ptr(texel), _C.stream()), "qf_texel_indices_packed")
     return texel
 
 

@@ -73,6 +73,15 @@ def test_texel_indices_bit_exact(device):
     far = xyz + 0.5
     want = oq.texel_indices(mesh.vertices[f], far.cpu().numpy(), torch.from_numpy(uv)[torch.from_numpy(f)], size)
     assert torch.equal(utils.texel_indices(mi, uv, far, index_tri, size).cpu(), want)
+    # the per-triangle record table (default) and the per-sample faces -> vertices -> uv walk give the same texels; the
+    # table follows the uv it was built from (cached per uv tensor, rebuilt when that tensor is modified in place)
+    uv_d = torch.from_numpy(uv).to(device)
+    a = utils.texel_indices(mi, uv_d, xyz, index_tri, size, packed=True)
+    b = utils.texel_indices(mi, uv_d, xyz, index_tri, size, packed=False)
+    assert torch.equal(a, b) and torch.equal(a, got)
+    uv_d.mul_(0.5)
+    c = utils.texel_indices(mi, uv_d, xyz, index_tri, size, packed=True)
+    assert torch.equal(c, utils.texel_indices(mi, uv_d, xyz, index_tri, size, packed=False)) and not torch.equal(c, a)
 
 
 def test_compress_roundtrip_through_textures(device):
