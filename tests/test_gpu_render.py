@@ -176,6 +176,44 @@ def test_baked_texture_render_matches_oracle(device):
     assert torch.equal(rgb_g, rgb_f)                       # without a camera: the ray-major route
 
 
+@pytest.mark.parametrize("w,h,k", [(40, 24, 64), (9, 1, 25), (1, 13, 25), (8, 8, 1)])
+def test_tile_order_frame_equals_the_ray_major_route_at_the_edges(device, w, h, k):
+    """The frame driver's tile-order path (qf_pack_tiles / qf_composite_tiles) against the function-by-function route on
+    the six ray-major tensors, bit for bit: the largest K the ABI allows (64 hits per ray: the tile kernels' LDS
+    columns), one-row / one-column images (tiles mostly outside the image), K = 1 (every ray overflows and is
+    repaired), plain and deformed."""
+    from quadraturefields_amd import synthetic, utils
+    from quadraturefields_amd.datasets.utils import Rays
+    from quadraturefields_amd.field import Field
+    from quadraturefields_amd.mesh_utils import MeshIntersection, make_camera
+    from quadraturefields_amd.radiance_fields.ngp import NGPRadianceField
+    from quadraturefields_amd.render import FrameRenderer
+    mesh = synthetic.shell_mesh(n_shells=20, subdivisions=2)          # up to 40 crossings per ray
+    mi = MeshIntersection(mesh, simplify_mesh=False, scale=1.0, num_intersections=k)
+    field = NGPRadianceField(aabb=[-1.5] * 3 + [1.5] * 3, log2_hashmap_size=12)
+    field.load_state_dict(synthetic.seeded_ngp_state(12, field.mlp_base.grid.n_rows), strict=False)
+    field = field.to(device)
+    net = Field(scale=1.5, precision=16, log2_T=12, L=16, max_res=512, min_res=16, output_dim=1, hidden_size=32,
+                num_features=2, back_prop=False, nl="relu")
+    net.load_state_dict(synthetic.seeded_deform_state(net.xyz_encoder.grid.n_params), strict=False)
+    net = net.to(device)
+    c2w = synthetic.orbit_cameras(1, seed=6)[0]
+    focal = synthetic.lego_focal(800) * max(w, h) / 800.0 * 2.0
+    o, d = synthetic.camera_rays(c2w, focal, w, h, device=device)
+    cam = make_camera(c2w, focal, w, h)
+    for fnet, sc in ((None, 0.0), (net, 0.5)):
+        fr = FrameRenderer(mi, field, field_net=fnet)
+        rgb, alpha, depth, n = fr.render(o, d, scaling=sc, camera=cam)
+        data = mi.sampling_raytrace_device(d, o)
+        assert data is not None and n == data[0].shape[0] and n > 0
+        if k == 64:
+            assert int(torch.bincount(data[2]).max()) > 25          # deeper than the usual K
+        ref = utils.render_image_finetune_with_occgrid(field, fnet, None, Rays(origins=o, viewdirs=d), data,
+                                                       render_step_size=5e-3, mesh_intersect=mi, scaling=sc)
+        assert torch.equal(rgb, ref[0].reshape(-1, 3)) and torch.equal(alpha, ref[1].reshape(-1, 1))
+        assert torch.equal(depth, ref[2].reshape(-1, 1))
+
+
 def test_frame_renderer_and_upsample(device):
     """up_sample 2 frame (train_finetune.py:620-627): render at 2x, box-average down, compare with the oracle."""
     from quadraturefields_amd.render import FrameRenderer, area_downsample, psnr
