@@ -421,6 +421,11 @@ int qf_frame_offsets(const int32_t *hit_count, int64_t n_rays, int32_t max_hits,
                      int64_t *ray_offset /* [n_rays+1] */, int64_t *tile_base /* or NULL */, void *temp,
                      int64_t temp_bytes, const int32_t *overflow_in, int64_t *host_out, void *stream);
 
+/* The same for a frame that is only rendered: tile_base (as above) and *total (device int64) alone -- what
+ * qf_pack_tiles and qf_composite_tiles take -- in two launches, without the per-ray offsets.              */
+int qf_tile_offsets(const int32_t *hit_count, int32_t max_hits, int32_t width, int32_t height, int64_t *tile_base,
+                    int64_t *total, const int32_t *overflow_in, int64_t *host_out, void *stream);
+
 /* Packs the per-ray hit lists into the sample arrays sampling_raytrace_numpy returns
  * (mesh_utils.py:359-387), already sorted by (ray, depth): location = o + t d in float64,
  * dirs = d/(|d|+1e-7), depth = |location - o| (float64, rounded to fp32 at the end).

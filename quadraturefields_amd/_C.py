@@ -112,6 +112,7 @@ _SIGNATURES = {
     "qf_sample_offsets": (c_int, [_P, c_int64, c_int32, _P, _P, c_int64, _P]),
     "qf_frame_offsets_temp_bytes": (c_int64, [c_int64]),
     "qf_frame_offsets": (c_int, [_P, c_int64, c_int32, c_int32, c_int32, _P, _P, _P, c_int64, _P, _P, _P]),
+    "qf_tile_offsets": (c_int, [_P, c_int32, c_int32, c_int32, _P, _P, _P, _P, _P]),
     "qf_pack_tiles": (c_int, [_P, _P, c_int32, c_int32, c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_float, _P, _P, _P, _P]),
     "qf_pack_samples": (c_int, [_P, _P, c_int64, c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_float, _P, _P]),
     "qf_tile_totals": (c_int, [_P, c_int32, c_int32, _P, _P]),

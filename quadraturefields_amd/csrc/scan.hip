@@ -148,7 +148,8 @@ __global__ __launch_bounds__(kFoThreads) void frame_scan_kernel(int64_t *partial
             a[i] = run;
             run += v;
         }
-        if (pass == 0 && threadIdx.x == 0) {
+        // the grand total comes from the per-ray partials when they exist, from the tile totals otherwise
+        if (threadIdx.x == 0 && (pass == 0 || !partial)) {
             *grand_total = total;
             if (host_out) {                 // pinned host memory: the frame's 16-byte readback without a copy kernel
                 host_out[0] = total;
@@ -212,5 +213,26 @@ extern "C" int qf_frame_offsets(const int32_t *hit_count, int64_t n_rays, int32_
                            max_hits, partial, ray_offset);
         QF_LAUNCH_CHECK();
     }
+    return QF_OK;
+}
+
+// The render-only frame's version: only the tile bases and the total (what qf_pack_tiles and qf_composite_tiles take),
+// no per-ray offsets -- the tile part of step 1 and a scan over the tile totals alone.
+extern "C" int qf_tile_offsets(const int32_t *hit_count, int32_t max_hits, int32_t width, int32_t height,
+                               int64_t *tile_base, int64_t *total, const int32_t *overflow_in, int64_t *host_out,
+                               void *stream)
+{
+    if (max_hits < 1 || width < 1 || height < 1 || !hit_count || !tile_base || !total) return QF_ERR_INVALID_ARGUMENT;
+    const int64_t n_rays = (int64_t)width * height;
+    if (n_rays >= 0x7fffffff) return QF_ERR_INVALID_ARGUMENT;
+    hipStream_t st = qf_stream(stream);
+    const int tiles_x = (width + 7) / 8;
+    const int n_tiles = tiles_x * ((height + 7) / 8);
+    const int tile_blocks = (int)qf_div_up(n_tiles, kFoThreads / 64);
+    hipLaunchKernelGGL(frame_partials_kernel, dim3((unsigned)tile_blocks), dim3(kFoThreads), 0, st, hit_count, n_rays, max_hits,
+                       0, (int)width, (int)height, tiles_x, n_tiles, (int64_t *)nullptr, tile_base);
+    hipLaunchKernelGGL(frame_scan_kernel, dim3(1), dim3(kFoThreads), 0, st, (int64_t *)nullptr, 0, tile_base, n_tiles, total,
+                       overflow_in, host_out);
+    QF_LAUNCH_CHECK();
     return QF_OK;
 }

@@ -376,9 +376,14 @@ class RayIntersector:
         if image:
             height = n // width
             tile_base = torch.empty((((width + 7) // 8) * ((height + 7) // 8),), dtype=torch.int64, device=dev)
-        _C.check(_C.lib().qf_frame_offsets(_C.ptr(hit_count), n, k, int(width) if image else 0, n // width if image else 0,
-                                           _C.ptr(buf), _C.ptr(tile_base), _C.ptr(temp), temp.numel(), _C.ptr(overflow),
-                                           ctypes.c_void_p(host.data_ptr()), _C.stream()), "qf_frame_offsets")
+        if bool(lean) and image:              # render-only frame: tile bases + total, no per-ray offsets
+            _C.check(_C.lib().qf_tile_offsets(_C.ptr(hit_count), k, int(width), n // int(width), _C.ptr(tile_base),
+                                              _C.ptr(buf[n:]), _C.ptr(overflow), ctypes.c_void_p(host.data_ptr()),
+                                              _C.stream()), "qf_tile_offsets")
+        else:
+            _C.check(_C.lib().qf_frame_offsets(_C.ptr(hit_count), n, k, int(width) if image else 0, n // width if image else 0,
+                                               _C.ptr(buf), _C.ptr(tile_base), _C.ptr(temp), temp.numel(), _C.ptr(overflow),
+                                               ctypes.c_void_p(host.data_ptr()), _C.stream()), "qf_frame_offsets")
         ev.record()                           # (total, overflow) are in pinned memory once this event has passed
         lean = bool(lean) and image
         want_layout = layout

@@ -725,6 +725,15 @@ def test_frame_offsets_equal_a_cumsum(device):
             pad[:h, :w] = c.view(h, w)
             tot = pad.view((h + 7) // 8, 8, (w + 7) // 8, 8).sum(dim=(1, 3)).reshape(-1)
             assert torch.equal(tiles, torch.cumsum(tot, 0) - tot)
+            # the render-only frame's two-launch version: the same tile bases and total, no per-ray offsets
+            tiles2 = torch.empty_like(tiles)
+            total2 = torch.full((1,), -1, dtype=torch.int64, device=device)
+            host2 = torch.full((4,), -1, dtype=torch.int64).pin_memory()
+            _C.check(_C.lib().qf_tile_offsets(_C.ptr(cnt), k, w, h, _C.ptr(tiles2), _C.ptr(total2), _C.ptr(ovf),
+                                              ctypes.c_void_p(host2.data_ptr()), _C.stream()), "qf_tile_offsets")
+            torch.cuda.synchronize()
+            assert torch.equal(tiles2, tiles) and int(total2) == int(c.sum())
+            assert int(host2[0]) == int(c.sum()) and int(host2[1]) == 7
 
 
 def test_filter_hits_applies_the_rule_in_place(device):
