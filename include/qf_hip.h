@@ -463,9 +463,11 @@ int qf_pack_samples(const float *rays_o, const float *rays_d, int64_t n_rays, in
  * min_separation > 0, it is applied HERE, on the sorted list (what qf_filter_hits does) -- no optimistic guess, no
  * second pass.  The hits it drops leave unused slots at the end of their tile (filled with a copy of a real sample so
  * that qf_field_forward can stream [0, *total) blindly): final_count [w*h] receives every pixel's kept count -- hand
- * THAT to qf_composite_tiles -- and *dropped (device int32, zeroed by this call) the frame's number of dropped hits
- * (samples of the frame = *total - *dropped).  host_out (or NULL): pinned host int64[3]; host_out[2] = *dropped after
- * the call's kernels, for a caller that wants the count without a copy.  final_count may be given without the rule.
+ * THAT to qf_composite_tiles -- and *dropped (device int32) the frame's number of dropped hits (samples of the frame =
+ * *total - *dropped).  Without host_out the call zeroes *dropped first and leaves the count in it.  host_out (pinned
+ * host int64[3]): host_out[2] = the count after the call's kernels, for a caller that wants it without a copy; *dropped
+ * must then be 0 on entry and is 0 again afterwards (a frame loop that keeps one counter pays no memset launch).
+ * final_count may be given without the rule.
  * tri_c (or NULL): the samples' triangle ids in the same order (the baked-texture render looks its texels up by
  * triangle, utils.py:1055-1063); without it hit_tri is not read at all (may be NULL).
  * Values equal qf_pack_samples' xyz_c / dirs_c / depth_c bit for bit (position for position when nothing is dropped). */

@@ -1064,8 +1064,13 @@ __global__ __launch_bounds__(64) void pack_tiles_kernel(
     }
 }
 
-// the frame's dropped-hit count -> pinned host memory (host_out[2]), one thread
-__global__ void publish_dropped_kernel(const int32_t *dropped, int64_t *host_out) { host_out[2] = (int64_t)*dropped; }
+// the frame's dropped-hit count -> pinned host memory (host_out[2]), one thread; the counter is left at zero for the
+// caller's next frame (which then needs no memset launch of its own)
+__global__ void publish_dropped_kernel(int32_t *dropped, int64_t *host_out)
+{
+    host_out[2] = (int64_t)*dropped;
+    *dropped = 0;
+}
 
 // Stable per-ray insertion sort of sample indices by fp32 depth (np.lexsort((depth, index_ray)) on grouped rays).
 __global__ void resort_kernel(const int64_t *index_ray, const float *depth, int64_t n, int64_t *perm)
@@ -1636,7 +1641,7 @@ extern "C" int qf_pack_tiles(const float *rays_o, const float *rays_d, int32_t w
     if (rule_here && (!final_count || !dropped)) return QF_ERR_INVALID_ARGUMENT;     // the counts change: they must go somewhere
     if (host_out && !dropped) return QF_ERR_INVALID_ARGUMENT;
     hipStream_t st = qf_stream(stream);
-    if (dropped) QF_HIP_TRY(hipMemsetAsync(dropped, 0, sizeof(int32_t), st));
+    if (dropped && !host_out) QF_HIP_TRY(hipMemsetAsync(dropped, 0, sizeof(int32_t), st));
     const int tiles_x = (width + 7) / 8, tiles_y = (height + 7) / 8;
     const float sep = rule_here ? min_separation : 0.0f;
     if (tri_c) {
