@@ -207,6 +207,19 @@ def timed_field_events(stages, frames, warm):
     return el, pts, stages.stage_ms()["field"]
 
 
+def _committed_traffic(name: str):
+    """(bytes per point, source) of a dominant kernel from the committed PMC reduction profiles/<round>/<name>, or
+    (None, None): bench.py cannot sample PMC counters itself (separate rocprofv3 --pmc passes, tools/config_traffic.sh)."""
+    for rnd in (PROFILE_ROUND, "r1"):
+        path = os.path.join(ROOT, "profiles", rnd, name)
+        if os.path.exists(path):
+            tj = json.load(open(path))
+            if tj.get("fetch_bytes_per_launch") and tj.get("points_per_launch"):
+                per_point = (tj["fetch_bytes_per_launch"] + (tj.get("write_bytes_per_launch") or 0.0)) / tj["points_per_launch"]
+                return per_point, f"profiles/{rnd}/{name} (FETCH_SIZE + WRITE_SIZE, bytes per point x points per launch)"
+    return None, None
+
+
 def config3_line(device, steps=5, warm=4):
     """BASELINE configs[2]: 1920x1080, T = 2^21, ~3 M triangles of thin concentric shells (most object rays collect
     more than K = 25 candidates), bf16 tables + MLPs with fp32 accumulate."""
@@ -228,6 +241,7 @@ def config3_line(device, steps=5, warm=4):
     ms["field"] = field_ms
     ppl = pts / steps
     achieved = ppl * 512 / (field_ms * 1e-3) / 1e9
+    t3 = _committed_traffic("config3_traffic.json")
     return {
         "workload": "configs[2]: 1920x1080, bf16 tables + MLPs (fp32 accumulate), T=2^21, dense thin shells, K=25",
         "dtype": "bf16", "triangles": int(mesh.faces.shape[0]), "rays_per_frame": w * h,
@@ -235,7 +249,9 @@ def config3_line(device, steps=5, warm=4):
         "mean_hits_per_ray": ppl / (w * h), "stage_ms": ms, "raster_wide": int(mi.rayintersector.raster_wide),
         "dominant_kernel": "field_kernel_bf16<NGP>",
         "roofline": {"kernel": "field_kernel_bf16<NGP>", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": None if t3[0] is None else t3[0] * ppl, "traffic_unit": "bytes per launch",
+                     "traffic_source": t3[1],
                      "algorithmic_bytes_per_point": 512, "points_per_launch": ppl, "avg_launch_ms": field_ms},
     }
 
@@ -284,6 +300,7 @@ def config5_line(device, scene, steps=8, warm=3, texture_size=4096, lobes=6):
     shade_ms = float(np.mean([a.elapsed_time(b) for a, b, _ in events]))
     ppl = pts / steps
     alg = 1 + 3 + 6 * lobes                       # uint8 codes a sample decodes (40 B at L = 6)
+    t5 = _committed_traffic("config5_traffic.json")
     achieved = ppl * alg / (shade_ms * 1e-3) / 1e9
     return {
         "workload": f"configs[4]: baked SG textures {texture_size}^2 uint8 x (2+2L) planes, L={lobes}, 800x800 frames, "
@@ -293,7 +310,9 @@ def config5_line(device, scene, steps=8, warm=3, texture_size=4096, lobes=6):
         "rays_per_s": W * H * steps / el, "quadrature_points_per_frame": ppl,
         "dominant_kernel": "texture_shade_packed_kernel",
         "roofline": {"kernel": "texture_shade_packed_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": None if t5[0] is None else t5[0] * ppl, "traffic_unit": "bytes per launch",
+                     "traffic_source": t5[1],
                      "algorithmic_bytes_per_point": alg, "fetched_bytes_per_point": 64 + 16 + 12,
                      "points_per_launch": ppl, "avg_launch_ms": shade_ms,
                      "note": "one 64-B texel record + 16-B texel index + 12-B direction per sample; the gather of "

@@ -25,6 +25,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--texture-size", type=int, default=4096)
     ap.add_argument("--lobes", type=int, default=6)
+    ap.add_argument("--frame-path", action="store_true",
+                    help="FrameRenderer.render_baked (the tile-order frame path of bench.py's configs[4] line) instead of the "
+                         "function-by-function route")
     args = ap.parse_args()
     torch.set_grad_enabled(False)
     from quadraturefields_amd import synthetic, utils
@@ -44,8 +47,14 @@ def main():
     cameras = [make_camera(cams[i], focal, bench.W, bench.H) for i in range(n_frames)]
     ev = {k: [] for k in ("sample", "render")}
 
+    from quadraturefields_amd.render import FrameRenderer
+    fr = FrameRenderer(mi, field, render_step_size=bench.STEP)
+
     def frame(i, record):
         o, d = rays[i]
+        if args.frame_path:
+            out = fr.render_baked(o, d, uv, comp, camera=cameras[i])
+            return out[0], out[3]
         marks = [torch.cuda.Event(enable_timing=True) for _ in range(3)] if record else None
         if record:
             marks[0].record()
@@ -70,7 +79,7 @@ def main():
         pts += frame(i, True)[1]
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
-    ms = {k: sum(a.elapsed_time(b) for a, b in v) / len(v) for k, v in ev.items()}
+    ms = {k: sum(a.elapsed_time(b) for a, b in v) / len(v) for k, v in ev.items() if v}
     n_rays = bench.W * bench.H
     bytes_per_sample = 1 + 3 + 6 * args.lobes
     print(json.dumps({
