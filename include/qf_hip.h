@@ -575,6 +575,13 @@ int qf_texture_pack(const qf_texture_set *tex /* host */, uint8_t *records, void
 int qf_texture_shade_packed(const uint8_t *records, int32_t texture_size, int32_t n_lobes,
                             int32_t sigmoid_codec, float lambda_thres, const int64_t *texel,
                             const float *dirs, int64_t n, float *rgb, float *sigma, void *stream);
+/* qf_texel_indices_packed + qf_texture_shade_packed in one launch: the texel of sample i is looked up from points[i] and
+ * index_tri[i] through the triangle records inside the shading kernel -- no texel array is written and read back.
+ * The baked-texture frame path's shading (utils.py:1055-1076).  Same values as the two calls.               */
+int qf_texture_shade_points(const uint8_t *records, int32_t texture_size, int32_t n_lobes, int32_t sigmoid_codec,
+                            float lambda_thres, const void *triangle_records, const float *points,
+                            const int64_t *index_tri, const float *dirs, int64_t n, float *rgb, float *sigma,
+                            void *stream);
 
 #ifdef __cplusplus
 }

@@ -127,6 +127,7 @@ _SIGNATURES = {
     "qf_texture_shade": (c_int, [POINTER(TextureSet), _P, _P, c_int64, _P, _P, _P]),
     "qf_texture_pack": (c_int, [POINTER(TextureSet), _P, _P]),
     "qf_texture_shade_packed": (c_int, [_P, c_int32, c_int32, c_int32, c_float, _P, _P, c_int64, _P, _P, _P]),
+    "qf_texture_shade_points": (c_int, [_P, c_int32, c_int32, c_int32, c_float, _P, _P, _P, _P, c_int64, _P, _P, _P]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 

@@ -1264,34 +1264,43 @@ __global__ void texel_records_kernel(const double *vertices, const int64_t *face
     }
 }
 
+__device__ __forceinline__ void texel_from_record(const TexelRecord &r, float px, float py, float pz, int texture_size,
+                                                  int64_t out[2])
+{
+    const double wx = (double)px - r.ax, wy = (double)py - r.ay, wz = (double)pz - r.az;
+    const double d02 = (r.e0x * wx + r.e0y * wy) + r.e0z * wz;
+    const double d12 = (r.e1x * wx + r.e1y * wy) + r.e1z * wz;
+    const double b2d = (r.d00 * d12 - r.d01 * d02) * r.inv;
+    const double b1d = (r.d11 * d02 - r.d01 * d12) * r.inv;
+    const double b0d = 1.0 - b1d - b2d;
+    float b0 = fminf(fmaxf((float)b0d, 0.0f), 1.0f);
+    float b1 = fminf(fmaxf((float)b1d, 0.0f), 1.0f);
+    float b2 = fminf(fmaxf((float)b2d, 0.0f), 1.0f);
+    const float s = (b0 + b1) + b2;
+    b0 = b0 / s;
+    b1 = b1 / s;
+    b2 = b2 / s;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const float u = (r.uv[k] * b0 + r.uv[2 + k] * b1) + r.uv[4 + k] * b2;
+        float fl = floorf(u);
+        int64_t q = (fl != fl) ? 0 : (fl <= -9.2e18f ? INT64_MIN : (fl >= 9.2e18f ? INT64_MAX : (int64_t)fl));
+        if (q < 0) q = 0;
+        if (q > texture_size - 1) q = texture_size - 1;
+        out[k] = q;
+    }
+}
+
 __global__ void texel_indices_packed_kernel(const TexelRecord *__restrict__ records, const float *__restrict__ points,
                                             const int64_t *__restrict__ index_tri, int64_t n, int texture_size,
                                             int64_t *__restrict__ texel)
 {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const TexelRecord r = records[index_tri[i]];
-        const double wx = (double)points[i * 3] - r.ax, wy = (double)points[i * 3 + 1] - r.ay, wz = (double)points[i * 3 + 2] - r.az;
-        const double d02 = (r.e0x * wx + r.e0y * wy) + r.e0z * wz;
-        const double d12 = (r.e1x * wx + r.e1y * wy) + r.e1z * wz;
-        const double b2d = (r.d00 * d12 - r.d01 * d02) * r.inv;
-        const double b1d = (r.d11 * d02 - r.d01 * d12) * r.inv;
-        const double b0d = 1.0 - b1d - b2d;
-        float b0 = fminf(fmaxf((float)b0d, 0.0f), 1.0f);
-        float b1 = fminf(fmaxf((float)b1d, 0.0f), 1.0f);
-        float b2 = fminf(fmaxf((float)b2d, 0.0f), 1.0f);
-        const float s = (b0 + b1) + b2;
-        b0 = b0 / s;
-        b1 = b1 / s;
-        b2 = b2 / s;
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const float u = (r.uv[k] * b0 + r.uv[2 + k] * b1) + r.uv[4 + k] * b2;
-            float fl = floorf(u);
-            int64_t q = (fl != fl) ? 0 : (fl <= -9.2e18f ? INT64_MIN : (fl >= 9.2e18f ? INT64_MAX : (int64_t)fl));
-            if (q < 0) q = 0;
-            if (q > texture_size - 1) q = texture_size - 1;
-            texel[i * 2 + k] = q;
-        }
+        int64_t q[2];
+        texel_from_record(r, points[i * 3], points[i * 3 + 1], points[i * 3 + 2], texture_size, q);
+        texel[i * 2 + 0] = q[0];
+        texel[i * 2 + 1] = q[1];
     }
 }
 
@@ -1403,10 +1412,14 @@ __global__ void texture_pack_kernel(TexArgs t, uint8_t *records)
 // Every quantity a record decodes to is a function of ONE uint8 code, so a workgroup first evaluates the reference's
 // dequantisers (the same expressions as decode_record, hence the same bits) for all 256 codes into LDS and then
 // decodes by lookup: the 4L sin/cos, L exp and 3+3L colour decodes per sample become LDS reads.
+// kLookup: the texel is not read but looked up here, from the sample's position and triangle (texel_from_record): the
+// frame path's fusion of qf_texel_indices_packed and this kernel (no int64 [n,2] texel array written and read back).
+template <bool kLookup>
 __global__ __launch_bounds__(256) void texture_shade_packed_kernel(const uint8_t *records, int size, int n_lobes,
                                                                    int sigmoid_codec, float lambda_thres,
                                                                    const int64_t *texel, const float *dirs, int64_t n,
-                                                                   float *rgb, float *sigma)
+                                                                   float *rgb, float *sigma, const TexelRecord *tri_records,
+                                                                   const float *points, const int64_t *index_tri)
 {
     __shared__ float s_sigma[256], s_col[256], s_caz[256], s_saz[256], s_sel[256], s_cel[256], s_lam[256];
     {
@@ -1426,7 +1439,15 @@ __global__ __launch_bounds__(256) void texture_shade_packed_kernel(const uint8_t
     __syncthreads();
     const int n16 = (4 + 6 * n_lobes + 15) / 16;       // 16-byte pieces of the record that carry data
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t px = texel[i * 2] * size + texel[i * 2 + 1];
+        int64_t px;
+        if (kLookup) {
+            const TexelRecord tr = tri_records[index_tri[i]];
+            int64_t rc[2];
+            texel_from_record(tr, points[i * 3], points[i * 3 + 1], points[i * 3 + 2], size, rc);
+            px = rc[0] * size + rc[1];
+        } else {
+            px = texel[i * 2] * size + texel[i * 2 + 1];
+        }
         union { uint8_t b[kTexelRecord]; uint4 q[kTexelRecord / 16]; } rec;
         const uint4 *src = reinterpret_cast<const uint4 *>(records + px * kTexelRecord);
 #pragma unroll
@@ -1761,8 +1782,24 @@ extern "C" int qf_texture_shade_packed(const uint8_t *records, int32_t texture_s
     if (n_lobes < 1 || n_lobes > QF_MAX_LOBES) return QF_ERR_UNSUPPORTED;
     if (n == 0) return QF_OK;
     if (!texel || !dirs || !rgb || !sigma) return QF_ERR_INVALID_ARGUMENT;
-    QF_SIMPLE_LAUNCH(texture_shade_packed_kernel, n, records, (int)texture_size, (int)n_lobes, (int)sigmoid_codec,
-                     lambda_thres, texel, dirs, n, rgb, sigma);
+    QF_SIMPLE_LAUNCH(texture_shade_packed_kernel<false>, n, records, (int)texture_size, (int)n_lobes, (int)sigmoid_codec,
+                     lambda_thres, texel, dirs, n, rgb, sigma, (const TexelRecord *)nullptr, (const float *)nullptr,
+                     (const int64_t *)nullptr);
+    return QF_OK;
+}
+
+extern "C" int qf_texture_shade_points(const uint8_t *records, int32_t texture_size, int32_t n_lobes, int32_t sigmoid_codec,
+                                       float lambda_thres, const void *triangle_records, const float *points,
+                                       const int64_t *index_tri, const float *dirs, int64_t n, float *rgb, float *sigma,
+                                       void *stream)
+{
+    if (!records || !triangle_records || texture_size < 1 || n < 0) return QF_ERR_INVALID_ARGUMENT;
+    if (n_lobes < 1 || n_lobes > QF_MAX_LOBES) return QF_ERR_UNSUPPORTED;
+    if (n == 0) return QF_OK;
+    if (!points || !index_tri || !dirs || !rgb || !sigma) return QF_ERR_INVALID_ARGUMENT;
+    QF_SIMPLE_LAUNCH(texture_shade_packed_kernel<true>, n, records, (int)texture_size, (int)n_lobes, (int)sigmoid_codec,
+                     lambda_thres, (const int64_t *)nullptr, dirs, n, rgb, sigma,
+                     static_cast<const TexelRecord *>(triangle_records), points, index_tri);
     return QF_OK;
 }
 

@@ -105,8 +105,8 @@ class FrameRenderer:
     @torch.no_grad()
     def render_baked(self, origins, viewdirs, uv, compressor, image_width: int = 0, camera=None):
         """Baked-texture variant (test_baking_texture_images.py:355-371).  With a ``camera`` (the rays are its pixel
-        grid) the frame never leaves the intersector's tile order: tile pack with triangle ids -> texel lookup ->
-        decode + SG shading -> tile compositor, every stage elementwise or tile-local; same pixels as
+        grid) the frame never leaves the intersector's tile order: tile pack with triangle ids -> texel lookup +
+        decode + SG shading in one launch -> tile compositor, every stage elementwise or tile-local; same pixels as
         ``render_image_bake_texture_images_with_occgrid`` on the ray-major samples, bit for bit."""
         n_rays = origins.shape[0]
         if camera is not None:
@@ -116,8 +116,7 @@ class FrameRenderer:
             if data is not None and ri.last_frame is not None and ri.last_frame.tri_c is not None:
                 frame = ri.last_frame
                 _, xyz_c, dirs_c = ri.last_layout
-                texel = utils.texel_indices(self.mesh_intersect, uv, xyz_c, frame.tri_c, compressor.texture_size)
-                rgbs, sigmas = compressor.shade(texel, dirs_c)
+                rgbs, sigmas = utils.shade_baked_points(self.mesh_intersect, uv, compressor, xyz_c, frame.tri_c, dirs_c)
                 rgb, alpha, depth, _ = utils.composite_frame(rgbs, sigmas, frame, self.render_step_size,
                                                              bg_color=self.bg_color)
                 return rgb, alpha, depth, ri.frame_samples()

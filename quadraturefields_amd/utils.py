@@ -341,10 +341,9 @@ def render_image_fit_sg_with_occgrid(
             xyzs.shape[0], weights, xyzs, index_ray, index_tri)
 
 
-def texel_indices(mesh_intersect, uv, points, index_tri, texture_size: int, packed: bool = True) -> torch.Tensor:
-    """Nearest-texel lookup of utils.py:1055-1063 on the device (float64 barycentrics, fp32 UV blend).  ``packed``: from
-    the per-(mesh, uv) table of 128-byte triangle records (built on first use, rebuilt when the vertices or the uv
-    change); ``packed=False``: following faces -> vertices -> uv per sample.  Same texels."""
+def _triangle_records(mesh_intersect, uv):
+    """(records, vertices float64, faces, uv fp32) on the device: the per-(mesh, uv) table of 128-byte triangle records
+    of ``qf_texel_records_pack``, built on first use and rebuilt when the mesh's vertices or the uv tensor change."""
     cache = getattr(mesh_intersect, "_texel_cache", None)
     if cache is None or cache[0] is not mesh_intersect.mesh.vertices:
         v64 = torch.from_numpy(np.ascontiguousarray(mesh_intersect.mesh.vertices, dtype=np.float64)).to(mesh_intersect.device)
@@ -352,6 +351,20 @@ def texel_indices(mesh_intersect, uv, points, index_tri, texture_size: int, pack
         cache = mesh_intersect._texel_cache = [mesh_intersect.mesh.vertices, v64, faces, None, None]
     _, v64, faces = cache[:3]
     uv = _C.f32c(torch.as_tensor(uv).to(mesh_intersect.device))
+    key = (uv.data_ptr(), uv._version, tuple(uv.shape))
+    if cache[3] != key:
+        records = torch.empty((faces.shape[0], _C.QF_TEXEL_TRIANGLE_RECORD_BYTES), dtype=torch.uint8, device=uv.device)
+        _C.check(_C.lib().qf_texel_records_pack(_C.ptr(v64), _C.ptr(faces), _C.ptr(uv), faces.shape[0], _C.ptr(records),
+                                                _C.stream()), "qf_texel_records_pack")
+        cache[3], cache[4] = key, (records, uv)             # the uv tensor stays referenced: its address is the key
+    return cache[4][0], v64, faces, uv
+
+
+def texel_indices(mesh_intersect, uv, points, index_tri, texture_size: int, packed: bool = True) -> torch.Tensor:
+    """Nearest-texel lookup of utils.py:1055-1063 on the device (float64 barycentrics, fp32 UV blend).  ``packed``: from
+    the per-(mesh, uv) table of 128-byte triangle records; ``packed=False``: following faces -> vertices -> uv per
+    sample.  Same texels."""
+    records, v64, faces, uv = _triangle_records(mesh_intersect, uv)
     points = _C.f32c(points)
     index_tri = _C.i64c(index_tri)
     n = points.shape[0]
@@ -360,15 +373,27 @@ def texel_indices(mesh_intersect, uv, points, index_tri, texture_size: int, pack
         _C.check(_C.lib().qf_texel_indices(_C.ptr(v64), _C.ptr(faces), _C.ptr(uv), _C.ptr(points), _C.ptr(index_tri), n,
                                            int(texture_size), _C.ptr(texel), _C.stream()), "qf_texel_indices")
         return texel
-    key = (uv.data_ptr(), uv._version, tuple(uv.shape))
-    if cache[3] != key:
-        records = torch.empty((faces.shape[0], _C.QF_TEXEL_TRIANGLE_RECORD_BYTES), dtype=torch.uint8, device=points.device)
-        _C.check(_C.lib().qf_texel_records_pack(_C.ptr(v64), _C.ptr(faces), _C.ptr(uv), faces.shape[0], _C.ptr(records),
-                                                _C.stream()), "qf_texel_records_pack")
-        cache[3], cache[4] = key, (records, uv)             # the uv tensor stays referenced: its address is the key
-    _C.check(_C.lib().qf_texel_indices_packed(_C.ptr(cache[4][0]), _C.ptr(points), _C.ptr(index_tri), n, int(texture_size),
+    _C.check(_C.lib().qf_texel_indices_packed(_C.ptr(records), _C.ptr(points), _C.ptr(index_tri), n, int(texture_size),
                                               _C.ptr(texel), _C.stream()), "qf_texel_indices_packed")
     return texel
+
+
+@torch.no_grad()
+def shade_baked_points(mesh_intersect, uv, compressor, points, index_tri, dirs):
+    """(rgb [n,3], sigma [n]) of samples given by position and triangle: ``texel_indices`` + ``compressor.shade`` in one
+    launch (``qf_texture_shade_points``: the texel is looked up inside the shading kernel, no index array in between).
+    Same values as the two calls."""
+    records, _, _, _ = _triangle_records(mesh_intersect, uv)
+    points, dirs = _C.f32c(points), _C.f32c(dirs)
+    index_tri = _C.i64c(index_tri)
+    n = points.shape[0]
+    rgb = torch.empty((n, 3), dtype=torch.float32, device=points.device)
+    sigma = torch.empty((n,), dtype=torch.float32, device=points.device)
+    _C.check(_C.lib().qf_texture_shade_points(
+        _C.ptr(compressor.records()), int(compressor.alpha.shape[0]), compressor.num_lobes,
+        1 if compressor.compression_type == "sigma" else 0, float(compressor.lambda_thres), _C.ptr(records), _C.ptr(points),
+        _C.ptr(index_tri), _C.ptr(dirs), n, _C.ptr(rgb), _C.ptr(sigma), _C.stream()), "qf_texture_shade_points")
+    return rgb, sigma
 
 
 def render_image_with_occgrid(

@@ -79,6 +79,15 @@ def test_texel_indices_bit_exact(device):
     a = utils.texel_indices(mi, uv_d, xyz, index_tri, size, packed=True)
     b = utils.texel_indices(mi, uv_d, xyz, index_tri, size, packed=False)
     assert torch.equal(a, b) and torch.equal(a, got)
+    # the fused lookup + shading launch of the frame path = the two calls
+    from quadraturefields_amd.texture_utils import FeatureCompression
+    tex = synthetic.random_textures(size, 3, seed=2)
+    comp = FeatureCompression.from_arrays(tex["alpha"], tex["diffuse"], tex["colors"], tex["lambdas"],
+                                          compression_type="linear", lambda_thres=5.0, device=device)
+    dirs = torch.nn.functional.normalize(torch.randn(xyz.shape[0], 3, generator=torch.Generator().manual_seed(1)), dim=-1).to(device)
+    rgb2, sig2 = comp.shade(a, dirs)
+    rgb1, sig1 = utils.shade_baked_points(mi, uv_d, comp, xyz, index_tri, dirs)
+    assert torch.equal(rgb1, rgb2) and torch.equal(sig1, sig2)
     uv_d.mul_(0.5)
     c = utils.texel_indices(mi, uv_d, xyz, index_tri, size, packed=True)
     assert torch.equal(c, utils.texel_indices(mi, uv_d, xyz, index_tri, size, packed=False)) and not torch.equal(c, a)
