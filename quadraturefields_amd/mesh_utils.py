@@ -64,6 +64,28 @@ def trimesh_ray_offset(vertices) -> float:
     return float(np.clip(1e-4 * (100.0 / diag), 1e-8, np.inf))
 
 
+class _PermuteRowsFn(torch.autograd.Function):
+    """``x[perm]`` for a PERMUTATION ``perm``: the backward is a plain scatter (``grad_in[perm] = grad_out``).  torch's
+    own indexing backward has to assume repeated indices and sorts them first (a segmented sort + merge: 20 launches,
+    ~0.3 ms per finetune step for the four re-sorted sample arrays)."""
+
+    @staticmethod
+    def forward(ctx, x, perm):
+        ctx.save_for_backward(perm)
+        return x[perm]
+
+    @staticmethod
+    def backward(ctx, grad):
+        (perm,) = ctx.saved_tensors
+        out = torch.empty_like(grad)
+        out[perm] = grad
+        return out, None
+
+
+def _permute_rows(x, perm):
+    return _PermuteRowsFn.apply(x, perm) if x.requires_grad else x[perm]
+
+
 class _InterView:
     """``RayIntersector.inter``: the native module's two methods, bound to the adapter's BVH."""
 
@@ -692,7 +714,7 @@ class MeshIntersection:
             _C.check(_C.lib().qf_resort_by_depth(_C.ptr(index_ray), _C.ptr(depth_c), n, _C.ptr(perm), _C.stream()),
                      "qf_resort_by_depth")
             index_tri, index_ray = index_tri[perm], index_ray[perm]
-            points, depth, origins, vectors = points[perm], depth[perm], origins[perm], vectors[perm]
+            points, depth, origins, vectors = (_permute_rows(t, perm) for t in (points, depth, origins, vectors))
             boundary = spc_render.mark_pack_boundaries(index_ray)
             return points, self.find_deltas(boundary, depth), boundary, vectors, index_ray, depth, index_tri, origins
         points, depth, origins, vectors = (_C.f32c(t.detach()) for t in (points, depth, origins, vectors))
