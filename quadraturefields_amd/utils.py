@@ -236,8 +236,13 @@ def render_image_finetune_with_occgrid(
         tri_v = mesh_intersect.vertices[_faces_on_device(mesh_intersect)[index_tri]][:, :, 0:3]        # [S,3,3]
         w = torch.rand((xyzs.shape[0], 3), device=device)[..., None]
         verts = torch.sum(tri_v * w, dim=1) / (torch.sum(w, dim=1) + 1e-6)
-        del_vector_v = torch.tanh(field_net(verts, return_grad=False)[0]).expand(-1, 3) * scaling
-        del_vector = torch.tanh(field_net(xyzs, return_grad=False)[0]).expand(-1, 3) * scaling     # [S,1] -> 3 (B-15)
+        # the reference evaluates the deformation field twice (utils.py:547,556: at the random triangle points and at
+        # the samples); one call on both point sets is the same per-point arithmetic with one forward, one MLP backward
+        # and one table scatter instead of two
+        n_v = verts.shape[0]
+        both = torch.tanh(field_net(torch.cat([verts, xyzs], dim=0), return_grad=False)[0]) * scaling
+        del_vector_v = both[:n_v].expand(-1, 3)
+        del_vector = both[n_v:].expand(-1, 3)                                                      # [S,1] -> 3 (B-15)
         del_delta = (del_vector * dirs).sum(-1, keepdim=True)
         dh = del_delta * dirs
         xyzs = xyzs + dh
