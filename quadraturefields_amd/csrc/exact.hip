@@ -1807,8 +1807,12 @@ static int raster_launch(const qf_bvh *bvh, const qf_camera *cam, const float *r
                          int capacity, bool wide, int32_t *hit_tri, float *hit_t, int32_t *hit_count, int32_t *overflow,
                          hipStream_t st)
 {
-    QF_HIP_TRY(hipMemsetAsync(hit_count, 0, (size_t)n_rays * sizeof(int32_t), st));
-    QF_HIP_TRY(hipMemsetAsync(overflow, 0, sizeof(int32_t), st));
+    if (overflow == hit_count + n_rays) {    // the caller put the counter right behind the counts: one fill launch
+        QF_HIP_TRY(hipMemsetAsync(hit_count, 0, (size_t)(n_rays + 1) * sizeof(int32_t), st));
+    } else {
+        QF_HIP_TRY(hipMemsetAsync(hit_count, 0, (size_t)n_rays * sizeof(int32_t), st));
+        QF_HIP_TRY(hipMemsetAsync(overflow, 0, sizeof(int32_t), st));
+    }
     RasterCam rc;
     const float *m = cam->c2w;     // row-major 3x4
     rc.r00 = m[0]; rc.r01 = m[1]; rc.r02 = m[2]; rc.cx = m[3];

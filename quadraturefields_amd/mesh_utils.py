@@ -318,9 +318,11 @@ class RayIntersector:
     def _hits_raster_frame(self, o, d, k, camera):
         """Camera-coherent pass whose overflow counter lives next to the frame's sample total (one readback)."""
         n = o.shape[0]
-        buf = self._frame_scratch(n)[0]
-        hit_tri, hit_t, hit_count = self._alloc_hits(n, k)
-        overflow = buf[n + 1:].view(torch.int32)[:1]           # low word of buf[n+1]; the high word stays zero
+        hit_tri, hit_t, _ = self._alloc_hits(n, k)
+        # the overflow counter rides right behind the counts (qf_raster_intersect then zeroes both with one fill); the
+        # offsets scan copies it to the frame's pinned block together with the sample total (one readback)
+        counts = torch.empty((n + 1,), dtype=torch.int32, device=self.device)
+        hit_count, overflow = counts[:n], counts[n:]
         wide = max(int(self.raster_wide), 0)
         if wide > k:
             key = (n, wide, torch.cuda.current_stream().cuda_stream)
