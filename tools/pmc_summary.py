@@ -13,7 +13,7 @@ for path in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recur
         acc[name][r["Counter_Name"]].append((r.get("Dispatch_Id"), float(r["Counter_Value"])))
 for name, ctrs in sorted(acc.items()):
     if not any(k in name for k in ("field_kernel", "bvh8_", "raster_kernel", "pack_samples", "derive_properties", "deform", "texture_shade",
-                                   "grid_backward")):
+                                   "grid_backward", "pack_tiles", "composite_tiles", "select_nearest")):
         continue
     print(name)
     for c, vals in sorted(ctrs.items()):
