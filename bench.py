@@ -38,7 +38,7 @@ N_SHELLS, SUBDIV = 12, 6           # 12 x 81,920 = 983,040 triangles
 STEP = 5e-3
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 ALG_BYTES_PER_POINT = 16 * 8 * 2 * 4   # 16 levels x 8 corners x 2 features x 4 B
-PROFILE_ROUND = "r2"
+PROFILE_ROUND = "r3"
 
 
 def log(msg):
@@ -210,7 +210,7 @@ def timed_field_events(stages, frames, warm):
 def _committed_traffic(name: str):
     """(bytes per point, source) of a dominant kernel from the committed PMC reduction profiles/<round>/<name>, or
     (None, None): bench.py cannot sample PMC counters itself (separate rocprofv3 --pmc passes, tools/config_traffic.sh)."""
-    for rnd in (PROFILE_ROUND, "r1"):
+    for rnd in (PROFILE_ROUND, "r2", "r1"):
         path = os.path.join(ROOT, "profiles", rnd, name)
         if os.path.exists(path):
             tj = json.load(open(path))
@@ -323,6 +323,103 @@ def config5_line(device, scene, steps=8, warm=3, texture_size=4096, lobes=6):
     }
 
 
+def reference_route_line(device, scene, frames=10, warm=3, texture_size=4096, lobes=6, deform_log2_t=24):
+    """What a maintainer who ONLY swaps imports gets (VERDICT r2 missing 3): the reference's own eval loops restated
+    over the reference-named entry points, next to the FrameRenderer headline.
+
+    * ``finetune_eval``: the ``test()`` closure of train_finetune.py:575-629 -- loader item (SubjectLoader.__getitem__:
+      ray generation, background blend, intersection, the six ray-major sample arrays) -> ``generate_splits`` in
+      160 000-ray windows -> ``render_image_finetune_with_occgrid`` per split with ``field_net`` (T = 2^24 as
+      train_finetune.py:387-399), ``mesh_finetune`` and ``mesh_intersect`` as the harness passes them -> the harness's
+      ``rgb[split[2]] = color[split[2]]`` assembly.  "after": ``scaling = 0`` (the evaluation after the vertex update,
+      comparable with the headline frame); "before": ``scaling = 0.0434`` (deformed evaluation).
+    * ``baking_eval``: the ``test()`` loop of test_baking_texture_images.py:340-372 -- loader item ->
+      ``render_image_bake_texture_images_with_occgrid``.
+    ms/frame from the host clock around the whole loop (device synchronised at both ends)."""
+    from quadraturefields_amd import synthetic, utils
+    from quadraturefields_amd.datasets.nerf_synthetic import SubjectLoader
+    from quadraturefields_amd.field import Field
+    from quadraturefields_amd.mesh_utils import MeshFinetune
+    from quadraturefields_amd.radiance_fields.ngp import NGPRadianceFieldSGNew
+    from quadraturefields_amd.texture_utils import FeatureCompression
+    mesh, mi, field = scene
+    n = frames + warm
+    cams = np.stack([np.asarray(c, dtype=np.float32) for c in synthetic.orbit_cameras(n, seed=42)])
+    images = np.zeros((n, H, W, 4), dtype=np.uint8)          # pixels only feed the PSNR of the harness, not the render
+    ds = SubjectLoader.from_arrays(images, cams, synthetic.lego_focal(W), split="test", mesh_intersect=mi, device=device)
+    field_net = Field(scale=1.5, precision=16, log2_T=deform_log2_t, L=16, max_res=512, min_res=16, output_dim=1,
+                      hidden_size=32, num_features=2, back_prop=False, nl="relu").to(device)
+    mesh_finetune = MeshFinetune(mi.mesh.vertices, mi.mesh.faces, 0.0434, device=device)
+    n_rays = W * H
+
+    def finetune_frame(i, scaling):
+        item = ds[i]
+        rays = item["rays"]
+        splits = utils.generate_splits(item["data"], rays.origins.shape[0])
+        rgb = torch.ones((rays.origins.shape[0], 3), device=device)
+        depth = torch.zeros((rays.origins.shape[0],), device=device)
+        pts = 0
+        for split in splits:
+            color, _, d, n_r_s, _, _, _, _, _ = utils.render_image_finetune_with_occgrid(
+                field, field_net, None, rays, split, near_plane=0.0, render_step_size=STEP,
+                render_bkgd=item["color_bkgd"], cone_angle=0.0, alpha_thre=0.0, mesh_intersect=mi,
+                mesh_finetune=mesh_finetune, scaling=scaling)
+            rgb[split[2]] = color[split[2]]
+            depth[split[2]] = d.squeeze()[split[2]]
+            pts += n_r_s
+        return rgb, depth, pts
+
+    def timed(fn):
+        for i in range(warm):
+            fn(i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        pts = 0
+        for i in range(warm, n):
+            pts += fn(i)[2]
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / frames * 1e3, pts / frames
+
+    after_ms, after_pts = timed(lambda i: finetune_frame(i, 0.0))
+    before_ms, before_pts = timed(lambda i: finetune_frame(i, 0.0434))
+    mesh_finetune.reset_d()
+    del field_net
+    torch.cuda.empty_cache()
+
+    tex = synthetic.random_textures(texture_size, lobes, seed=42)
+    comp = FeatureCompression.from_arrays(tex["alpha"], tex["diffuse"], tex["colors"], tex["lambdas"],
+                                          compression_type="sigmoid", lambda_thres=7.5, device=device)
+    del tex
+    uv = torch.from_numpy(synthetic.scaled_uv(mesh, texture_size)).to(device)
+    sg = NGPRadianceFieldSGNew(aabb=[-1.5] * 3 + [1.5] * 3, use_viewdirs=False, num_g_lobes=lobes,
+                               log2_hashmap_size=14).to(device)
+
+    def baking_frame(i):
+        item = ds[i]
+        rgb, _, depth, n_s, _, _, _, _ = utils.render_image_bake_texture_images_with_occgrid(
+            sg, item["rays"], item["data"], texture=None, uv=uv, near_plane=0.0, render_step_size=STEP,
+            render_bkgd=item["color_bkgd"], cone_angle=0.0, alpha_thre=0.0, mesh_intersect=mi, mesh_finetune=None,
+            scaling=0, discretize=False, compressor=comp)
+        return rgb, depth, n_s
+
+    bake_ms, bake_pts = timed(baking_frame)
+    return {
+        "what": "the reference's eval loops over the reference-named entry points (import swap only, no FrameRenderer): "
+                "SubjectLoader item -> generate_splits (160000-ray windows) -> render_image_finetune_with_occgrid per split "
+                "-> rgb[split[2]] = color[split[2]]; and SubjectLoader item -> render_image_bake_texture_images_with_occgrid",
+        "frames": frames, "rays_per_frame": n_rays,
+        "finetune_eval_after": {"scaling": 0.0, "ms_per_frame": after_ms, "rays_per_s": n_rays / (after_ms * 1e-3),
+                                "quadrature_points_per_frame": after_pts,
+                                "reference": "train_finetune.py:575-629 (test(0, test_dataset))"},
+        "finetune_eval_before": {"scaling": 0.0434, "deform_log2_T": deform_log2_t, "ms_per_frame": before_ms,
+                                 "rays_per_s": n_rays / (before_ms * 1e-3), "quadrature_points_per_frame": before_pts,
+                                 "reference": "train_finetune.py:696 (test(args.scaling, train_whole_dataset))"},
+        "baking_eval": {"texture_size": texture_size, "lobes": lobes, "ms_per_frame": bake_ms,
+                        "rays_per_s": n_rays / (bake_ms * 1e-3), "quadrature_points_per_frame": bake_pts,
+                        "reference": "test_baking_texture_images.py:340-372"},
+    }
+
+
 def sharded_frames(device, rank, world, scene0, n_scenes, frames_per_scene, backend):
     """BASELINE configs[3]: every frame cut into row bands over the ranks, gathered with one collective; eight seeded
     scenes.  Returns the dict for the JSON line (identical on every rank up to timing; rank 0's is printed)."""
@@ -386,6 +483,43 @@ def sharded_frames(device, rank, world, scene0, n_scenes, frames_per_scene, back
     }
 
 
+def launch_guard(args):
+    """``--gpus N`` must run as N ranks or not at all -- never print a 1-rank line for an N-GPU request.
+
+    * launched by torch.distributed.run (WORLD_SIZE set): it has to equal ``--gpus``, else exit 2;
+    * N > 1 and WORLD_SIZE unset (``python bench.py --gpus 8``): this process starts the N ranks itself with the
+      driver's own command line (``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+      127.0.0.1 ...``) as a CHILD process before any HIP call, and exits with its code; if the box shows fewer than N
+      devices (``torch.cuda.device_count()`` does not initialise the GPU) and the run is not a ``--single-device``
+      rehearsal, exit 2."""
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is not None:
+        if int(env_world) != args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={env_world}: launch with "
+                             f"--nproc-per-node {args.gpus} (refusing to report a {env_world}-rank number for it)")
+        return
+    if args.gpus == 1:
+        return
+    if args.gpus < 1:
+        raise SystemExit(f"bench.py: --gpus {args.gpus}")
+    have = torch.cuda.device_count()
+    if have < args.gpus and not args.single_device:
+        print(f"bench.py: --gpus {args.gpus} but this box shows {have} GPU(s) and WORLD_SIZE is unset: refusing to "
+              f"print a 1-rank line for a {args.gpus}-GPU request", file=sys.stderr, flush=True)
+        raise SystemExit(2)
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log(f"--gpus {args.gpus} without a launcher: starting the ranks myself: {' '.join(cmd)}")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -393,6 +527,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the configs[2] / configs[4] lines (N = 1)")
+    ap.add_argument("--no-reference-route", action="store_true",
+                    help="skip the reference_route leg (the reference-named entry points timed beside the headline, N = 1)")
     ap.add_argument("--scenes", type=int, default=8, help="seeded scenes of the sharded_frame loop (0 = skip it)")
     ap.add_argument("--sharded-frames", type=int, default=4, help="frames per scene in the sharded_frame loop")
     ap.add_argument("--spin-up", type=float, default=1.0,
@@ -415,6 +551,7 @@ def main():
     ap.add_argument("--intersector", default="raster", choices=["raster", "bvh"],
                     help="raster: camera-coherent intersector (BVH fallback on overflow); bvh: BVH traversal only")
     args = ap.parse_args()
+    launch_guard(args)                     # before anything touches a GPU
     torch.set_grad_enabled(False)          # inference: the fields take the fused kernels
     global W, H
     W = H = 800 * args.up_sample
@@ -423,8 +560,7 @@ def main():
     if args.single_device:
         os.environ["LOCAL_RANK"] = "0"
     rank, local_rank, world = parallel.init_from_env(args.backend)
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    assert world == args.gpus, (world, args.gpus)      # launch_guard
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
 
@@ -548,7 +684,7 @@ def main():
     # command, see profiles/<round>/README.md); bench.py cannot sample them itself, so the committed measurement is
     # scaled to this run's points per launch.
     traffic = traffic_src = None
-    for rnd in (PROFILE_ROUND, "r1"):
+    for rnd in (PROFILE_ROUND, "r2", "r1"):
         tpath = os.path.join(ROOT, "profiles", rnd, "field_traffic.json")
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
@@ -605,6 +741,10 @@ def main():
     }
     if sharded is not None:
         result["sharded_frame"] = sharded
+    if world == 1 and not args.no_reference_route and args.up_sample == 1:
+        log("reference_route (loader item -> generate_splits -> render_image_finetune_with_occgrid; baked-texture loop)")
+        result["reference_route"] = reference_route_line(device, (mesh, mi, field))
+        torch.cuda.empty_cache()
     if world == 1 and not args.no_configs and args.up_sample == 1:
         log("configs[4] (baked textures)")
         cfg5 = config5_line(device, (mesh, mi, field))

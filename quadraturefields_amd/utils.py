@@ -3,7 +3,7 @@
 Mirrors the hot-path functions of ``examples/utils.py`` of the reference with the same names, arguments and
 return tuples: ``derive_properties`` (:863-898), ``render_image_finetune_with_occgrid`` (:465-607),
 ``render_image_fit_sg_with_occgrid`` (:610-730), ``render_image_bake_texture_images_with_occgrid`` (:998-1095),
-``compress_sigma`` /
+``render_image_with_occgrid`` (:65-172), ``render_image_field_with_occgrid`` (:353-462), ``compress_sigma`` /
 ``inverse_of_compressed_sigma`` (:54-63), plus ``generate_splits`` (``examples/train_finetune.py:419-439``).
 Every tensor stays on the device; the reference's 160 000-sample Python batch loops, its
 ``torch.cuda.empty_cache()`` calls and its host round trips (np.lexsort, trimesh barycentrics) are gone,
@@ -20,6 +20,9 @@ from .datasets.utils import Rays, namedtuple_map
 from .field import Field as _Field
 
 NERF_SYNTHETIC_SCENES = ["chair", "drums", "ficus", "hotdog", "lego", "materials", "mic", "ship"]
+# imported by both harness scripts (train_finetune.py:18, test_baking_texture_images.py:23) and only used to pick the
+# unbounded-scene loader / aabb (train_finetune.py:248), which is out of scope here: the names exist, the branch does not
+MIPNERF360_UNBOUNDED_SCENES = ["garden", "bicycle", "bonsai", "counter", "kitchen", "room", "stump"]
 
 
 def set_random_seed(seed):
@@ -442,3 +445,63 @@ def render_image_with_occgrid(
     extras["t_origins"] = origins
     return (rgb.view((*rays_shape[:-1], -1)), opacity.view((*rays_shape[:-1], -1)), depth.view((*rays_shape[:-1], -1)),
             int(t_starts.shape[0]), extras)
+
+
+def render_image_field_with_occgrid(
+    radiance_field: torch.nn.Module, estimator, rays: Rays, near_plane: float = 0.0, far_plane: float = 1e10,
+    render_step_size: float = 1e-3, render_bkgd: Optional[torch.Tensor] = None, cone_angle: float = 0.0,
+    alpha_thre: float = 0.0, test_chunk_size: int = 8192, timestamps: Optional[torch.Tensor] = None,
+):
+    """Occupancy-grid ray marching + ``rendering_field`` -- utils.py:353-462 of the reference (imported by
+    train_finetune.py:21 and test_baking_texture_images.py:26, called by train_field.py:330): the renderer that also
+    returns the weights of the reversed rays.  Returns the reference's 8-tuple (colors, opacities, depths, n_samples,
+    weights, weights_rev, positions, dirs).  The chunk loop of the reference is kept (``test_chunk_size`` rays per
+    chunk at eval, one chunk in training): colours / opacities / depths / weights do not depend on it, but
+    ``weights_rev`` does -- ``rendering_field`` applies the chunk's ascending pack layout to the flipped samples
+    (field_rendering.py:575-733), so a chunk's reversed weights depend on which rays share the chunk.  Sampling uses
+    ``early_stop_eps=1e-4`` as the reference passes it (utils.py:437)."""
+    from .field_rendering import rendering_field
+    if timestamps is not None:
+        raise NotImplementedError("dynamic (D-NeRF) fields are out of scope")
+    rays, rays_shape, num_rays = _flatten_rays(rays)
+    device = estimator.aabbs.device
+    origins = _C.f32c(rays.origins.to(device))
+    viewdirs = _C.f32c(rays.viewdirs.to(device))
+    results = []
+    chunk = torch.iinfo(torch.int32).max if radiance_field.training else int(test_chunk_size)
+    for i in range(0, num_rays, chunk):
+        c_origins, c_dirs = origins[i:i + chunk], viewdirs[i:i + chunk]
+
+        def positions_of(t_starts, t_ends, ray_indices):
+            return c_origins[ray_indices] + c_dirs[ray_indices] * (t_starts + t_ends)[:, None] / 2.0
+
+        def sigma_fn(t_starts, t_ends, ray_indices):
+            return radiance_field.query_density(positions_of(t_starts, t_ends, ray_indices)).squeeze(-1)
+
+        def rgb_sigma_fn(t_starts, t_ends, ray_indices):
+            rgbs, sigmas = radiance_field(positions_of(t_starts, t_ends, ray_indices), c_dirs[ray_indices])
+            return rgbs, sigmas.squeeze(-1)
+
+        ray_indices, t_starts, t_ends = estimator.sampling(
+            c_origins, c_dirs, sigma_fn=sigma_fn, near_plane=near_plane, far_plane=far_plane,
+            render_step_size=render_step_size, stratified=radiance_field.training, cone_angle=cone_angle,
+            alpha_thre=alpha_thre, early_stop_eps=1e-4)
+        n_chunk = c_origins.shape[0]
+        if t_starts.shape[0] == 0:
+            # the reference's rendering_field takes torch.max of an empty tensor here and raises; a chunk of pure
+            # background is ordinary at eval (8192 rays of an image corner), so it renders as background instead
+            colors = torch.zeros((n_chunk, 3), device=device)
+            if render_bkgd is not None:
+                colors = colors + render_bkgd.to(device)
+            empty = torch.zeros((0,), device=device)
+            results.append([colors, torch.zeros((n_chunk, 1), device=device), torch.zeros((n_chunk, 1), device=device),
+                            0, empty, empty, torch.zeros((0, 3), device=device), torch.zeros((0, 3), device=device)])
+            continue
+        rgb, opacity, depth, weights, weights_rev = rendering_field(
+            t_starts, t_ends, ray_indices, n_rays=n_chunk, rgb_sigma_fn=rgb_sigma_fn, render_bkgd=render_bkgd)
+        results.append([rgb, opacity, depth, int(t_starts.shape[0]), weights, weights_rev,
+                        positions_of(t_starts, t_ends, ray_indices), c_dirs[ray_indices]])
+    colors, opacities, depths, n_rendering_samples, weights, weights_rev, positions, dirs = [
+        torch.cat(r, dim=0) if isinstance(r[0], torch.Tensor) else r for r in zip(*results)]
+    return (colors.view((*rays_shape[:-1], -1)), opacities.view((*rays_shape[:-1], -1)),
+            depths.view((*rays_shape[:-1], -1)), sum(n_rendering_samples), weights, weights_rev, positions, dirs)

@@ -103,3 +103,65 @@ def test_sampling_filter_and_render_image_with_occgrid(device):
     assert (colors.reshape(-1, 3).cpu() - c_o).abs().max().item() <= 5e-4
     assert torch.allclose(opac.reshape(-1, 1).cpu(), a_o, atol=5e-4)
     assert set(["weights", "trans", "alphas", "t_starts", "t_ends", "ray_indices"]) <= set(extras)
+
+
+@pytest.mark.gpu
+def test_render_image_field_with_occgrid_matches_oracle(device):
+    """utils.py:353-462 (harness import of train_finetune.py:21 / test_baking_texture_images.py:26): marching +
+    ``rendering_field`` per ``test_chunk_size`` chunk, against the oracle's restatement chunk by chunk -- colours,
+    opacities, depths, the forward weights and the reversed-ray weights with their pack-layout quirk."""
+    from quadraturefields_amd import synthetic, utils
+    from quadraturefields_amd.datasets.utils import Rays
+    from quadraturefields_amd.estimators import OccGridEstimator
+    from quadraturefields_amd.radiance_fields.ngp import NGPRadianceField
+    aabb = [-1.5] * 3 + [1.5] * 3
+    field = NGPRadianceField(aabb=aabb, log2_hashmap_size=12)
+    field.load_state_dict(synthetic.seeded_ngp_state(12, field.mlp_base.grid.n_rows), strict=False)
+    field = field.to(device).eval()
+    est = OccGridEstimator(roi_aabb=aabb, resolution=32, levels=1).to(device)
+    est.set_occupancy_from_density(lambda p: field.query_density(p), threshold=5.0)
+    w = h = 24
+    c2w = synthetic.orbit_cameras(1, seed=3)[0]
+    o, d = synthetic.camera_rays(c2w, synthetic.lego_focal(800) * w / 800.0, w, h)
+    step, chunk = 0.02, 200                     # 576 rays -> chunks of 200 / 200 / 176
+    wts = helpers.oracle_ngp_weights(field)
+    b = est.binaries[0].cpu().numpy()
+    bk = torch.tensor([1.0, 1.0, 1.0])
+    outs = []
+    for i in range(0, w * h, chunk):
+        oc, dc = o[i:i + chunk], d[i:i + chunk]
+
+        def sigma_fn_o(ts, te, ridx):
+            return ofields.query_density(oc[ridx] + dc[ridx] * (ts + te)[:, None] / 2.0, wts).squeeze(-1)
+
+        def rgb_sigma_fn_o(ts, te, ridx):
+            rgb, sig = ofields.ngp_forward(oc[ridx] + dc[ridx] * (ts + te)[:, None] / 2.0, dc[ridx], wts)
+            return rgb, sig.squeeze(-1)
+
+        ridx_o, ts_o, te_o = oocc.sampling(aabb, b, float(est.occs.mean()), oc.numpy(), dc.numpy(), sigma_fn=sigma_fn_o,
+                                           render_step_size=step, alpha_thre=0.0, early_stop_eps=1e-4)
+        assert ts_o.shape[0] > 0
+        c_o, a_o, dep_o, w_o, wr_o = ov.rendering_field(ts_o, te_o, ridx_o, n_rays=oc.shape[0],
+                                                        rgb_sigma_fn=rgb_sigma_fn_o, render_bkgd=bk)
+        outs.append((c_o, a_o, dep_o, w_o, wr_o, oc[ridx_o] + dc[ridx_o] * (ts_o + te_o)[:, None] / 2.0, dc[ridx_o]))
+    c_o, a_o, dep_o, w_o, wr_o, pos_o, dirs_o = (torch.cat(x, dim=0) for x in zip(*outs))
+    rays = Rays(origins=o.reshape(h, w, 3).to(device), viewdirs=d.reshape(h, w, 3).to(device))
+    with torch.no_grad():
+        colors, opac, depths, n_samples, weights, weights_rev, positions, dirs = utils.render_image_field_with_occgrid(
+            field, est, rays, render_step_size=step, render_bkgd=bk.to(device), test_chunk_size=chunk)
+    assert colors.shape == (h, w, 3) and opac.shape == (h, w, 1) and depths.shape == (h, w, 1)
+    assert (colors.reshape(-1, 3).cpu() - c_o).abs().max().item() <= 5e-4
+    assert torch.allclose(opac.reshape(-1, 1).cpu(), a_o, atol=5e-4)
+    assert torch.allclose(depths.reshape(-1, 1).cpu(), dep_o, atol=2e-3)
+    if n_samples == w_o.shape[0]:               # the visibility filter thresholds a float: equal in practice
+        assert torch.allclose(weights.cpu(), w_o, atol=5e-5)
+        assert torch.allclose(weights_rev.cpu(), wr_o, atol=5e-5)
+        assert torch.allclose(positions.cpu(), pos_o, atol=1e-6) and torch.equal(dirs.cpu(), dirs_o)
+    else:
+        assert abs(n_samples - w_o.shape[0]) <= 3
+    assert weights.shape == weights_rev.shape == (n_samples,)
+    # a chunk of pure background (image corner) renders as background instead of raising on torch.max of nothing
+    far = Rays(origins=(o + 100.0).reshape(h, w, 3).to(device), viewdirs=d.reshape(h, w, 3).to(device))
+    with torch.no_grad():
+        out = utils.render_image_field_with_occgrid(field, est, far, render_step_size=step, render_bkgd=bk.to(device))
+    assert out[3] == 0 and torch.equal(out[0].cpu(), torch.ones(h, w, 3)) and out[4].numel() == 0
