@@ -28,7 +28,7 @@ extern "C" {
 #define QF_ERR_UNSUPPORTED (-3)
 #define QF_ERR_NO_DEVICE (-4)
 
-#define QF_ABI_VERSION 2
+#define QF_ABI_VERSION 3
 #define QF_MAX_LEVELS 16
 #define QF_MAX_LOBES 8
 
@@ -198,9 +198,11 @@ int qf_deform_mlp_backward(const float *enc, const float *x01, const float *d_ou
                            float *d_enc, float *d_x01, float *g_w1, float *g_b1, float *g_w2, float *g_b2,
                            float *g_wout, float *g_bout, void *stream);
 
-/* xyz += (tanh(f)*scaling*(1,1,1) . dir) dir ; ts += same scalar.  utils.py:566-571.          */
-int qf_apply_deformation(const float *f /* [n] */, float scaling, const float *dirs,
-                         float *xyz /* in/out [n,3] */, float *ts /* in/out [n] */, int64_t n,
+/* xyz_out = xyz + dh, ts_out = ts + dd with dd = tanh(f)*scaling*(1,1,1) . dir and dh = dd * dir (utils.py:566-571,
+ * every operation rounded on its own as the reference's tensor ops are).  In place when xyz_out == xyz / ts_out == ts.
+ * dh_out [n,3] or NULL: the reference's ``dh`` itself (what MeshFinetune.update_d accumulates, utils.py:570,598).  */
+int qf_apply_deformation(const float *f /* [n] */, float scaling, const float *dirs, const float *xyz /* [n,3] */,
+                         const float *ts /* [n] */, int64_t n, float *xyz_out, float *ts_out, float *dh_out,
                          void *stream);
 
 /* ------------------------------------------------------------------------------------------
@@ -524,11 +526,35 @@ int qf_resort_by_depth(const int64_t *index_ray, const float *depth, int64_t n, 
 
 /* The whole of sampling_indexing (mesh_utils.py:389-412) in one launch: the re-sort above, the gathers of
  * points / depth / origins / vectors / index_tri through the permutation (index_ray is unchanged by a within-ray
- * sort) and kaolin's mark_pack_boundaries (:407).  perm and boundary may be NULL.               */
+ * sort) and kaolin's mark_pack_boundaries (:407).  perm and boundary may be NULL.
+ * inverse (or NULL; from qf_split_layout / qf_coherent_layout on the same index_ray): the launch also writes the
+ * re-sorted positions and directions a second time at out_points_c / out_vectors_c [inverse[i]] -- the copies
+ * qf_field_forward streams (see qf_pack_samples).                                                 */
 int qf_resort_samples(const int64_t *index_ray, const float *depth, int64_t n, const float *points,
                       const float *origins, const float *vectors, const int64_t *index_tri,
                       int64_t *perm, float *out_points, float *out_depth, float *out_origins,
-                      float *out_vectors, int64_t *out_index_tri, uint8_t *boundary, void *stream);
+                      float *out_vectors, int64_t *out_index_tri, uint8_t *boundary, const int32_t *inverse,
+                      float *out_points_c, float *out_vectors_c, void *stream);
+
+/* The coherent processing order of qf_coherent_layout for the samples of ONE SPLIT of a frame -- the windows of
+ * generate_splits (train_finetune.py:419-439) that render_image_finetune_with_occgrid (utils.py:465-607) receives --
+ * from nothing but the split's ray ids: index_ray [n] int64, ascending (grouped by ray, as the reference's loader
+ * leaves them, mesh_utils.py:373-381), ids of a row-major width x height frame.  Four launches, no host round trip.
+ * Scratch the caller provides: hit_count int32 [w*h], ray_offset int64 [w*h+1], tile_base int64
+ * [ceil(w/8)*ceil(h/8)], invalid int32 [1].  Outputs: inverse int32 [n] (inverse[sample] = position), order int32 [n]
+ * or NULL.  If the ids are NOT ascending or lie outside the frame, *invalid is set on the device and order / inverse
+ * are the identity (the batch is then processed in its own order; results do not depend on the order).  */
+int qf_split_layout(const int64_t *index_ray, int64_t n, int32_t width, int32_t height, int32_t *hit_count,
+                    int64_t *ray_offset, int64_t *tile_base, int32_t *invalid, int32_t *order, int32_t *inverse,
+                    void *stream);
+
+/* MeshFinetune.update_d (mesh_utils.py:126-131; called per split by render_image_finetune_with_occgrid,
+ * utils.py:596-600): cache_d[index_tri[i]] += d[i] * w[i], cache_w[index_tri[i]] += w[i] in one launch (fp32
+ * atomics, as torch's index_add_).  cache [n_faces, 4]: cache_d in columns 0-2 and cache_w in column 3 of one
+ * 16-byte row per triangle, so that a sample's four atomics are one memory request.  d == NULL: the displacement
+ * is identically zero, only the weight column moves.                                                */
+int qf_mesh_update_d(const float *d /* [n,3] or NULL */, const float *w /* [n] */, const int64_t *index_tri, int64_t n,
+                     int64_t n_faces, float *cache /* [n_faces,4] */, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Baked spherical-Gaussian textures.

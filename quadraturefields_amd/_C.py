@@ -70,7 +70,7 @@ _SIGNATURES = {
     "qf_sg_features_to_rgb_backward": (c_int, [_P, c_int64, _P, _P, c_int64, c_int32, _P, c_int64, _P]),
     "qf_deform_field_forward": (c_int, [POINTER(GridDesc), _P, c_float, c_int32, _P, _P, _P, _P, _P, _P, _P, c_int64, _P, _P, _P, _P]),
     "qf_deform_mlp_backward": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
-    "qf_apply_deformation": (c_int, [_P, c_float, _P, _P, _P, c_int64, _P]),
+    "qf_apply_deformation": (c_int, [_P, c_float, _P, _P, _P, c_int64, _P, _P, _P, _P]),
     "qf_mark_pack_boundaries": (c_int, [_P, c_int64, _P, _P]),
     "qf_exponential_integration": (c_int, [_P, c_int32, _P, _P, c_int64, c_int64, c_int32, _P, _P, _P]),
     "qf_sum_reduce": (c_int, [_P, c_int32, _P, c_int64, c_int64, _P, _P]),
@@ -119,7 +119,9 @@ _SIGNATURES = {
     "qf_coherent_order": (c_int, [_P, _P, _P, c_int32, c_int32, _P, _P]),
     "qf_coherent_layout": (c_int, [_P, _P, _P, c_int32, c_int32, _P, _P, _P]),
     "qf_resort_by_depth": (c_int, [_P, _P, c_int64, _P, _P]),
-    "qf_resort_samples": (c_int, [_P, _P, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "qf_resort_samples": (c_int, [_P, _P, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "qf_split_layout": (c_int, [_P, c_int64, c_int32, c_int32, _P, _P, _P, _P, _P, _P, _P]),
+    "qf_mesh_update_d": (c_int, [_P, _P, _P, c_int64, c_int64, _P, _P]),
     "qf_texel_indices": (c_int, [_P, _P, _P, _P, _P, c_int64, c_int32, _P, _P]),
     "qf_texel_records_pack": (c_int, [_P, _P, _P, c_int64, _P, _P]),
     "qf_texel_indices_packed": (c_int, [_P, _P, _P, c_int64, c_int32, _P, _P]),
@@ -130,6 +132,7 @@ _SIGNATURES = {
     "qf_texture_shade_points": (c_int, [_P, c_int32, c_int32, c_int32, c_float, _P, _P, _P, _P, c_int64, _P, _P, _P]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+ABI_VERSION = 3              # QF_ABI_VERSION of include/qf_hip.h
 
 _lib = None
 
@@ -147,7 +150,7 @@ def lib() -> ctypes.CDLL:
             fn = getattr(handle, name)   # AttributeError if the symbol is not exported
             fn.restype = restype
             fn.argtypes = argtypes
-        if handle.qf_abi_version() != 2:
+        if handle.qf_abi_version() != ABI_VERSION:
             raise RuntimeError("libqf_hip.so ABI version mismatch")
         _lib = handle
     return _lib

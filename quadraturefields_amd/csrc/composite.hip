@@ -285,7 +285,7 @@ __global__ void render_from_density_kernel(const float *ts, const float *te, con
 // reference's tensor ops are (no contraction, see composite_step): v = tanh(f) * scaling; dd = (v dx + v dy) + v dz;
 // p += dd * d; t += dd.
 __device__ __forceinline__ void deform_sample(float f, float scaling, float dx, float dy, float dz, float &x, float &y,
-                                              float &z, float &t)
+                                              float &z, float &t, float *dh = nullptr)
 {
 #pragma clang fp contract(off)
     const float v = tanhf(f) * scaling;
@@ -296,17 +296,21 @@ __device__ __forceinline__ void deform_sample(float f, float scaling, float dx, 
     y = y + my;
     z = z + mz;
     t = t + dd;
+    if (dh) { dh[0] = mx; dh[1] = my; dh[2] = mz; }     // the reference's ``dh = del_delta * dirs`` (utils.py:570)
 }
 
-__global__ void apply_deformation_kernel(const float *f, float scaling, const float *dirs, float *xyz, float *ts, int64_t n)
+__global__ void apply_deformation_kernel(const float *f, float scaling, const float *dirs, const float *xyz,
+                                         const float *ts, int64_t n, float *xyz_out, float *ts_out, float *dh_out)
 {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         float x = xyz[i * 3], y = xyz[i * 3 + 1], z = xyz[i * 3 + 2], t = ts[i];
-        deform_sample(f[i], scaling, dirs[i * 3], dirs[i * 3 + 1], dirs[i * 3 + 2], x, y, z, t);
-        xyz[i * 3 + 0] = x;
-        xyz[i * 3 + 1] = y;
-        xyz[i * 3 + 2] = z;
-        ts[i] = t;
+        float dh[3];
+        deform_sample(f[i], scaling, dirs[i * 3], dirs[i * 3 + 1], dirs[i * 3 + 2], x, y, z, t, dh);
+        xyz_out[i * 3 + 0] = x;
+        xyz_out[i * 3 + 1] = y;
+        xyz_out[i * 3 + 2] = z;
+        ts_out[i] = t;
+        if (dh_out) { dh_out[i * 3] = dh[0]; dh_out[i * 3 + 1] = dh[1]; dh_out[i * 3 + 2] = dh[2]; }
     }
 }
 
@@ -413,13 +417,13 @@ extern "C" int qf_render_from_density(const float *t_starts, const float *t_ends
     return QF_OK;
 }
 
-extern "C" int qf_apply_deformation(const float *f, float scaling, const float *dirs, float *xyz, float *ts, int64_t n,
-                                    void *stream)
+extern "C" int qf_apply_deformation(const float *f, float scaling, const float *dirs, const float *xyz, const float *ts,
+                                    int64_t n, float *xyz_out, float *ts_out, float *dh_out, void *stream)
 {
     if (n < 0) return QF_ERR_INVALID_ARGUMENT;
     if (n == 0) return QF_OK;
-    if (!f || !dirs || !xyz || !ts) return QF_ERR_INVALID_ARGUMENT;
-    QF_SIMPLE_LAUNCH(apply_deformation_kernel, n, f, scaling, dirs, xyz, ts, n);
+    if (!f || !dirs || !xyz || !ts || !xyz_out || !ts_out) return QF_ERR_INVALID_ARGUMENT;
+    QF_SIMPLE_LAUNCH(apply_deformation_kernel, n, f, scaling, dirs, xyz, ts, n, xyz_out, ts_out, dh_out);
     return QF_OK;
 }
 
@@ -738,6 +742,147 @@ extern "C" int qf_scatter_max(const float *values, const int64_t *index, int64_t
     if (!values || !index || !out) return QF_ERR_INVALID_ARGUMENT;
     hipLaunchKernelGGL(scatter_max_kernel, dim3(qf_grid_1d(n, 256)), dim3(256), 0, qf_stream(stream), values, index, n,
                        n_out, out);
+    QF_LAUNCH_CHECK();
+    return QF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Coherent processing order of a SPLIT (the 160 000-ray windows of generate_splits, train_finetune.py:419-439) from
+// nothing but its sorted ray ids: the reference-shaped entry point render_image_finetune_with_occgrid receives the six
+// sample tensors of a window of a frame and no processing order; without one the field kernel runs ray-major at
+// 0.58 ms per 10^6 points instead of 0.34.  Four launches, no host round trip:
+//   1. split_rays_kernel: per ray r of the frame, ray_offset[r] = lower_bound(index_ray, r) (binary search in the
+//      sorted ids) and hit_count[r] = the run length; the same launch verifies that the ids ARE sorted and in range
+//      and raises *invalid otherwise;
+//   2.+3. the tile totals and their exclusive scan (frame_partials_kernel / frame_scan_kernel via qf_tile_offsets);
+//   4. coherent_order_kernel.  When *invalid is set it writes the identity instead -- an unsorted batch renders in its
+//      own order rather than through a layout derived from garbage counts (whose positions could exceed n).
+namespace {
+
+__global__ void split_rays_kernel(const int64_t *__restrict__ index_ray, int64_t n, int64_t n_rays,
+                                  int32_t *__restrict__ hit_count, int64_t *__restrict__ ray_offset, int32_t *invalid)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x, t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int bad = 0;
+    for (int64_t i = t0; i < n; i += stride) {
+        const int64_t r = index_ray[i];
+        bad |= (r < 0) | (r >= n_rays) | (i + 1 < n && index_ray[i + 1] < r);
+    }
+    if (bad) atomicOr(invalid, 1);
+    for (int64_t r = t0; r <= n_rays; r += stride) {
+        int64_t lo = 0, hi = n;                      // first i with index_ray[i] >= r
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (index_ray[mid] < r) lo = mid + 1; else hi = mid;
+        }
+        ray_offset[r] = lo;
+        if (r < n_rays) {
+            int64_t e = lo, he = n;                  // first i with index_ray[i] > r: runs are short, gallop from lo
+            int64_t step = 1;
+            while (e + step < he && index_ray[e + step] <= r) { e += step; step <<= 1; }
+            he = e + step < he ? e + step : he;
+            while (e < he) {
+                const int64_t mid = (e + he) >> 1;
+                if (index_ray[mid] <= r) e = mid + 1; else he = mid;
+            }
+            hit_count[r] = (int32_t)(e - lo);
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void split_order_kernel(const int32_t *hit_count, const int64_t *ray_offset,
+                                                         const int64_t *tile_base, int w, int h, int tiles_x, int64_t n,
+                                                         const int32_t *invalid, int32_t *order, int32_t *inverse)
+{
+    const int tile = blockIdx.x, lane = threadIdx.x;
+    if (*invalid) {                                   // identity, the tiles sharing [0, n)
+        const int64_t per = (n + gridDim.x - 1) / gridDim.x, i0 = per * tile, i1 = i0 + per < n ? i0 + per : n;
+        for (int64_t i = i0 + lane; i < i1; i += 64) {
+            if (order) order[i] = (int32_t)i;
+            inverse[i] = (int32_t)i;
+        }
+        return;
+    }
+    int64_t ray = 0;
+    int cnt = 0;
+    int64_t first = 0;
+    if (tile_lane_ray(tile, lane, w, h, tiles_x, &ray)) { cnt = hit_count[ray]; first = ray_offset[ray]; }
+    int64_t base = tile_base[tile];
+    const unsigned long long below = (1ull << lane) - 1ull;
+    for (int k = 0;; ++k) {
+        const unsigned long long mask = __ballot(cnt > k);
+        if (mask == 0ull) break;
+        if (cnt > k) {
+            const int64_t pos = base + __popcll(mask & below), smp = first + k;
+            if (order) order[pos] = (int32_t)smp;
+            inverse[smp] = (int32_t)pos;
+        }
+        base += __popcll(mask);
+    }
+}
+
+// MeshFinetune.update_d (mesh_utils.py:126-131): cache_d[tri] += d * w, cache_w[tri] += w, one launch (the reference
+// issues two torch index_add_).  d == NULL: the displacement is identically zero (scaling 0) and only cache_w moves.
+// cache [n_faces, 4] = (sum d w | sum w) per triangle, one 16-byte row: FOUR lanes serve a sample, lane q adds component
+// q, so the four atomics of a sample are one instruction on one 16-byte piece of one line -- the memory pipeline carries
+// them as ONE request (the trick of grid_backward_table_kernel).  The atomic rate is per request (~1.9e10/s chip-wide),
+// so 10^6 samples cost ~50 us instead of the ~200 us of four separate atomics per lane.
+__global__ void mesh_update_d_kernel(const float *__restrict__ d, const float *__restrict__ w,
+                                     const int64_t *__restrict__ index_tri, int64_t n, int64_t n_faces, float *cache)
+{
+#pragma clang fp contract(off)
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    if (!d) {                                         // zero displacement: only the weight column moves
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+            const int64_t t = index_tri[i];
+            if (t >= 0 && t < n_faces) unsafeAtomicAdd(cache + t * 4 + 3, w[i]);
+        }
+        return;
+    }
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < 4 * n; e += stride) {
+        const int64_t i = e >> 2;
+        const int c = (int)(e & 3);
+        const int64_t t = index_tri[i];
+        if (t < 0 || t >= n_faces) continue;
+        const float wi = w[i];
+        unsafeAtomicAdd(cache + t * 4 + c, c < 3 ? d[i * 3 + c] * wi : wi);
+    }
+}
+
+}  // namespace
+
+extern "C" int qf_split_layout(const int64_t *index_ray, int64_t n, int32_t width, int32_t height, int32_t *hit_count,
+                               int64_t *ray_offset, int64_t *tile_base, int32_t *invalid, int32_t *order,
+                               int32_t *inverse, void *stream)
+{
+    if (n < 0 || n >= 0x7fffffff || width < 1 || height < 1) return QF_ERR_INVALID_ARGUMENT;
+    const int64_t n_rays = (int64_t)width * height;
+    if (n_rays >= 0x7fffffff) return QF_ERR_INVALID_ARGUMENT;
+    if (!hit_count || !ray_offset || !tile_base || !invalid || !inverse || (n > 0 && !index_ray))
+        return QF_ERR_INVALID_ARGUMENT;
+    hipStream_t st = qf_stream(stream);
+    QF_HIP_TRY(hipMemsetAsync(invalid, 0, sizeof(int32_t), st));
+    hipLaunchKernelGGL(split_rays_kernel, dim3(qf_grid_1d(n_rays + 1, 256)), dim3(256), 0, st, index_ray, n, n_rays,
+                       hit_count, ray_offset, invalid);
+    QF_LAUNCH_CHECK();
+    // tile bases: exclusive scan of the 8x8-tile totals (the grand total lands in ray_offset[n_rays], where it already is)
+    int rc = qf_tile_offsets(hit_count, 0x7fffffff, width, height, tile_base, ray_offset + n_rays, nullptr, nullptr, stream);
+    if (rc != QF_OK) return rc;
+    const int tiles_x = (width + 7) / 8, tiles_y = (height + 7) / 8;
+    hipLaunchKernelGGL(split_order_kernel, dim3(tiles_x * tiles_y), dim3(64), 0, st, hit_count, ray_offset, tile_base,
+                       (int)width, (int)height, tiles_x, n, invalid, order, inverse);
+    QF_LAUNCH_CHECK();
+    return QF_OK;
+}
+
+extern "C" int qf_mesh_update_d(const float *d, const float *w, const int64_t *index_tri, int64_t n, int64_t n_faces,
+                                float *cache, void *stream)
+{
+    if (n < 0 || n_faces < 0) return QF_ERR_INVALID_ARGUMENT;
+    if (n == 0) return QF_OK;
+    if (!w || !index_tri || !cache) return QF_ERR_INVALID_ARGUMENT;
+    hipLaunchKernelGGL(mesh_update_d_kernel, dim3(qf_grid_1d(d ? 4 * n : n, 256)), dim3(256), 0, qf_stream(stream), d, w,
+                       index_tri, n, n_faces, cache);
     QF_LAUNCH_CHECK();
     return QF_OK;
 }

@@ -1103,7 +1103,8 @@ constexpr int RS_STAGE = RS_CHUNK + RS_HALO;
 __global__ __launch_bounds__(RS_THREADS) void resort_samples_kernel(
     const int64_t *index_ray, const float *depth, int64_t n, const float *points, const float *origins,
     const float *vectors, const int64_t *index_tri, int64_t *perm, float *out_points, float *out_depth,
-    float *out_origins, float *out_vectors, int64_t *out_index_tri, uint8_t *boundary)
+    float *out_origins, float *out_vectors, int64_t *out_index_tri, uint8_t *boundary, const int32_t *inverse,
+    float *out_points_c, float *out_vectors_c)
 {
     __shared__ float s_depth[RS_STAGE];
     __shared__ int64_t s_ray[RS_STAGE + 1];
@@ -1165,10 +1166,15 @@ __global__ __launch_bounds__(RS_THREADS) void resort_samples_kernel(
                     if (perm) perm[dst] = q;
                     out_depth[dst] = dq;
                     out_index_tri[dst] = index_tri[q];
+                    const int64_t pos_c = inverse ? (int64_t)inverse[dst] : 0;
                     for (int c = 0; c < 3; ++c) {
                         out_points[dst * 3 + c] = points[q * 3 + c];
                         out_origins[dst * 3 + c] = origins[q * 3 + c];
                         out_vectors[dst * 3 + c] = vectors[q * 3 + c];
+                        if (inverse) {
+                            out_points_c[pos_c * 3 + c] = points[q * 3 + c];
+                            out_vectors_c[pos_c * 3 + c] = vectors[q * 3 + c];
+                        }
                     }
                 }
             }
@@ -1185,9 +1191,15 @@ __global__ __launch_bounds__(RS_THREADS) void resort_samples_kernel(
             const int k = e / 3, c = e - 3 * k;
             if (!s_mine[k]) continue;
             const int64_t src = (b0 + s_src[k]) * 3 + c, dst = b0 * 3 + e;
-            out_points[dst] = points[src];
+            const float pv = points[src], vv = vectors[src];
+            out_points[dst] = pv;
             out_origins[dst] = origins[src];
-            out_vectors[dst] = vectors[src];
+            out_vectors[dst] = vv;
+            if (inverse) {                            // second copy at the sample's place in the coherent order
+                const int64_t pc = (int64_t)inverse[b0 + k] * 3 + c;
+                out_points_c[pc] = pv;
+                out_vectors_c[pc] = vv;
+            }
         }
         __syncthreads();
     }
@@ -1693,17 +1705,18 @@ extern "C" int qf_resort_by_depth(const int64_t *index_ray, const float *depth, 
 extern "C" int qf_resort_samples(const int64_t *index_ray, const float *depth, int64_t n, const float *points,
                                  const float *origins, const float *vectors, const int64_t *index_tri, int64_t *perm,
                                  float *out_points, float *out_depth, float *out_origins, float *out_vectors,
-                                 int64_t *out_index_tri, uint8_t *boundary, void *stream)
+                                 int64_t *out_index_tri, uint8_t *boundary, const int32_t *inverse, float *out_points_c,
+                                 float *out_vectors_c, void *stream)
 {
     if (n < 0) return QF_ERR_INVALID_ARGUMENT;
     if (n == 0) return QF_OK;
     if (!index_ray || !depth || !points || !origins || !vectors || !index_tri || !out_points || !out_depth ||
-        !out_origins || !out_vectors || !out_index_tri)
+        !out_origins || !out_vectors || !out_index_tri || (inverse && (!out_points_c || !out_vectors_c)))
         return QF_ERR_INVALID_ARGUMENT;
     const int64_t n_chunks = (n + RS_CHUNK - 1) / RS_CHUNK;
     hipLaunchKernelGGL(resort_samples_kernel, dim3((unsigned)(n_chunks < 65536 ? n_chunks : 65536)), dim3(RS_THREADS), 0,
                        qf_stream(stream), index_ray, depth, n, points, origins, vectors, index_tri, perm, out_points,
-                       out_depth, out_origins, out_vectors, out_index_tri, boundary);
+                       out_depth, out_origins, out_vectors, out_index_tri, boundary, inverse, out_points_c, out_vectors_c);
     QF_LAUNCH_CHECK();
     return QF_OK;
 }

@@ -134,6 +134,8 @@ class RayIntersector:
         self._scratch = {}               # per-ray-count frame scratch, see _frame_scratch
         self.last_layout = None          # (inverse, xyz, dirs) of the most recent image-shaped pack, in the coherent order
         self.last_frame = None           # what utils.composite_frame needs of that pack (depths in the coherent order, ...)
+        self.last_image_shape = None     # (width, height) of the most recent image-shaped batch (see split_layout)
+        self._split_scratch = {}
         self._handle = ctypes.c_void_p()
         tri = np.ascontiguousarray(mesh.vertices.astype(np.float32)[mesh.faces].reshape(-1, 9))
         with torch.cuda.device(self.device):
@@ -293,26 +295,34 @@ class RayIntersector:
         return hit_tri.reshape(-1).cpu().numpy()
 
     def _frame_scratch(self, n):
-        """Per-ray-count scratch reused across frames: [n+3] int64 = sample offsets | total | raster overflow counter |
+        """Frame scratch reused across frames: [n+3] int64 = sample offsets | total | raster overflow counter |
         hits dropped by the tile pack's re-origin rule,
         the scan's temp storage, a pinned (device-writable) host block [total, overflow, close-pair flag or dropped hits, -] that the
-        kernels write directly, and the two events that guard it (after the offsets; after the pack)."""
+        kernels write directly, and the two events that guard it (after the offsets; after the pack).
+        One entry per (stream, slot), sized for the LARGEST ray count seen there: the band-sharded renderer moves its
+        cuts every frame, and keying by n would allocate -- and pin -- a fresh block for every new band height; the
+        pinned block and the events are never replaced, only the device buffers grow."""
         # frames in flight on different streams, or two consecutive frames of a front / back pipeline (``scratch_slot``
         # alternates: the next frame's offsets kernel must not overwrite the pinned block the host has not read yet),
         # do not share it
-        key = (n, torch.cuda.current_stream().cuda_stream, self.scratch_slot)
+        key = (torch.cuda.current_stream().cuda_stream, self.scratch_slot)
         s = self._scratch.get(key)
         if s is None:
-            buf = torch.zeros((n + 3,), dtype=torch.int64, device=self.device)
-            nbytes = int(_C.lib().qf_frame_offsets_temp_bytes(n))
+            host = torch.zeros((4,), dtype=torch.int64).pin_memory()
+            # the tile pack's dropped-hit counter: its own fixed word (the kernel that publishes it leaves it at zero
+            # for the next frame, so it must not move with n)
+            dropped = torch.zeros((1,), dtype=torch.int32, device=self.device)
+            s = self._scratch[key] = [0, None, None, host, (torch.cuda.Event(), torch.cuda.Event()), dropped]
+        if n > s[0]:
+            cap = max(n, 2 * s[0]) if s[0] else n
+            nbytes = int(_C.lib().qf_frame_offsets_temp_bytes(cap))
             if nbytes < 0:
                 raise _C.QFError("qf_frame_offsets_temp_bytes failed")
-            temp = torch.empty((nbytes,), dtype=torch.uint8, device=self.device)
-            host = torch.zeros((4,), dtype=torch.int64).pin_memory()
-            s = self._scratch[key] = (buf, temp, host, (torch.cuda.Event(), torch.cuda.Event()))
-            if len(self._scratch) > 16:
-                self._scratch.pop(next(iter(self._scratch)))
-        return s
+            # stream-ordered allocator: the previous buffers are only reused after the kernels queued on them ran
+            s[1] = torch.zeros((cap + 3,), dtype=torch.int64, device=self.device)
+            s[2] = torch.empty((nbytes,), dtype=torch.uint8, device=self.device)
+            s[0] = cap
+        return s[1][:n + 3], s[2], s[3], s[4], s[5]
 
     @_on_device
     def _hits_raster_frame(self, o, d, k, camera):
@@ -392,9 +402,10 @@ class RayIntersector:
         render looks its texels up by triangle).  ``layout=False``: no processing order at all."""
         n = o.shape[0]
         dev = self.device
-        buf, temp, host, (ev, ev_flag) = self._frame_scratch(n)
+        buf, temp, host, (ev, ev_flag), dropped = self._frame_scratch(n)
         cap = n * k
         image = bool(layout) and width > 0 and n % width == 0
+        self.last_image_shape = (int(width), n // int(width)) if width > 0 and n % width == 0 else None
         # sample offsets (+ total) and, for an image, the tile bases of the coherent order: three small launches
         tile_base = None
         if image:
@@ -434,7 +445,6 @@ class RayIntersector:
             layout = (None, xyz_c, dirs_c)
             optimistic = False
             final_count = torch.empty((n,), dtype=torch.int32, device=dev)
-            dropped = buf[n + 2:].view(torch.int32)[:1]
             frame.tri_c = torch.empty((cap,), dtype=torch.int64, device=dev) if want_tri else None
             _C.check(_C.lib().qf_pack_tiles(_C.ptr(o), _C.ptr(d), int(width), n // int(width), k, _C.ptr(hit_tri),
                                             _C.ptr(hit_t), _C.ptr(hit_count), _C.ptr(tile_base), _C.ptr(buf[n:]),
@@ -599,6 +609,37 @@ class RayIntersector:
         return order, inverse
 
     @_on_device
+    def split_layout(self, index_ray: torch.Tensor, width: int, height: int, want_order: bool = True):
+        """(order or None, inverse, invalid flag) -- the coherent processing order of ``coherent_layout`` for the samples
+        of one SPLIT of a ``width x height`` frame, from its ascending ray ids alone (``qf_split_layout``: four launches,
+        no host wait).  This is what lets ``render_image_finetune_with_occgrid`` stream the field kernel when the
+        caller -- the reference's eval loop -- hands it a 160 000-ray window and no order.  Ids that are not ascending
+        or lie outside the frame give the identity (flag set on the device, not read here)."""
+        index_ray = _C.i64c(index_ray)
+        n = index_ray.shape[0]
+        n_rays = int(width) * int(height)
+        if n == 0:
+            empty = torch.empty((0,), dtype=torch.int32, device=self.device)
+            return (empty if want_order else None), empty.clone(), torch.zeros((1,), dtype=torch.int32, device=self.device)
+        key = (n_rays, int(width), torch.cuda.current_stream().cuda_stream)
+        sc = self._split_scratch.get(key)
+        if sc is None:
+            if len(self._split_scratch) > 4:
+                self._split_scratch.clear()
+            tiles = ((width + 7) // 8) * ((height + 7) // 8)
+            sc = self._split_scratch[key] = (torch.empty((n_rays,), dtype=torch.int32, device=self.device),
+                                             torch.empty((n_rays + 1,), dtype=torch.int64, device=self.device),
+                                             torch.empty((tiles,), dtype=torch.int64, device=self.device),
+                                             torch.zeros((1,), dtype=torch.int32, device=self.device))
+        hit_count, ray_offset, tile_base, invalid = sc
+        order = torch.empty((n,), dtype=torch.int32, device=self.device) if want_order else None
+        inverse = torch.empty((n,), dtype=torch.int32, device=self.device)
+        _C.check(_C.lib().qf_split_layout(_C.ptr(index_ray), n, int(width), int(height), _C.ptr(hit_count),
+                                          _C.ptr(ray_offset), _C.ptr(tile_base), _C.ptr(invalid), _C.ptr(order),
+                                          _C.ptr(inverse), _C.stream()), "qf_split_layout")
+        return order, inverse, invalid
+
+    @_on_device
     def coherent_order(self, hit_count: torch.Tensor, ray_offset: torch.Tensor, total: int, width: int) -> torch.Tensor:
         """int32 permutation of the ``total`` packed samples of a row-major ``width``-wide image, ordered
         (8x8 tile, hit rank, pixel).  Handing it to ``radiance_field(points, dirs, order=...)`` makes the points of
@@ -633,14 +674,25 @@ class MeshFinetune:
         self.vertices = np.array(vertices).astype(np.float32)
         self.device = torch.device(device)
         self.faces = torch.from_numpy(np.asarray(faces)).to(self.device).long()
-        self.cache_d = torch.zeros((self.faces.shape[0], 3), device=self.device)
-        self.cache_w = torch.ones(self.faces.shape[0], device=self.device) * 1e-8
+        # one 16-byte row per triangle (sum d w | sum w): qf_mesh_update_d's four atomics of a sample are one request
+        self._cache = torch.zeros((self.faces.shape[0], 4), device=self.device)
+        self.cache_d = self._cache[:, :3]                 # the reference's two attributes, as views
+        self.cache_w = self._cache[:, 3]
+        self.cache_w[:] = 1e-8
         self.scaling = scaling
 
     @torch.no_grad()
     def update_d(self, d, w, index_tri):
-        self.cache_d.index_add_(0, index_tri, d * w[..., None])
-        self.cache_w.index_add_(0, index_tri, w)
+        """cache_d[tri] += d * w, cache_w[tri] += w (mesh_utils.py:126-131) in one launch (``qf_mesh_update_d``).
+        ``d`` may be None: a displacement that is identically zero (``scaling == 0``) leaves cache_d as it is."""
+        n = int(w.shape[0])
+        if n == 0:
+            return
+        with torch.cuda.device(self.device):
+            _C.check(_C.lib().qf_mesh_update_d(
+                _C.ptr(_C.f32c(d.reshape(-1, 3))) if d is not None else None, _C.ptr(_C.f32c(w.reshape(-1))),
+                _C.ptr(_C.i64c(index_tri.reshape(-1))), n, int(self.faces.shape[0]), _C.ptr(self._cache), _C.stream()),
+                "qf_mesh_update_d")
 
     @torch.no_grad()
     def update_faces(self):
@@ -702,11 +754,15 @@ class MeshIntersection:
         xyz, dirs, index_ray, depth, index_tri, org = [t.cpu().numpy() for t in out]
         return xyz, dirs, index_ray, depth, index_tri, 0, org
 
-    def sampling_indexing(self, points, origins, vectors, index_ray, depth, index_tri, random=0):
+    def sampling_indexing(self, points, origins, vectors, index_ray, depth, index_tri, random=0, layout_inverse=None):
         """Re-sort by (ray, depth) after deformation, boundaries, deltas -- mesh_utils.py:389-412, without
         leaving the device.  Inference: ONE launch (``qf_resort_samples``: sort, gathers and boundaries fused).
         When autograd is recording on the inputs (training) the permutation is applied with differentiable
-        indexing instead."""
+        indexing instead.
+        ``layout_inverse`` (extension, inference only; from ``RayIntersector.split_layout`` on the same ``index_ray``):
+        the launch also writes the re-sorted positions / directions in the coherent order; they are left in
+        ``self.last_resort_layout = (points_c, vectors_c)`` (the return value keeps the reference's 8-tuple)."""
+        self.last_resort_layout = None
         index_ray = _C.i64c(index_ray)
         n = depth.shape[0]
         dev = depth.device
@@ -724,8 +780,16 @@ class MeshIntersection:
         o_points, o_origins, o_vectors = torch.empty_like(points), torch.empty_like(origins), torch.empty_like(vectors)
         o_depth, o_tri = torch.empty_like(depth), torch.empty_like(index_tri)
         boundary = torch.empty((n,), dtype=torch.bool, device=dev)
+        points_c = vectors_c = None
+        if layout_inverse is not None:
+            if layout_inverse.shape[0] != n:
+                raise ValueError(f"layout_inverse has {layout_inverse.shape[0]} entries for {n} samples")
+            points_c, vectors_c = torch.empty_like(points), torch.empty_like(vectors)
         _C.check(_C.lib().qf_resort_samples(
             _C.ptr(index_ray), _C.ptr(depth), n, _C.ptr(points), _C.ptr(origins), _C.ptr(vectors), _C.ptr(index_tri),
             None, _C.ptr(o_points), _C.ptr(o_depth), _C.ptr(o_origins), _C.ptr(o_vectors), _C.ptr(o_tri),
-            _C.ptr(boundary), _C.stream()), "qf_resort_samples")
+            _C.ptr(boundary), _C.ptr(layout_inverse, torch.int32), _C.ptr(points_c), _C.ptr(vectors_c), _C.stream()),
+            "qf_resort_samples")
+        if layout_inverse is not None:
+            self.last_resort_layout = (points_c, vectors_c)
         return o_points, self.find_deltas(boundary, o_depth), boundary, o_vectors, index_ray, o_depth, o_tri, o_origins

@@ -45,9 +45,21 @@ class FrameRenderer:
         """[xyzs, dirs, index_ray, ts, index_tri, origins] on the device (None if no hit)."""
         return self.mesh_intersect.sampling_raytrace_device(viewdirs, origins, image_width=image_width, camera=camera)
 
+    def _background(self, n_rays, dev):
+        fill = 0.0 if self.bg_color == "black" else 1.0
+        return (torch.full((n_rays, 3), fill, device=dev), torch.zeros((n_rays, 1), device=dev),
+                torch.zeros((n_rays, 1), device=dev), 0)
+
+    def _again(self, origins, viewdirs, image_width, scaling, render_bkgd, camera, _retry):
+        """The optimistic re-origin check of a ray-major pack failed: sample again (the intersector now decides the rule
+        up front, so the retry is exact).  ONE retry: a flag that is still raised afterwards is a bug, not a frame."""
+        if _retry:
+            raise RuntimeError("re-origin rule: the exact retry was refuted as well (RayIntersector._rule_upfront not armed?)")
+        return self.render(origins, viewdirs, image_width, scaling, render_bkgd, camera, _retry=True)
+
     @torch.no_grad()
     def render(self, origins: torch.Tensor, viewdirs: torch.Tensor, image_width: int = 0, scaling: float = 0.0,
-               render_bkgd: Optional[torch.Tensor] = None, camera=None):
+               render_bkgd: Optional[torch.Tensor] = None, camera=None, _retry: bool = False):
         """(rgb [R,3], alpha [R,1], depth [R,1], n_samples) for R rays."""
         n_rays = origins.shape[0]
         if camera is not None:
@@ -58,7 +70,9 @@ class FrameRenderer:
             # (streams) -> displacement + per-ray re-sort inside the tiles -> field -> tile compositor.  Same pixels
             # as render_image_finetune_with_occgrid on the ray-major samples, bit for bit (tested).
             data = ri.sample_device(origins, viewdirs, self.mesh_intersect.num_intersections, image_width, camera, lean=True)
-            if data is not None and ri.last_frame is not None:
+            if data is None:                      # nothing hit: the background, without intersecting a second time
+                return self._background(n_rays, origins.device)
+            if ri.last_frame is not None:
                 frame = ri.last_frame
                 _, xyz_c, dirs_c = ri.last_layout
                 f = self.field_net(xyz_c, return_grad=False)[0]
@@ -77,10 +91,7 @@ class FrameRenderer:
                                 defer_rule_check=lean)
         if data is None:
             ri.rule_violated()
-            dev = origins.device
-            fill = 0.0 if self.bg_color == "black" else 1.0
-            return (torch.full((n_rays, 3), fill, device=dev), torch.zeros((n_rays, 1), device=dev),
-                    torch.zeros((n_rays, 1), device=dev), 0)
+            return self._background(n_rays, origins.device)
         if (self.field_net is None or scaling == 0) and ri.last_layout is not None:
             # No deformation: the samples are already sorted by (ray, depth), the re-sort of sampling_indexing is the
             # identity, and the field can stream the copies laid out in its processing order (same bits).
@@ -90,10 +101,10 @@ class FrameRenderer:
             rgb, alpha, depth, _ = utils.composite_frame(rgbs, sigmas, ri.last_frame, self.render_step_size,
                                                          render_bkgd=render_bkgd, bg_color=self.bg_color)
             if ri.rule_violated():      # rare (near-coincident faces): these samples are not the reference's; again, exactly
-                return self.render(origins, viewdirs, image_width, scaling, render_bkgd, camera)
+                return self._again(origins, viewdirs, image_width, scaling, render_bkgd, camera, _retry)
             return rgb, alpha, depth, ri.frame_samples()
         if ri.rule_violated():
-            return self.render(origins, viewdirs, image_width, scaling, render_bkgd, camera)
+            return self._again(origins, viewdirs, image_width, scaling, render_bkgd, camera, _retry)
         rays = Rays(origins=origins, viewdirs=viewdirs)
         rgb, alpha, depth, n_samples, *_ = utils.render_image_finetune_with_occgrid(
             self.radiance_field, self.field_net, None, rays, data, render_step_size=self.render_step_size,

@@ -42,9 +42,25 @@ def inverse_of_compressed_sigma(alpha):
 
 
 def generate_splits(data, num_rays, chunk_size=160000):
-    """Windows of ``chunk_size`` rays over the packed samples (train_finetune.py:419-439)."""
+    """Windows of ``chunk_size`` rays over the packed samples (train_finetune.py:419-439).
+
+    The reference masks every array once per window (on the CPU tensors of its DataLoader worker).  Device arrays
+    whose ray ids ascend -- what every loader of the path produces (mesh_utils.py:373-381: lexsort by (depth, ray)) --
+    are cut with ONE searchsorted and one host read instead: a window's samples are a contiguous slice, the splits are
+    views (same values as the masked copies).  Anything else takes the masks."""
     xyzs, dirs, index_ray, ts, index_tri, origins = data
     chunks = []
+    n = int(index_ray.shape[0])
+    if n > 0 and index_ray.is_cuda and index_ray.dim() == 1 and index_ray.dtype == torch.int64:
+        edges = torch.arange(0, int(num_rays) + int(chunk_size), int(chunk_size), dtype=torch.int64, device=index_ray.device)
+        cuts = torch.searchsorted(index_ray, edges)
+        ascending = (index_ray[1:] >= index_ray[:-1]).all().reshape(1).to(torch.int64)
+        host = torch.cat([cuts, ascending]).tolist()
+        if host[-1]:
+            for a, b in zip(host[:-2], host[1:-1]):
+                if b > a:
+                    chunks.append(tuple(t[a:b] for t in (xyzs, dirs, index_ray, ts, index_tri, origins)))
+            return chunks
     for i in range(0, num_rays, chunk_size):
         mask = (index_ray < i + chunk_size) & (index_ray >= i)
         if mask.sum() == 0:
@@ -235,6 +251,18 @@ def render_image_finetune_with_occgrid(
     xyzs, dirs, index_ray, ts, index_tri, origins = _to_device(data, device)
     dh = None
     loss = torch.zeros(1, device=device)
+    inference = not (torch.is_grad_enabled() and (xyzs.requires_grad or ts.requires_grad or _module_trains(radiance_field)
+                                                  or _module_trains(field_net)))
+    auto_inverse = None
+    if order is None and inference and xyzs.shape[0] > 0:
+        # the reference's eval loop hands over a window of a frame and no processing order: derive the coherent order
+        # from the window's own ray ids (qf_split_layout) when the intersector knows the frame's width, and let the
+        # re-sort launch write the streamed copies -- locality only, same pixels
+        shape = getattr(getattr(mesh_intersect, "rayintersector", None), "last_image_shape", None)
+        if shape is not None and shape[0] * shape[1] == num_rays:
+            deforms = field_net is not None and scaling != 0 and isinstance(field_net, _Field)
+            order, auto_inverse, _ = mesh_intersect.rayintersector.split_layout(index_ray, shape[0], shape[1],
+                                                                               want_order=deforms)
     if _module_trains(field_net):
         tri_v = mesh_intersect.vertices[_faces_on_device(mesh_intersect)[index_tri]][:, :, 0:3]        # [S,3,3]
         w = torch.rand((xyzs.shape[0], 3), device=device)[..., None]
@@ -252,20 +280,29 @@ def render_image_finetune_with_occgrid(
         ts = ts + del_delta.view(-1)
         loss = ((del_vector ** 2).mean() + ((del_vector_v - del_vector.detach()) ** 2).mean()).reshape(1)
     elif field_net is not None and scaling != 0:
-        xyzs, ts = xyzs.clone(), ts.clone()
+        xyzs, ts = _C.f32c(xyzs), _C.f32c(ts)
         # the samples arrive sorted by (ray, depth), which is the layout ``order`` was built for
         f = (field_net(xyzs, return_grad=False, order=order) if isinstance(field_net, _Field)
              else field_net(xyzs, return_grad=False))[0].detach().reshape(-1).contiguous()
-        before = xyzs.clone() if mesh_finetune is not None else None
-        _C.check(_C.lib().qf_apply_deformation(_C.ptr(f), float(scaling), _C.ptr(_C.f32c(dirs)), _C.ptr(xyzs),
-                                               _C.ptr(ts), xyzs.shape[0], _C.stream()), "qf_apply_deformation")
-        if before is not None:
-            dh = xyzs - before
+        moved, ts_moved = torch.empty_like(xyzs), torch.empty_like(ts)      # out of place: the inputs are the caller's
+        dh = torch.empty_like(xyzs) if mesh_finetune is not None else None  # the reference's dh = del_delta * dirs
+        _C.check(_C.lib().qf_apply_deformation(_C.ptr(f), float(scaling), _C.ptr(_C.f32c(dirs)), _C.ptr(xyzs), _C.ptr(ts),
+                                               xyzs.shape[0], _C.ptr(moved), _C.ptr(ts_moved), _C.ptr(dh), _C.stream()),
+                 "qf_apply_deformation")
+        xyzs, ts = moved, ts_moved
     # scaling == 0 multiplies the displacement by zero in the reference (utils.py:566-571): skipping is exact.
-    points, deltas, boundary, dirs, index_ray, depth, index_tri_s, _ = mesh_intersect.sampling_indexing(
-        xyzs, origins, dirs, index_ray, ts, index_tri)
+    if auto_inverse is not None:
+        points, deltas, boundary, dirs, index_ray, depth, index_tri_s, _ = mesh_intersect.sampling_indexing(
+            xyzs, origins, dirs, index_ray, ts, index_tri, layout_inverse=auto_inverse)
+    else:
+        points, deltas, boundary, dirs, index_ray, depth, index_tri_s, _ = mesh_intersect.sampling_indexing(
+            xyzs, origins, dirs, index_ray, ts, index_tri)
     sample_index = None
-    if order is not None and order.shape[0] == points.shape[0]:
+    if auto_inverse is not None:
+        points_c, dirs_c = mesh_intersect.last_resort_layout
+        rgbs, sigmas = radiance_field(points_c, dirs_c)
+        sample_index = auto_inverse
+    elif order is not None and order.shape[0] == points.shape[0]:
         # coherent processing order: locality only
         if torch.is_grad_enabled() and (points.requires_grad or _module_trains(radiance_field)):
             rgbs, sigmas = radiance_field(points, dirs, order=order)
@@ -281,13 +318,14 @@ def render_image_finetune_with_occgrid(
                 sample_index[o64] = torch.arange(order.shape[0], dtype=order.dtype, device=order.device)
     else:
         rgbs, sigmas = radiance_field(points, dirs)
+    # (boundary=None: the third return value, index_ray[boundary], is discarded here as in the reference -- utils.py:585
+    #  -- and computing it would cost a boolean-mask gather with a host wait per split)
     rgb, opacity, _, depth_img, weights = derive_properties(
-        rgbs, sigmas.reshape(-1), depth, deltas, boundary, index_ray, bg_color=bg_color, render_bkgd=render_bkgd,
+        rgbs, sigmas.reshape(-1), depth, deltas, None, index_ray, bg_color=bg_color, render_bkgd=render_bkgd,
         N=num_rays, sample_index=sample_index)
     if mesh_finetune is not None:
-        if dh is None:
-            dh = torch.zeros_like(xyzs)
-        mesh_finetune.update_d(dh.detach(), weights[:, 0].detach(), index_tri)
+        # dh None: the displacement is identically zero, cache_d += 0 * w is a no-op (update_d skips it)
+        mesh_finetune.update_d(None if dh is None else dh.detach(), weights[:, 0].detach(), index_tri)
     return (rgb.view((*rays_shape[:-1], -1)), opacity.view((*rays_shape[:-1], -1)),
             depth_img.view((*rays_shape[:-1], -1)), xyzs.shape[0], weights, points, index_ray, loss, index_tri)
 

@@ -54,7 +54,7 @@ def test_loader_item_renders_like_the_frame_renderer(device):
     item = ds[1]
     assert item["pixels"].shape == (h * w, 3) and item["rays"].origins.shape == (80 * 80, 3)
     out = utils.render_image_finetune_with_occgrid(field, None, None, item["rays"], item["data"], render_step_size=5e-3,
-                                                   mesh_intersect=mi, scaling=0, order=item["order"])
+                                                   mesh_intersect=mi, scaling=0)
     rgb = out[0]
     # oracle on the same rays
     o, d = item["rays"].origins.cpu(), item["rays"].viewdirs.cpu()

@@ -1,0 +1,233 @@
+"""GPU: the pieces behind the reference-shaped eval loop (bench.py ``reference_route``): the split layout derived from
+a window's ray ids, the re-sort launch that also writes the streamed copies, ``generate_splits`` on device arrays,
+``MeshFinetune.update_d`` as one launch, the hand-written ``qf_sample_offsets`` -- and that the eval loop of
+train_finetune.py:575-629, restated over the reference-named entry points, gives the FrameRenderer's pixels."""
+import numpy as np
+import pytest
+import torch
+
+from tests import helpers
+
+pytestmark = pytest.mark.gpu
+
+
+def _scene(device, log2_T=14, shells=4, subdiv=3):
+    from quadraturefields_amd import synthetic
+    from quadraturefields_amd.mesh_utils import MeshIntersection
+    from quadraturefields_amd.radiance_fields.ngp import NGPRadianceField
+    mesh = synthetic.shell_mesh(n_shells=shells, subdivisions=subdiv)
+    mi = MeshIntersection(mesh, simplify_mesh=False, scale=1.0, num_intersections=25)
+    field = NGPRadianceField(aabb=[-1.5] * 3 + [1.5] * 3, log2_hashmap_size=log2_T)
+    field.load_state_dict(synthetic.seeded_ngp_state(log2_T, field.mlp_base.grid.n_rows), strict=False)
+    return mesh, mi, field.to(device)
+
+
+def _frame(mi, w, h, device, seed=0):
+    from quadraturefields_amd import synthetic
+    from quadraturefields_amd.mesh_utils import make_camera
+    c2w = synthetic.orbit_cameras(1, seed=seed)[0]
+    focal = synthetic.lego_focal(800) * w / 800.0
+    o, d = synthetic.camera_rays(c2w, focal, w, h, device=device)
+    return o, d, make_camera(c2w, focal, w, h)
+
+
+def test_split_layout_equals_the_frame_layout_on_tile_aligned_windows(device):
+    """A window of whole tile rows is a contiguous slice of the frame's coherent order: the layout derived from the
+    window's ids alone must be that slice, re-based; the whole frame must reproduce the frame's own inverse map."""
+    _, mi, _ = _scene(device)
+    w, h = 96, 80
+    o, d, cam = _frame(mi, w, h, device)
+    data = mi.sampling_raytrace_device(d, o, camera=cam)
+    ri = mi.rayintersector
+    inv_frame = ri.last_layout[0].clone()
+    order_frame = ri.last_order.clone()
+    index_ray = data[2]
+    order, inverse, invalid = ri.split_layout(index_ray, w, h)
+    assert int(invalid) == 0
+    assert torch.equal(inverse, inv_frame) and torch.equal(order, order_frame)
+    for y0, y1 in ((0, 24), (24, 64), (64, 80)):             # multiples of 8 rows
+        lo, hi = y0 * w, y1 * w
+        a = int(torch.searchsorted(index_ray, torch.tensor(lo, device=device)))
+        b = int(torch.searchsorted(index_ray, torch.tensor(hi, device=device)))
+        assert b > a
+        o_s, inv_s, bad = ri.split_layout(index_ray[a:b], w, h)
+        assert int(bad) == 0
+        assert torch.equal(inv_s, inv_frame[a:b] - a)
+        assert torch.equal(o_s, order_frame[a:b] - a)
+        # a permutation of [0, n)
+        assert torch.equal(torch.sort(inv_s.long()).values, torch.arange(b - a, device=device))
+    # a window that is NOT tile aligned still yields a valid permutation (its own tiles)
+    lo, hi = 5 * w + 7, 37 * w + 3
+    a = int(torch.searchsorted(index_ray, torch.tensor(lo, device=device)))
+    b = int(torch.searchsorted(index_ray, torch.tensor(hi, device=device)))
+    o_s, inv_s, bad = ri.split_layout(index_ray[a:b], w, h)
+    assert int(bad) == 0 and torch.equal(torch.sort(inv_s.long()).values, torch.arange(b - a, device=device))
+    assert torch.equal(o_s.long()[inv_s.long()], torch.arange(b - a, device=device))
+
+
+def test_split_layout_refuses_unsorted_or_out_of_range_ids(device):
+    _, mi, _ = _scene(device)
+    ri = mi.rayintersector
+    w = h = 32
+    ids = torch.tensor([5, 5, 9, 7, 7, 100], dtype=torch.int64, device=device)          # 9 > 7: not ascending
+    order, inverse, bad = ri.split_layout(ids, w, h)
+    assert int(bad) == 1
+    assert inverse.tolist() == list(range(6)) and order.tolist() == list(range(6))
+    ids = torch.tensor([1, 2, 3, w * h], dtype=torch.int64, device=device)               # outside the frame
+    _, inverse, bad = ri.split_layout(ids, w, h)
+    assert int(bad) == 1 and inverse.tolist() == [0, 1, 2, 3]
+    ids = torch.tensor([-1, 2, 3], dtype=torch.int64, device=device)
+    assert int(ri.split_layout(ids, w, h)[2]) == 1
+    # long runs (more samples per ray than any tile step assumes) and empty input
+    ids = torch.repeat_interleave(torch.tensor([3, 40, 41, 1000], device=device), torch.tensor([70, 1, 300, 2], device=device))
+    order, inverse, bad = ri.split_layout(ids, w, h)
+    assert int(bad) == 0 and torch.equal(torch.sort(inverse.long()).values, torch.arange(ids.shape[0], device=device))
+    _, inverse, bad = ri.split_layout(ids[:0], w, h)
+    assert inverse.numel() == 0 and int(bad) == 0
+
+
+def test_resort_writes_the_streamed_copies(device):
+    """qf_resort_samples(inverse=...): the coherent copies are the re-sorted arrays permuted by the inverse map, incl.
+    rays whose depths really change order and a ray longer than the kernel's staging window."""
+    _, mi, _ = _scene(device)
+    g = torch.Generator().manual_seed(3)
+    counts = torch.randint(0, 12, (400,), generator=g)
+    counts[17] = 1500                                      # longer than the 1088-sample staging window
+    index_ray = torch.repeat_interleave(torch.arange(400), counts).to(device)
+    n = index_ray.shape[0]
+    depth = torch.rand(n, generator=g).to(device)          # unsorted within the rays
+    pts, org, vec = (torch.randn(n, 3, generator=g).to(device) for _ in range(3))
+    tri = torch.randint(0, 1000, (n,), generator=g).to(device)
+    ref = mi.sampling_indexing(pts, org, vec, index_ray, depth, tri)
+    _, inverse, bad = mi.rayintersector.split_layout(index_ray, 20, 20, want_order=False)
+    assert int(bad) == 0
+    out = mi.sampling_indexing(pts, org, vec, index_ray, depth, tri, layout_inverse=inverse)
+    for a, b in zip(ref, out):
+        assert torch.equal(a, b)
+    p_c, v_c = mi.last_resort_layout
+    assert torch.equal(p_c[inverse.long()], out[0]) and torch.equal(v_c[inverse.long()], out[3])
+    # sorted within each ray
+    same = out[4][1:] == out[4][:-1]
+    assert bool((out[5][1:][same] >= out[5][:-1][same]).all())
+
+
+def test_generate_splits_views_equal_the_masked_copies(device):
+    from quadraturefields_amd import utils
+    _, mi, _ = _scene(device)
+    w, h = 64, 48
+    o, d, cam = _frame(mi, w, h, device, seed=1)
+    data = mi.sampling_raytrace_device(d, o, camera=cam)
+
+    def masked(data, num_rays, chunk):                     # the reference's body (train_finetune.py:419-439), restated
+        chunks = []
+        for i in range(0, num_rays, chunk):
+            m = (data[2] < i + chunk) & (data[2] >= i)
+            if m.sum() == 0:
+                continue
+            chunks.append(tuple(t[m].contiguous() for t in data))
+        return chunks
+
+    for chunk in (160000, 1000, 517, 64):
+        fast = utils.generate_splits(data, w * h, chunk)
+        slow = masked(data, w * h, chunk)
+        assert len(fast) == len(slow) > 0
+        for a, b in zip(fast, slow):
+            assert all(torch.equal(x, y) for x, y in zip(a, b))
+    # ids that do not ascend take the masks (same result as the reference's body)
+    perm = torch.randperm(data[2].shape[0], device=device)
+    shuffled = [t[perm] for t in data]
+    fast, slow = utils.generate_splits(shuffled, w * h, 1000), masked(shuffled, w * h, 1000)
+    assert len(fast) == len(slow) and all(torch.equal(x, y) for a, b in zip(fast, slow) for x, y in zip(a, b))
+    # host tensors (the reference's DataLoader hands those over) take the masks too
+    host = [t.cpu() for t in data]
+    assert len(utils.generate_splits(host, w * h, 1000)) == len(slow)
+
+
+def test_mesh_update_d_matches_index_add(device):
+    from quadraturefields_amd.mesh_utils import MeshFinetune
+    g = torch.Generator().manual_seed(0)
+    n_v, n_f, n = 300, 500, 20000
+    verts = torch.randn(n_v, 3, generator=g).numpy()
+    faces = torch.randint(0, n_v, (n_f, 3), generator=g).numpy()
+    mf = MeshFinetune(verts, faces, 0.04, device=device)
+    d = torch.randn(n, 3, generator=g).to(device) * 0.01
+    wgt = torch.rand(n, generator=g).to(device)
+    tri = torch.randint(0, n_f, (n,), generator=g).to(device)
+    cd = torch.zeros(n_f, 3, device=device).index_add_(0, tri, d * wgt[:, None])
+    cw = (torch.ones(n_f, device=device) * 1e-8).index_add_(0, tri, wgt)
+    mf.update_d(d, wgt, tri)
+    assert torch.allclose(mf.cache_d, cd, atol=1e-5) and torch.allclose(mf.cache_w, cw, rtol=1e-5)
+    before = mf.cache_d.clone()
+    mf.update_d(None, wgt, tri)                            # zero displacement: cache_d untouched, cache_w moves
+    assert torch.equal(mf.cache_d, before) and torch.allclose(mf.cache_w, cw + (cw - 1e-8), rtol=1e-5)
+    mf.reset_d()
+    assert float(mf.cache_d.abs().max()) == 0.0
+
+
+def test_sample_offsets_hand_written_scan(device):
+    """qf_sample_offsets (no library scan behind it any more): exclusive sums of min(count, K) + the grand total."""
+    from quadraturefields_amd import _C
+    g = torch.Generator().manual_seed(1)
+    for n in (1, 7, 1024, 1025, 70001):
+        cnt = torch.randint(-2, 40, (n,), generator=g, dtype=torch.int32).to(device)
+        k = 25
+        out = torch.empty((n + 1,), dtype=torch.int64, device=device)
+        nb = int(_C.lib().qf_sample_offsets_temp_bytes(n))
+        temp = torch.empty((nb,), dtype=torch.uint8, device=device)
+        _C.check(_C.lib().qf_sample_offsets(_C.ptr(cnt), n, k, _C.ptr(out), _C.ptr(temp), nb, _C.stream()), "qf_sample_offsets")
+        c = cnt.clamp(0, k).long()
+        ref = torch.cat([torch.zeros(1, dtype=torch.int64, device=device), torch.cumsum(c, 0)])
+        assert torch.equal(out, ref)
+
+
+@pytest.mark.parametrize("scaling", [0.0, 0.05])
+def test_reference_eval_loop_equals_the_frame_renderer(device, scaling):
+    """train_finetune.py:575-629 restated over the package's names (SubjectLoader item -> generate_splits ->
+    render_image_finetune_with_occgrid per split -> rgb[split[2]] = color[split[2]]) gives the same pixels as the
+    tile-order FrameRenderer, and the automatic split layout changes nothing: identical to the same call with the
+    layout switched off (ray-major field evaluation)."""
+    from quadraturefields_amd import synthetic, utils
+    from quadraturefields_amd.datasets.nerf_synthetic import SubjectLoader
+    from quadraturefields_amd.field import Field
+    from quadraturefields_amd.mesh_utils import MeshFinetune
+    from quadraturefields_amd.render import FrameRenderer
+    mesh, mi, field = _scene(device)
+    w = h = 96
+    cams = np.stack([np.asarray(c, dtype=np.float32) for c in synthetic.orbit_cameras(2, seed=5)])
+    ds = SubjectLoader.from_arrays(np.zeros((2, h, w, 4), np.uint8), cams, synthetic.lego_focal(800) * w / 800.0,
+                                   split="test", mesh_intersect=mi, device=device)
+    torch.manual_seed(0)
+    field_net = Field(scale=1.5, precision=16, log2_T=14, L=16, max_res=512, min_res=16, output_dim=1, hidden_size=32,
+                      num_features=2, back_prop=False, nl="relu").to(device)
+    with torch.no_grad():
+        field_net.xyz_encoder.params.uniform_(-0.5, 0.5)
+    mf = MeshFinetune(mi.mesh.vertices, mi.mesh.faces, 0.05, device=device)
+
+    def loop(item, auto):
+        rays = item["rays"]
+        n = rays.origins.shape[0]
+        rgb = torch.ones((n, 3), device=device)
+        depth = torch.zeros((n,), device=device)
+        shape = mi.rayintersector.last_image_shape
+        if not auto:
+            mi.rayintersector.last_image_shape = None
+        for split in utils.generate_splits(item["data"], n, chunk_size=24 * w):
+            color, _, dd, _, _, _, _, _, _ = utils.render_image_finetune_with_occgrid(
+                field, field_net, None, rays, split, render_step_size=5e-3, render_bkgd=item["color_bkgd"],
+                mesh_intersect=mi, mesh_finetune=mf, scaling=scaling)
+            rgb[split[2]] = color[split[2]]
+            depth[split[2]] = dd.squeeze()[split[2]]
+        mi.rayintersector.last_image_shape = shape
+        return rgb, depth
+
+    for i in range(2):
+        item = ds[i]
+        assert mi.rayintersector.last_image_shape == (w, h)
+        rgb_a, dep_a = loop(item, True)
+        rgb_b, dep_b = loop(item, False)
+        assert torch.equal(rgb_a, rgb_b) and torch.equal(dep_a, dep_b)
+        rays = item["rays"]
+        fr = FrameRenderer(mi, field, field_net=field_net if scaling else None, render_step_size=5e-3)
+        rgb_f, _, dep_f, _ = fr.render(rays.origins, rays.viewdirs, scaling=scaling, camera=item["camera"])
+        assert torch.equal(rgb_a, rgb_f)
+        assert torch.equal(dep_a, dep_f.reshape(-1))
