@@ -1,7 +1,7 @@
 """Golden fixtures produced by the reference's own function bodies (tests/golden/gen_from_reference.py).
 
-CPU part (-m "not gpu"): the oracle reproduces the reference's outputs -- this is what pins the oracle.
-GPU part (-m gpu): the HIP path reproduces the same reference outputs directly.
+CPU (-m "not gpu"): the oracle reproduces the reference's outputs -- this is what pins the oracle.
+The HIP path is run on the SAME fixtures, directly (no oracle in between), in tests/test_gpu_golden.py.
 Tolerances: integer / uint8 / bool outputs bit exact; fp32 outputs 1e-6 + 1e-5*|x| (libm and summation order).
 """
 import os
@@ -171,78 +171,3 @@ def test_product_host_quantisers_vs_reference():
     assert torch.equal(ngp.continuous_color(u), z["continuous_color"]) and torch.equal(ngp.continuous_axis(u), z["continuous_axis"])
     assert torch.equal(ngp.discretize_color(z["x"]), z["discretize_color"])
     assert torch.equal(ngp.discretize_axis(torch.tanh(z["x"])), z["discretize_axis"])
-
-
-# =============================================================================== GPU: HIP path vs reference
-@pytest.mark.gpu
-def test_hip_volrend_vs_reference(device):
-    from quadraturefields_amd import field_rendering as fr
-    z = {k: (v.to(device) if isinstance(v, torch.Tensor) else v) for k, v in load("volrend_ref.npz").items()}
-    fn = lambda a, b, r: (z["rgbs"], z["sigmas"])
-    c, o, d, ex = fr.rendering(z["t_starts"], z["t_ends"], z["ray_indices"], z["n_rays"], rgb_sigma_fn=fn, render_bkgd=z["bkgd"])
-    close(c, z["colors"]); close(o, z["opacities"]); close(d, z["depths"], 1e-5, 1e-4)
-    for k in ("weights", "trans", "alphas"):
-        close(ex[k], z[k])
-    c, o, d, ex = fr.rendering(z["t_starts"], z["t_ends"], z["ray_indices"], z["n_rays"],
-                               rgb_alpha_fn=lambda a, b, r: (z["rgbs"], z["alphas_in"]))
-    close(c, z["colors_alpha"], 1e-6, 3e-5); close(ex["weights"], z["weights_alpha"], 1e-6, 3e-5)
-    f = fr.rendering_field(z["t_starts"], z["t_ends"], z["ray_indices"], z["n_rays"], rgb_sigma_fn=fn)
-    for got, key in zip(f, ("field_colors", "field_opacities", "field_depths", "field_weights", "field_weights_rev")):
-        close(got, z[key], 1e-5, 1e-4)
-    vis = fr.render_visibility_from_density(z["t_starts"], z["t_ends"], z["sigmas"], ray_indices=z["ray_indices"],
-                                            n_rays=z["n_rays"], early_stop_eps=0.05, alpha_thre=0.02)
-    assert torch.equal(vis, z["visibility"])
-    close(fr.accumulate_along_rays(z["weights"], z["rgbs"], z["ray_indices"], z["n_rays"]), z["accumulated"])
-
-
-@pytest.mark.gpu
-def test_hip_derive_properties_vs_reference(device):
-    from quadraturefields_amd import spc_render, utils
-    z = {k: (v.to(device) if isinstance(v, torch.Tensor) else v) for k, v in load("derive_properties_ref.npz").items()}
-    b = spc_render.mark_pack_boundaries(z["index_ray"])
-    for bg in ("white", "black", "random"):
-        rgb, alpha, hit, dep, w = utils.derive_properties(z["color"], z["density"], z["depth"], z["deltas"], b, z["index_ray"],
-                                                          render_bkgd=z["bkgd"], bg_color=bg, N=z["n_rays"])
-        assert torch.equal(hit, z[f"hit_{bg}"])
-        close(rgb, z[f"rgb_{bg}"], 2e-6, 2e-5); close(alpha, z[f"alpha_{bg}"], 2e-6, 2e-5)
-        close(dep, z[f"depth_{bg}"], 2e-6, 2e-5); close(w, z[f"weights_{bg}"], 2e-6, 2e-5)
-
-
-@pytest.mark.gpu
-def test_hip_sg_and_texture_vs_reference(device):
-    from quadraturefields_amd.radiance_fields.ngp import NGPRadianceFieldSGNew
-    from quadraturefields_amd.texture_utils import FeatureCompression
-    z = load("sg_ref.npz")
-    for lobes in (3, 6):
-        f = NGPRadianceFieldSGNew(aabb=[-1] * 3 + [1] * 3, use_viewdirs=False, num_g_lobes=lobes, log2_hashmap_size=8).to(device)
-        close(f.features_to_rgb(z[f"features_{lobes}"].to(device), z[f"dirs_{lobes}"].to(device)), z[f"rgb_{lobes}"], 2e-6, 2e-5)
-        close(f.spherical_gaussian_mixture(z[f"features_{lobes}"][:, 3:].to(device), z[f"dirs_{lobes}"].to(device)),
-              ofields.spherical_gaussian_mixture(z[f"features_{lobes}"][:, 3:], z[f"dirs_{lobes}"], lobes), 2e-6, 2e-5)
-        # discretize=True: device atan2 / acos / log may land one uint8 code away from the host's on a handful of
-        # elements (a code step moves rgb by up to ~0.05), everything else agrees to rounding
-        fd = NGPRadianceFieldSGNew(aabb=[-1] * 3 + [1] * 3, use_viewdirs=False, num_g_lobes=lobes, log2_hashmap_size=8,
-                                   discretize=True).to(device)
-        got = fd.features_to_rgb(z[f"features_{lobes}"].to(device), z[f"dirs_{lobes}"].to(device)).cpu()
-        err = (got - z[f"rgb_disc_{lobes}"]).abs().max(dim=1).values
-        assert (err > 2e-5).float().mean() < 0.02 and err.max() < 0.1, (float((err > 2e-5).float().mean()), float(err.max()))
-    z = load("texture_ref.npz")
-    for codec, thres in (("sigmoid", 7.5), ("linear", 5.0)):
-        comp = FeatureCompression.from_arrays(z[f"{codec}_alpha"], z[f"{codec}_diffuse"], [z[f"{codec}_colors{i}"] for i in range(3)],
-                                              [z[f"{codec}_lambdas{i}"] for i in range(3)], compression_type=codec, lambda_thres=thres)
-        close(comp.get_features_from_texture_map(z[f"{codec}_indices"].to(device)), z[f"{codec}_features"], 2e-6, 2e-5)
-
-
-@pytest.mark.gpu
-def test_hip_sampling_vs_reference(device):
-    from quadraturefields_amd.mesh_io import TriMesh
-    from quadraturefields_amd.mesh_utils import MeshIntersection
-    z = load("sampling_ref.npz")
-    mi = MeshIntersection(TriMesh(z["vertices"].numpy(), z["faces"].numpy()), simplify_mesh=False, scale=1.0,
-                          num_intersections=25, min_hit_separation=0.0)      # the fixture's stand-in intersector returns every hit
-    data = mi.sampling_raytrace_device(z["viewdirs"], z["origins"])
-    for got, key in zip(data, ("xyzs", "dirs", "index_ray", "ts", "index_tri", "origins_s")):
-        assert torch.equal(got.cpu(), z[key]), key
-    dev = lambda t: t.to(device)
-    out = mi.sampling_indexing(data[0], data[5], data[1], data[2], dev(z["ts_perturbed"]), data[4])
-    for got, key in zip(out, ("s_points", "s_deltas", "s_boundary", "s_dirs", "s_index_ray", "s_depth", "s_index_tri", "s_origins")):
-        assert torch.equal(got.cpu(), z[key]), key

@@ -171,6 +171,36 @@ def test_deform_field_matches_oracle(device):
     _close(f(big.to(device), return_grad=False)[0], want_big, 2e-5, 2e-5)
 
 
+def test_deform_field_at_the_reference_table_size(device):
+    """The deformation field as the reference builds it (train_finetune.py:387-399: ``Field(log2_T=24)``, 101.6 M rows,
+    0.8 GB fp32 -- four times the Infinity Cache, levels 0-10 dense and 11-15 hashed): ``deform_kernel`` against the
+    oracle on a few thousand points (the oracle only gathers from the host copy of the table), ray-major and through a
+    processing permutation."""
+    from quadraturefields_amd import synthetic
+    from quadraturefields_amd.field import Field
+    f = Field(scale=1.5, precision=16, log2_T=24, L=16, max_res=512, min_res=16, output_dim=1, hidden_size=32,
+              num_features=2, back_prop=False, nl="relu")
+    g = f.xyz_encoder.grid
+    lv = ofields.grid_levels(g.n_levels, g.log2_hashmap_size, g.base_resolution, g.per_level_scale)
+    assert g.n_rows == lv.n_entries and 101_000_000 < g.n_rows < 102_000_000
+    assert lv.hashed == [False] * 11 + [True] * 5                     # SURVEY.md A.1: dense levels 0-10 at T = 2^24
+    f.load_state_dict(synthetic.seeded_deform_state(g.n_params), strict=False)
+    wts = helpers.oracle_deform_weights(f)
+    f = f.to(device)
+    x, _ = helpers.random_points(4001, seed=24, outside_frac=0.0)
+    want = ofields.deform_field(x, wts)
+    got = f(x.to(device), return_grad=False)[0]
+    _close(got, want, 2e-5, 2e-5)
+    order = torch.randperm(4001, generator=torch.Generator().manual_seed(2)).to(torch.int32).to(device)
+    assert torch.equal(f(x.to(device), return_grad=False, order=order)[0], got)
+    # points on a surface patch a pixel apart (what a coherent wave pass holds): neighbours share cells on every level
+    base = torch.tensor([0.31, -0.42, 0.77])
+    patch = base + 1e-3 * torch.randn(2048, 3, generator=torch.Generator().manual_seed(3))
+    _close(f(patch.to(device), return_grad=False)[0], ofields.deform_field(patch, wts), 2e-5, 2e-5)
+    del f, wts
+    torch.cuda.empty_cache()
+
+
 def test_linearity_of_grid_in_table(device):
     """Size-independent property at the full T=2^19 table: the encoding is linear in the table."""
     from quadraturefields_amd import tinycudann as tcnn
