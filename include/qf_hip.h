@@ -472,12 +472,13 @@ int qf_pack_samples(const float *rays_o, const float *rays_d, int64_t n_rays, in
  * host int64[3]): host_out[2] = the count after the call's kernels, for a caller that wants it without a copy; *dropped
  * must then be 0 on entry and is 0 again afterwards (a frame loop that keeps one counter pays no memset launch).
  * final_count may be given without the rule.
- * tri_c (or NULL): the samples' triangle ids in the same order (the baked-texture render looks its texels up by
- * triangle, utils.py:1055-1063); without it hit_tri is not read at all (may be NULL).
+ * tri_c (or NULL): the samples' triangle ids in the same order, int32 (the baked-texture render looks its texels up
+ * by triangle, utils.py:1055-1063 -- qf_texture_shade_points takes them as they are); without it hit_tri is not read at
+ * all (may be NULL).
  * Values equal qf_pack_samples' xyz_c / dirs_c / depth_c bit for bit (position for position when nothing is dropped). */
 int qf_pack_tiles(const float *rays_o, const float *rays_d, int32_t width, int32_t height, int32_t max_hits,
                   const int32_t *hit_tri, const float *hit_t, const int32_t *hit_count, const int64_t *tile_base,
-                  const int64_t *total, float *xyz_c, float *dirs_c, float *depth_c, int64_t *tri_c /* or NULL */,
+                  const int64_t *total, float *xyz_c, float *dirs_c, float *depth_c, int32_t *tri_c /* or NULL */,
                   const uint64_t *keep_mask, const int32_t *raw_count, float min_separation, int32_t *final_count,
                   int32_t *dropped, int64_t *host_out, void *stream);
 
@@ -604,12 +605,14 @@ int qf_texture_shade_packed(const uint8_t *records, int32_t texture_size, int32_
                             int32_t sigmoid_codec, float lambda_thres, const int64_t *texel,
                             const float *dirs, int64_t n, float *rgb, float *sigma, void *stream);
 /* qf_texel_indices_packed + qf_texture_shade_packed in one launch: the texel of sample i is looked up from points[i] and
- * index_tri[i] through the triangle records inside the shading kernel -- no texel array is written and read back.
- * The baked-texture frame path's shading (utils.py:1055-1076).  Same values as the two calls.               */
+ * its triangle id through the triangle records inside the shading kernel -- no texel array is written and read back.
+ * The baked-texture frame path's shading (utils.py:1055-1076).  Same values as the two calls.
+ * The triangle ids come as EXACTLY ONE of index_tri (int64, the reference's dtype) or index_tri32 (int32, what
+ * qf_pack_tiles writes: half the bytes per sample); the other is NULL.                                        */
 int qf_texture_shade_points(const uint8_t *records, int32_t texture_size, int32_t n_lobes, int32_t sigmoid_codec,
                             float lambda_thres, const void *triangle_records, const float *points,
-                            const int64_t *index_tri, const float *dirs, int64_t n, float *rgb, float *sigma,
-                            void *stream);
+                            const int64_t *index_tri, const int32_t *index_tri32, const float *dirs, int64_t n,
+                            float *rgb, float *sigma, void *stream);
 
 #ifdef __cplusplus
 }

@@ -10,7 +10,10 @@ from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int
 import torch
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libqf_hip.so")
+# QF_HIP_LIBRARY: load another build of the C ABI instead of the in-tree one (experiment builds of tools/, which live
+# outside the package directory).  A library whose qf_abi_version() differs is refused unless
+# QF_HIP_LIBRARY_EXPERIMENT=1 accepts the experiment offset (+1000) on top of the right version.
+LIB_PATH = os.environ.get("QF_HIP_LIBRARY") or os.path.join(_PKG, "libqf_hip.so")
 
 QF_MAX_LEVELS = 16
 QF_MAX_LOBES = 8
@@ -129,7 +132,7 @@ _SIGNATURES = {
     "qf_texture_shade": (c_int, [POINTER(TextureSet), _P, _P, c_int64, _P, _P, _P]),
     "qf_texture_pack": (c_int, [POINTER(TextureSet), _P, _P]),
     "qf_texture_shade_packed": (c_int, [_P, c_int32, c_int32, c_int32, c_float, _P, _P, c_int64, _P, _P, _P]),
-    "qf_texture_shade_points": (c_int, [_P, c_int32, c_int32, c_int32, c_float, _P, _P, _P, _P, c_int64, _P, _P, _P]),
+    "qf_texture_shade_points": (c_int, [_P, c_int32, c_int32, c_int32, c_float, _P, _P, _P, _P, _P, c_int64, _P, _P, _P]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 ABI_VERSION = 3              # QF_ABI_VERSION of include/qf_hip.h
@@ -150,8 +153,11 @@ def lib() -> ctypes.CDLL:
             fn = getattr(handle, name)   # AttributeError if the symbol is not exported
             fn.restype = restype
             fn.argtypes = argtypes
-        if handle.qf_abi_version() != ABI_VERSION:
-            raise RuntimeError("libqf_hip.so ABI version mismatch")
+        version = handle.qf_abi_version()
+        experiment = os.environ.get("QF_HIP_LIBRARY_EXPERIMENT") == "1" and version == ABI_VERSION + 1000
+        if version != ABI_VERSION and not experiment:
+            raise RuntimeError(f"{LIB_PATH}: ABI version {version}, expected {ABI_VERSION} (an experiment build "
+                               "reports +1000 and is only loaded with QF_HIP_LIBRARY_EXPERIMENT=1)")
         _lib = handle
     return _lib
 

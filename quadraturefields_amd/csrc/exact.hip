@@ -903,7 +903,7 @@ __global__ __launch_bounds__(64) void pack_tiles_kernel(
     const float *__restrict__ rays_o, const float *__restrict__ rays_d, int w, int h, int tiles_x, int n_tiles, int max_hits,
     const int32_t *__restrict__ hit_tri, const float *__restrict__ hit_t, const int32_t *__restrict__ hit_count,
     const int64_t *__restrict__ tile_base, const int64_t *__restrict__ total, float *__restrict__ xyz_c,
-    float *__restrict__ dirs_c, float *__restrict__ depth_c, int64_t *__restrict__ tri_c, const uint64_t *__restrict__ keep_mask,
+    float *__restrict__ dirs_c, float *__restrict__ depth_c, int32_t *__restrict__ tri_c, const uint64_t *__restrict__ keep_mask,
     const int32_t *__restrict__ raw_count, float min_sep, int32_t *__restrict__ final_count, int32_t *__restrict__ dropped)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1037,7 +1037,7 @@ __global__ __launch_bounds__(64) void pack_tiles_kernel(
             dirs_c[c * 3 + 1] = dn[1];
             dirs_c[c * 3 + 2] = dn[2];
             depth_c[c] = (float)dep;
-            if (kTri) tri_c[c] = (int64_t)row_i[k];
+            if (kTri) tri_c[c] = (int32_t)row_i[k];
             if (k == 0) { first_xyz[0] = (float)p[0]; first_xyz[1] = (float)p[1]; first_xyz[2] = (float)p[2]; }
         }
         base += __popcll(mask);
@@ -1055,7 +1055,7 @@ __global__ __launch_bounds__(64) void pack_tiles_kernel(
             xyz_c[c * 3 + 0] = gx; xyz_c[c * 3 + 1] = gy; xyz_c[c * 3 + 2] = gz;
             dirs_c[c * 3 + 0] = hx; dirs_c[c * 3 + 1] = hy; dirs_c[c * 3 + 2] = hz;
             depth_c[c] = 0.0f;
-            if (kTri) tri_c[c] = (int64_t)gtri;
+            if (kTri) tri_c[c] = (int32_t)gtri;
         }
         int sum = n_dropped;
 #pragma unroll
@@ -1336,34 +1336,6 @@ __device__ __forceinline__ float decode_color(uint8_t c, int sigmoid_codec)
 // planes (the PNG set of texture_utils.py:67-124), i.e. 2 + 2L scattered sector reads per sample; a record is ONE.
 constexpr int kTexelRecord = QF_TEXEL_RECORD_BYTES;
 
-// Decodes one record into out[0 .. 3+7L] = [diffuse3 | (axis3, lambda, colour3) * L | sigma].
-__device__ __forceinline__ void decode_record(const uint8_t *rec, int n_lobes, int sigmoid_codec, float lambda_thres,
-                                              float *out)
-{
-    const float a = (float)rec[0] / 255.0f;
-    const float sigma = -logf(fmaxf(1.0f - a, 1e-6f)) / 0.005f;                   // texture_utils.py:61-65 (B-9)
-    out[0] = decode_color(rec[1], sigmoid_codec);
-    out[1] = decode_color(rec[2], sigmoid_codec);
-    out[2] = decode_color(rec[3], sigmoid_codec);
-    const float pi = 3.14159274101257324f;   // float32(np.pi)
-    for (int l = 0; l < n_lobes; ++l) {
-        const uint8_t *r = rec + 4 + 6 * l;
-        const uint8_t lc = r[0], az8 = r[1], el8 = r[2];
-        const float az = (float)(uint8_t)(az8 - 128) / 128.0f * pi;               // uint8 wrap (B-8), ngp.py:246
-        const float el = (float)el8 / 256.0f * pi;                                // ngp.py:248
-        const float se = sinf(el);
-        float *o = out + 3 + 7 * l;
-        o[0] = cosf(az) * se;
-        o[1] = sinf(az) * se;
-        o[2] = cosf(el);
-        o[3] = expf((float)lc * lambda_thres / 255.0f - 2.5f);                    // ngp.py:261-262
-        o[4] = decode_color(r[3], sigmoid_codec);
-        o[5] = decode_color(r[4], sigmoid_codec);
-        o[6] = decode_color(r[5], sigmoid_codec);
-    }
-    out[3 + 7 * n_lobes] = sigma;
-}
-
 // Gathers a texel's bytes from the reference's planes into record order.
 __device__ __forceinline__ void gather_record(const TexArgs &t, int64_t px, uint8_t *rec)
 {
@@ -1380,31 +1352,6 @@ __device__ __forceinline__ void gather_record(const TexArgs &t, int64_t px, uint
         r[4] = t.colors[l][px * 3 + 1];
         r[5] = t.colors[l][px * 3 + 2];
     }
-}
-
-__device__ __forceinline__ void decode_texel(const TexArgs &t, int64_t row, int64_t col, float *out)
-{
-    uint8_t rec[kTexelRecord];
-    gather_record(t, row * t.size + col, rec);
-    decode_record(rec, t.n_lobes, t.sigmoid_codec, t.lambda_thres, out);
-}
-
-// SG shading of one decoded texel (ngp.py:371-393,456-461).
-__device__ __forceinline__ void shade_decoded(const float *f, int n_lobes, float dx, float dy, float dz, float *rgb3)
-{
-    float r = 0.0f, g = 0.0f, b = 0.0f;
-    for (int l = 0; l < n_lobes; ++l) {
-        const float *x = f + 3 + 7 * l;
-        const float nrm = sqrtf((x[0] * x[0] + x[1] * x[1]) + x[2] * x[2]);
-        const float dotp = ((x[0] / nrm) * dx + (x[1] / nrm) * dy) + (x[2] / nrm) * dz;
-        const float e = expf(fabsf(x[3]) * (dotp - 1.0f));
-        r += x[4] * e;
-        g += x[5] * e;
-        b += x[6] * e;
-    }
-    rgb3[0] = 1.0f / (1.0f + expf(-(f[0] + r)));
-    rgb3[1] = 1.0f / (1.0f + expf(-(f[1] + g)));
-    rgb3[2] = 1.0f / (1.0f + expf(-(f[2] + b)));
 }
 
 __global__ void texture_pack_kernel(TexArgs t, uint8_t *records)
@@ -1426,12 +1373,25 @@ __global__ void texture_pack_kernel(TexArgs t, uint8_t *records)
 // decodes by lookup: the 4L sin/cos, L exp and 3+3L colour decodes per sample become LDS reads.
 // kLookup: the texel is not read but looked up here, from the sample's position and triangle (texel_from_record): the
 // frame path's fusion of qf_texel_indices_packed and this kernel (no int64 [n,2] texel array written and read back).
-template <bool kLookup>
-__global__ __launch_bounds__(256) void texture_shade_packed_kernel(const uint8_t *records, int size, int n_lobes,
+// The record stays in REGISTERS: sixteen 32-bit words addressed with compile-time indices only -- the lobe loop is fully
+// unrolled over QF_MAX_LOBES with a wave-uniform ``l < n_lobes`` guard, so ``word[(4 + 6 l + j) >> 2]`` is a constant
+// register and the byte comes out with one shift + mask (v_bfe).  Round 2 indexed a byte array with the run-time lobe
+// counter, which put the whole record in scratch: 80 B per lane written and read back per sample.
+__device__ __forceinline__ uint32_t rec_byte(const uint32_t (&w)[kTexelRecord / 4], int idx)   // idx: compile-time
+{
+    return (w[idx >> 2] >> ((idx & 3) * 8)) & 0xffu;
+}
+
+// TriT: int64_t (the reference's index_tri) or int32_t (the tile pack's ids).
+template <bool kLookup, typename TriT>
+__global__ __launch_bounds__(256) void texture_shade_packed_kernel(const uint8_t *__restrict__ records, int size, int n_lobes,
                                                                    int sigmoid_codec, float lambda_thres,
-                                                                   const int64_t *texel, const float *dirs, int64_t n,
-                                                                   float *rgb, float *sigma, const TexelRecord *tri_records,
-                                                                   const float *points, const int64_t *index_tri)
+                                                                   const int64_t *__restrict__ texel,
+                                                                   const float *__restrict__ dirs, int64_t n,
+                                                                   float *__restrict__ rgb, float *__restrict__ sigma,
+                                                                   const TexelRecord *__restrict__ tri_records,
+                                                                   const float *__restrict__ points,
+                                                                   const TriT *__restrict__ index_tri)
 {
     __shared__ float s_sigma[256], s_col[256], s_caz[256], s_saz[256], s_sel[256], s_cel[256], s_lam[256];
     {
@@ -1460,38 +1420,77 @@ __global__ __launch_bounds__(256) void texture_shade_packed_kernel(const uint8_t
         } else {
             px = texel[i * 2] * size + texel[i * 2 + 1];
         }
-        union { uint8_t b[kTexelRecord]; uint4 q[kTexelRecord / 16]; } rec;
         const uint4 *src = reinterpret_cast<const uint4 *>(records + px * kTexelRecord);
+        uint32_t w[kTexelRecord / 4];
 #pragma unroll
-        for (int k = 0; k < kTexelRecord / 16; ++k)
-            if (k < n16) rec.q[k] = src[k];
+        for (int k = 0; k < kTexelRecord / 16; ++k) {
+            uint4 q = make_uint4(0u, 0u, 0u, 0u);
+            if (k < n16) q = src[k];                   // wave-uniform
+            w[4 * k] = q.x; w[4 * k + 1] = q.y; w[4 * k + 2] = q.z; w[4 * k + 3] = q.w;
+        }
         const float dx = dirs[i * 3], dy = dirs[i * 3 + 1], dz = dirs[i * 3 + 2];
         float r = 0.0f, g = 0.0f, b = 0.0f;
-        for (int l = 0; l < n_lobes; ++l) {
-            const uint8_t *q = rec.b + 4 + 6 * l;
-            const float se = s_sel[q[2]];
-            const float x0 = s_caz[q[1]] * se, x1 = s_saz[q[1]] * se, x2 = s_cel[q[2]];
-            const float nrm = sqrtf((x0 * x0 + x1 * x1) + x2 * x2);
-            const float dotp = ((x0 / nrm) * dx + (x1 / nrm) * dy) + (x2 / nrm) * dz;
-            const float e = expf(fabsf(s_lam[q[0]]) * (dotp - 1.0f));
-            r += s_col[q[3]] * e;
-            g += s_col[q[4]] * e;
-            b += s_col[q[5]] * e;
+#pragma unroll
+        for (int l = 0; l < QF_MAX_LOBES; ++l) {
+            if (l < n_lobes) {                         // wave-uniform; every index below is a compile-time constant
+                const int o = 4 + 6 * l;
+                const uint32_t c_lam = rec_byte(w, o), c_az = rec_byte(w, o + 1), c_el = rec_byte(w, o + 2);
+                const float se = s_sel[c_el];
+                const float x0 = s_caz[c_az] * se, x1 = s_saz[c_az] * se, x2 = s_cel[c_el];
+                const float nrm = sqrtf((x0 * x0 + x1 * x1) + x2 * x2);
+                const float dotp = ((x0 / nrm) * dx + (x1 / nrm) * dy) + (x2 / nrm) * dz;
+                const float e = expf(fabsf(s_lam[c_lam]) * (dotp - 1.0f));
+                r += s_col[rec_byte(w, o + 3)] * e;
+                g += s_col[rec_byte(w, o + 4)] * e;
+                b += s_col[rec_byte(w, o + 5)] * e;
+            }
         }
-        rgb[i * 3 + 0] = 1.0f / (1.0f + expf(-(s_col[rec.b[1]] + r)));
-        rgb[i * 3 + 1] = 1.0f / (1.0f + expf(-(s_col[rec.b[2]] + g)));
-        rgb[i * 3 + 2] = 1.0f / (1.0f + expf(-(s_col[rec.b[3]] + b)));
-        sigma[i] = s_sigma[rec.b[0]];
+        rgb[i * 3 + 0] = 1.0f / (1.0f + expf(-(s_col[rec_byte(w, 1)] + r)));
+        rgb[i * 3 + 1] = 1.0f / (1.0f + expf(-(s_col[rec_byte(w, 2)] + g)));
+        rgb[i * 3 + 2] = 1.0f / (1.0f + expf(-(s_col[rec_byte(w, 3)] + b)));
+        sigma[i] = s_sigma[rec_byte(w, 0)];
     }
+}
+
+// The planar kernels (the reference's 2 + 2L separate planes): the same register discipline -- one texel's bytes are
+// read plane by plane inside the unrolled lobe loop, each lobe is decoded and consumed at once (no per-lane feature
+// array; round 2 kept float f[60] + a 64-byte record per lane in scratch: 256 B).
+__device__ __forceinline__ void decode_lobe(const TexArgs &t, int l, int64_t px, float *o /* [7] */)
+{
+    const uint8_t lc = t.lam[l][px * 3 + 0], az8 = t.lam[l][px * 3 + 1], el8 = t.lam[l][px * 3 + 2];
+    const float pi = 3.14159274101257324f;   // float32(np.pi)
+    const float az = (float)(uint8_t)(az8 - 128) / 128.0f * pi;               // uint8 wrap (B-8), ngp.py:246
+    const float el = (float)el8 / 256.0f * pi;                                // ngp.py:248
+    const float se = sinf(el);
+    o[0] = cosf(az) * se;
+    o[1] = sinf(az) * se;
+    o[2] = cosf(el);
+    o[3] = expf((float)lc * t.lambda_thres / 255.0f - 2.5f);                  // ngp.py:261-262
+    o[4] = decode_color(t.colors[l][px * 3 + 0], t.sigmoid_codec);
+    o[5] = decode_color(t.colors[l][px * 3 + 1], t.sigmoid_codec);
+    o[6] = decode_color(t.colors[l][px * 3 + 2], t.sigmoid_codec);
 }
 
 __global__ void texture_fetch_kernel(TexArgs t, const int64_t *texel, int64_t n, float *features)
 {
     const int width = 3 + 7 * t.n_lobes + 1;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        float f[3 + 7 * QF_MAX_LOBES + 1];
-        decode_texel(t, texel[i * 2], texel[i * 2 + 1], f);
-        for (int k = 0; k < width; ++k) features[i * width + k] = f[k];
+        const int64_t px = texel[i * 2] * t.size + texel[i * 2 + 1];
+        float *f = features + i * width;
+        const float a = (float)t.alpha[px] / 255.0f;
+        f[0] = decode_color(t.diffuse[px * 3 + 0], t.sigmoid_codec);
+        f[1] = decode_color(t.diffuse[px * 3 + 1], t.sigmoid_codec);
+        f[2] = decode_color(t.diffuse[px * 3 + 2], t.sigmoid_codec);
+#pragma unroll
+        for (int l = 0; l < QF_MAX_LOBES; ++l) {
+            if (l < t.n_lobes) {
+                float o[7];
+                decode_lobe(t, l, px, o);
+#pragma unroll
+                for (int k = 0; k < 7; ++k) f[3 + 7 * l + k] = o[k];
+            }
+        }
+        f[width - 1] = -logf(fmaxf(1.0f - a, 1e-6f)) / 0.005f;                // texture_utils.py:61-65 (B-9)
     }
 }
 
@@ -1499,10 +1498,27 @@ __global__ void texture_shade_kernel(TexArgs t, const int64_t *texel, const floa
                                      float *sigma)
 {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        float f[3 + 7 * QF_MAX_LOBES + 1];
-        decode_texel(t, texel[i * 2], texel[i * 2 + 1], f);
-        shade_decoded(f, t.n_lobes, dirs[i * 3], dirs[i * 3 + 1], dirs[i * 3 + 2], rgb + i * 3);
-        sigma[i] = f[3 + 7 * t.n_lobes];
+        const int64_t px = texel[i * 2] * t.size + texel[i * 2 + 1];
+        const float dx = dirs[i * 3], dy = dirs[i * 3 + 1], dz = dirs[i * 3 + 2];
+        float r = 0.0f, g = 0.0f, b = 0.0f;
+#pragma unroll
+        for (int l = 0; l < QF_MAX_LOBES; ++l) {
+            if (l < t.n_lobes) {
+                float x[7];
+                decode_lobe(t, l, px, x);
+                const float nrm = sqrtf((x[0] * x[0] + x[1] * x[1]) + x[2] * x[2]);
+                const float dotp = ((x[0] / nrm) * dx + (x[1] / nrm) * dy) + (x[2] / nrm) * dz;
+                const float e = expf(fabsf(x[3]) * (dotp - 1.0f));
+                r += x[4] * e;
+                g += x[5] * e;
+                b += x[6] * e;
+            }
+        }
+        rgb[i * 3 + 0] = 1.0f / (1.0f + expf(-(decode_color(t.diffuse[px * 3 + 0], t.sigmoid_codec) + r)));
+        rgb[i * 3 + 1] = 1.0f / (1.0f + expf(-(decode_color(t.diffuse[px * 3 + 1], t.sigmoid_codec) + g)));
+        rgb[i * 3 + 2] = 1.0f / (1.0f + expf(-(decode_color(t.diffuse[px * 3 + 2], t.sigmoid_codec) + b)));
+        const float a = (float)t.alpha[px] / 255.0f;
+        sigma[i] = -logf(fmaxf(1.0f - a, 1e-6f)) / 0.005f;
     }
 }
 
@@ -1661,7 +1677,7 @@ extern "C" int qf_pack_samples(const float *rays_o, const float *rays_d, int64_t
 
 extern "C" int qf_pack_tiles(const float *rays_o, const float *rays_d, int32_t width, int32_t height, int32_t max_hits,
                              const int32_t *hit_tri, const float *hit_t, const int32_t *hit_count, const int64_t *tile_base,
-                             const int64_t *total, float *xyz_c, float *dirs_c, float *depth_c, int64_t *tri_c,
+                             const int64_t *total, float *xyz_c, float *dirs_c, float *depth_c, int32_t *tri_c,
                              const uint64_t *keep_mask, const int32_t *raw_count, float min_separation,
                              int32_t *final_count, int32_t *dropped, int64_t *host_out, void *stream)
 {
@@ -1795,24 +1811,31 @@ extern "C" int qf_texture_shade_packed(const uint8_t *records, int32_t texture_s
     if (n_lobes < 1 || n_lobes > QF_MAX_LOBES) return QF_ERR_UNSUPPORTED;
     if (n == 0) return QF_OK;
     if (!texel || !dirs || !rgb || !sigma) return QF_ERR_INVALID_ARGUMENT;
-    QF_SIMPLE_LAUNCH(texture_shade_packed_kernel<false>, n, records, (int)texture_size, (int)n_lobes, (int)sigmoid_codec,
-                     lambda_thres, texel, dirs, n, rgb, sigma, (const TexelRecord *)nullptr, (const float *)nullptr,
-                     (const int64_t *)nullptr);
+    QF_SIMPLE_LAUNCH((texture_shade_packed_kernel<false, int64_t>), n, records, (int)texture_size, (int)n_lobes,
+                     (int)sigmoid_codec, lambda_thres, texel, dirs, n, rgb, sigma, (const TexelRecord *)nullptr,
+                     (const float *)nullptr, (const int64_t *)nullptr);
     return QF_OK;
 }
 
 extern "C" int qf_texture_shade_points(const uint8_t *records, int32_t texture_size, int32_t n_lobes, int32_t sigmoid_codec,
                                        float lambda_thres, const void *triangle_records, const float *points,
-                                       const int64_t *index_tri, const float *dirs, int64_t n, float *rgb, float *sigma,
-                                       void *stream)
+                                       const int64_t *index_tri, const int32_t *index_tri32, const float *dirs, int64_t n,
+                                       float *rgb, float *sigma, void *stream)
 {
     if (!records || !triangle_records || texture_size < 1 || n < 0) return QF_ERR_INVALID_ARGUMENT;
     if (n_lobes < 1 || n_lobes > QF_MAX_LOBES) return QF_ERR_UNSUPPORTED;
     if (n == 0) return QF_OK;
-    if (!points || !index_tri || !dirs || !rgb || !sigma) return QF_ERR_INVALID_ARGUMENT;
-    QF_SIMPLE_LAUNCH(texture_shade_packed_kernel<true>, n, records, (int)texture_size, (int)n_lobes, (int)sigmoid_codec,
-                     lambda_thres, (const int64_t *)nullptr, dirs, n, rgb, sigma,
-                     static_cast<const TexelRecord *>(triangle_records), points, index_tri);
+    if (!points || (!index_tri == !index_tri32) || !dirs || !rgb || !sigma) return QF_ERR_INVALID_ARGUMENT;   // exactly one id array
+    const TexelRecord *tr = static_cast<const TexelRecord *>(triangle_records);
+    if (index_tri32) {
+        QF_SIMPLE_LAUNCH((texture_shade_packed_kernel<true, int32_t>), n, records, (int)texture_size, (int)n_lobes,
+                         (int)sigmoid_codec, lambda_thres, (const int64_t *)nullptr, dirs, n, rgb, sigma, tr, points,
+                         index_tri32);
+    } else {
+        QF_SIMPLE_LAUNCH((texture_shade_packed_kernel<true, int64_t>), n, records, (int)texture_size, (int)n_lobes,
+                         (int)sigmoid_codec, lambda_thres, (const int64_t *)nullptr, dirs, n, rgb, sigma, tr, points,
+                         index_tri);
+    }
     return QF_OK;
 }
 

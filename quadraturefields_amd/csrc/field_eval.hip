@@ -19,19 +19,6 @@
 //   * workgroup = 8 waves, persistent: grid = CUs, waves stride over the 16-point groups of their XCD's share.
 #include "field_common.h"
 
-// EXPERIMENT SWITCH (off in the product build): -DQF_REC_SIM=1|2 replaces the 8 corner gathers of levels 12..15 by the
-// FETCH PATTERN of a "cell record" layout -- one (1) or two (2) 128-byte lines per (point, level), addressed by a hash
-// of the cell, out of a table of 2^QF_REC_SIM_LOG2 lines (environment, default 29 = 64 GB) -- to measure what such a
-// layout could buy before building it.  Values are garbage; only the timing means anything.  Result (profiles/r2/
-// cell_record_experiment.md): half the fabric requests, no time gained at the table sizes the bench scene needs, so
-// the layout was not built.  tools/cell_record_experiment.sh runs it.
-#ifndef QF_REC_SIM
-#define QF_REC_SIM 0
-#endif
-#if QF_REC_SIM > 0
-#include <cstdlib>
-#endif
-
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
@@ -62,10 +49,6 @@ struct FieldArgs {
     int32_t n_lobes;
     int32_t n_out;      // 3 + 7L
     int32_t nt_out;     // ceil(n_out / 16)
-#if QF_REC_SIM > 0
-    const float4 *rec_sim;
-    uint32_t rec_mask;
-#endif
 };
 
 __device__ __forceinline__ f32x4 mfma(float a, float b, f32x4 c)
@@ -216,34 +199,6 @@ __global__ __launch_bounds__(kBlock, 4) void field_kernel(const FieldArgs a)
             lc.scale = __uint_as_float(lv[4]);
             uint32_t idx[8];
             level_indices(lc, x01, y01, z01, idx, frac[j]);
-#if QF_REC_SIM > 0
-            if (j == 3) {       // see QF_REC_SIM above: the fetch pattern of a cell-record layout, not its values
-                const float px = fmaf(lc.scale, x01, 0.5f), py = fmaf(lc.scale, y01, 0.5f), pz = fmaf(lc.scale, z01, 0.5f);
-                const uint32_t gx = (uint32_t)(int32_t)floorf(px), gy = (uint32_t)(int32_t)floorf(py), gz = (uint32_t)(int32_t)floorf(pz);
-                uint32_t h = (gx >> 1) * 0x9E3779B1u ^ gy * 0x85EBCA77u ^ gz * 0xC2B2AE3Du ^ (uint32_t)(4 * j + g) * 0x27D4EB2Fu;
-                h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12;
-                const uint32_t s1 = h & a.rec_mask;
-                const float4 *l1 = a.rec_sim + (size_t)s1 * 8 + ((gx & 1u) ? 2 : 0);
-                const float4 v0 = l1[0], v1 = l1[1], v2 = l1[2], v3 = l1[3];
-                const float2 k1 = reinterpret_cast<const float2 *>(a.rec_sim + (size_t)s1 * 8)[12];
-                val[j][0] = make_float2(v0.x + k1.x, v0.y); val[j][1] = make_float2(v0.z, v0.w);
-                val[j][2] = make_float2(v1.x, v1.y); val[j][3] = make_float2(v1.z, v1.w);
-                val[j][4] = make_float2(v2.x, v2.y); val[j][5] = make_float2(v2.z, v2.w);
-                val[j][6] = make_float2(v3.x, v3.y); val[j][7] = make_float2(v3.z, v3.w + k1.y);
-#if QF_REC_SIM > 1
-                uint32_t h2 = h * 0x165667B1u + 0x9E3779B9u; h2 ^= h2 >> 13;
-                const uint32_t s2 = h2 & a.rec_mask;
-                const float4 *l2 = a.rec_sim + (size_t)s2 * 8 + ((gx & 1u) ? 2 : 0);
-                const float4 w0 = l2[0], w1 = l2[1], w2 = l2[2], w3 = l2[3];
-                const float2 k2 = reinterpret_cast<const float2 *>(a.rec_sim + (size_t)s2 * 8)[12];
-                val[j][0].x += w0.x + k2.x; val[j][1].x += w0.z; val[j][2].x += w1.x; val[j][3].x += w1.z;
-                val[j][4].x += w2.x; val[j][5].x += w2.z; val[j][6].x += w3.x; val[j][7].x += w3.z + k2.y;
-                val[j][0].y += w0.y; val[j][1].y += w0.w; val[j][2].y += w1.y; val[j][3].y += w1.w;
-                val[j][4].y += w2.y; val[j][5].y += w2.w; val[j][6].y += w3.y; val[j][7].y += w3.w;
-#endif
-                continue;
-            }
-#endif
 #pragma unroll
             for (int c = 0; c < 8; ++c) val[j][c] = a.table[idx[c]];
         }
@@ -535,18 +490,18 @@ __global__ __launch_bounds__(kBlock, 4) void deform_kernel(const DeformArgs a)
     float *bias = lds + kDeformMfma * 64;
     if (tid < 32) bias[tid] = a.b2[tid];
     if (tid == 32) bias[32] = a.bout[0];
+    // the per-level constants live in LDS next to the weights, as in field_kernel (round 2 kept four LevelConst per lane
+    // in registers for the whole point loop: 128 VGPRs + 6 spilled, 28 B/lane of scratch)
+    uint32_t *lvl_lds = reinterpret_cast<uint32_t *>(bias + 64);
+    if (tid < QF_MAX_LEVELS) {
+        lvl_lds[tid * 8 + 0] = a.grid.offset[tid];
+        lvl_lds[tid * 8 + 1] = a.grid.rows[tid];
+        lvl_lds[tid * 8 + 2] = a.grid.res[tid];
+        lvl_lds[tid * 8 + 3] = (a.grid.hashed_mask >> tid) & 1u;
+        lvl_lds[tid * 8 + 4] = __float_as_uint(a.grid.scale[tid]);
+    }
     __syncthreads();
 
-    LevelConst lc[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int level = 4 * j + g;
-        lc[j].offset = a.grid.offset[level];
-        lc[j].rows = a.grid.rows[level];
-        lc[j].res = a.grid.res[level];
-        lc[j].scale = a.grid.scale[level];
-        lc[j].hashed = (a.grid.hashed_mask >> level) & 1u;
-    }
     // one contiguous eighth of the processing order per XCD (see field_kernel)
     const int64_t n_groups = (a.n + 15) >> 4;
     int64_t grp_begin, grp_end, wave_stride;
@@ -573,10 +528,21 @@ __global__ __launch_bounds__(kBlock, 4) void deform_kernel(const DeformArgs a)
         float in[9];
         float frac[4][3];
         float2 val[4][8];
+        // LDS contents are loop-invariant; opaque offsets keep the compiler from hoisting the level table and the
+        // weight operands out of the point loop
+        int loff = lane, goff = g * 8;
+        asm volatile("" : "+v"(loff), "+v"(goff));
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
+            const uint32_t *lv = lvl_lds + 32 * j + goff;     // level 4j + g
+            LevelConst lc;
+            lc.offset = lv[0];
+            lc.rows = lv[1];
+            lc.res = lv[2];
+            lc.hashed = lv[3];
+            lc.scale = __uint_as_float(lv[4]);
             uint32_t idx[8];
-            level_indices(lc[j], x01, y01, z01, idx, frac[j]);
+            level_indices(lc, x01, y01, z01, idx, frac[j]);
 #pragma unroll
             for (int c = 0; c < 8; ++c) val[j][c] = a.table[idx[c]];
         }
@@ -587,8 +553,6 @@ __global__ __launch_bounds__(kBlock, 4) void deform_kernel(const DeformArgs a)
             for (int j = 0; j < 4; ++j)
                 *reinterpret_cast<float2 *>(a.enc_out + pt * 32 + 2 * (4 * j + g)) = make_float2(in[2 * j], in[2 * j + 1]);
         }
-        int loff = lane;
-        asm volatile("" : "+v"(loff));
         const float *wl = lds + loff;
         in[8] = g == 0 ? x01 : (g == 1 ? y01 : (g == 2 ? z01 : 1.0f));
         f32x4 h1[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
@@ -684,20 +648,6 @@ extern "C" int qf_field_forward(const qf_field_desc *desc, const float *table, c
     a.geo = geo;
     a.features = features;
     a.order = order;
-#if QF_REC_SIM > 0
-    {
-        static float4 *sim = nullptr;
-        static uint32_t mask = 0;
-        if (!sim) {
-            const char *e = getenv("QF_REC_SIM_LOG2");
-            const int lg = e ? atoi(e) : 29;
-            QF_HIP_TRY(hipMalloc((void **)&sim, ((size_t)1 << lg) * 128));
-            mask = (1u << lg) - 1u;
-        }
-        a.rec_sim = sim;
-        a.rec_mask = mask;
-    }
-#endif
     if (n == 0) return QF_OK;
     if (!xyz) return QF_ERR_INVALID_ARGUMENT;
     hipStream_t st = qf_stream(stream);
@@ -763,7 +713,7 @@ extern "C" int qf_deform_field_forward(const qf_grid_desc *grid, const float *ta
     a.n = n;
     a.out = out;
     a.enc_out = enc_out;
-    const size_t lds_bytes = (size_t)(kDeformMfma * 64 + 64) * sizeof(float);
+    const size_t lds_bytes = (size_t)(kDeformMfma * 64 + 64 + 8 * QF_MAX_LEVELS) * sizeof(float);
     int64_t blocks = qf_div_up((n + 15) / 16, kBlock / 64);
     const int64_t cap = (int64_t)qf_cu_count_cached();     // one workgroup per CU, see launch_field
     if (blocks > cap) blocks = cap;

@@ -328,12 +328,8 @@ extern "C" int qf_grid_encode_backward_ws(const qf_grid_desc *desc, const float 
     }
     plan.first_item[QF_MAX_LEVELS] = item;
     const size_t lds = (size_t)kLdsRows * sizeof(float2);
-    static bool attr_set = false;
-    if (!attr_set) {
-        QF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(grid_backward_table_lds_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    static QfLdsAttr attr;                           // per device
+    QF_HIP_TRY(qf_ensure_dynamic_lds(attr, reinterpret_cast<const void *>(grid_backward_table_lds_kernel), lds));
     hipLaunchKernelGGL(grid_backward_table_lds_kernel, dim3((unsigned)item), dim3(kScatterThreads), lds, st, ga, plan, x01,
                        lm, n, grad_table);
     QF_LAUNCH_CHECK();

@@ -29,7 +29,11 @@ extern "C" const char *qf_status_string(int status)
     }
 }
 
-extern "C" int qf_abi_version(void) { return QF_ABI_VERSION; }
+// An experiment build (tools/cell_record_experiment.sh) adds an offset, so that the loader refuses it as the product.
+#ifndef QF_ABI_VERSION_OFFSET
+#define QF_ABI_VERSION_OFFSET 0
+#endif
+extern "C" int qf_abi_version(void) { return QF_ABI_VERSION + QF_ABI_VERSION_OFFSET; }
 
 int qf_cu_count_cached()
 {

@@ -909,12 +909,8 @@ extern "C" int qf_ngp_mlp_backward(const float *enc, const float *dirs, const ui
     a.enc = enc; a.dirs = dirs; a.sel = selector; a.d_rgb = d_rgb; a.d_sigma = d_sigma;
     a.base_w = base_w; a.head_w = head_w; a.n = n; a.d_enc = d_enc; a.g_base = grad_base_w; a.g_head = grad_head_w;
     const size_t lds_bytes = (size_t)((kFwdMfma + kBwdMfma) * 64 + (kTrainBlock / 64) * 16 * 17) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        QF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(ngp_mlp_backward_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        attr_set = true;
-    }
+    static QfLdsAttr attr;                           // per device
+    QF_HIP_TRY(qf_ensure_dynamic_lds(attr, reinterpret_cast<const void *>(ngp_mlp_backward_kernel), lds_bytes));
     const int64_t n_groups = (n + 15) / 16;
     int64_t blocks = qf_div_up(n_groups, kTrainBlock / 64);
     const int64_t cap = (int64_t)qf_cu_count_cached();
@@ -960,12 +956,8 @@ extern "C" int qf_sg_mlp_backward(const float *enc, const uint8_t *selector, con
     a.g_w2 = const_cast<float *>(grad_head->w2); a.g_b2 = const_cast<float *>(grad_head->b2);
     a.g_wout = const_cast<float *>(grad_head->wout); a.g_bout = const_cast<float *>(grad_head->bout);
     const size_t lds_bytes = (size_t)((kSgFwdMfma + kSgBwdMfma) * 64 + 64 + (kTrainBlock / 64) * 16 * 17) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        QF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(sg_mlp_backward_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        attr_set = true;
-    }
+    static QfLdsAttr attr;                           // per device
+    QF_HIP_TRY(qf_ensure_dynamic_lds(attr, reinterpret_cast<const void *>(sg_mlp_backward_kernel), lds_bytes));
     const int64_t n_groups = (n + 15) / 16;
     int64_t blocks = qf_div_up(n_groups, kTrainBlock / 64);
     const int64_t cap = (int64_t)qf_cu_count_cached();

@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "qf_hip.h"
 
 #define QF_HIP_TRY(expr)                       \
@@ -39,4 +41,22 @@ static inline int qf_grid_1d(int64_t n, int block, int blocks_per_cu = 8)
     int64_t cap = (int64_t)qf_cu_count_cached() * blocks_per_cu;
     if (want < 1) want = 1;
     return (int)(want < cap ? want : cap);
+}
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) for a kernel that wants more than 48 KB of dynamic LDS: the attribute
+// is PER DEVICE, so one flag per device ordinal (atomic: the entry points may be called from several host threads); a
+// process that launches on a second GPU sets it there too instead of failing the launch.
+struct QfLdsAttr {
+    std::atomic<bool> set[64];
+};
+static inline hipError_t qf_ensure_dynamic_lds(QfLdsAttr &a, const void *fn, size_t bytes)
+{
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const bool tracked = dev >= 0 && dev < 64;
+    if (tracked && a.set[dev].load(std::memory_order_acquire)) return hipSuccess;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess && tracked) a.set[dev].store(true, std::memory_order_release);
+    return e;
 }

@@ -445,7 +445,7 @@ class RayIntersector:
             layout = (None, xyz_c, dirs_c)
             optimistic = False
             final_count = torch.empty((n,), dtype=torch.int32, device=dev)
-            frame.tri_c = torch.empty((cap,), dtype=torch.int64, device=dev) if want_tri else None
+            frame.tri_c = torch.empty((cap,), dtype=torch.int32, device=dev) if want_tri else None
             _C.check(_C.lib().qf_pack_tiles(_C.ptr(o), _C.ptr(d), int(width), n // int(width), k, _C.ptr(hit_tri),
                                             _C.ptr(hit_t), _C.ptr(hit_count), _C.ptr(tile_base), _C.ptr(buf[n:]),
                                             _C.ptr(xyz_c), _C.ptr(dirs_c), _C.ptr(depth_c), _C.ptr(frame.tri_c),

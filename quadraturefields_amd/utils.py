@@ -431,14 +431,16 @@ def shade_baked_points(mesh_intersect, uv, compressor, points, index_tri, dirs):
     Same values as the two calls."""
     records, _, _, _ = _triangle_records(mesh_intersect, uv)
     points, dirs = _C.f32c(points), _C.f32c(dirs)
-    index_tri = _C.i64c(index_tri)
+    # int32 ids (what the tile pack writes) go to the kernel as they are; anything else as the reference's int64
+    tri32 = index_tri.contiguous() if index_tri.dtype == torch.int32 else None
+    tri64 = None if tri32 is not None else _C.i64c(index_tri)
     n = points.shape[0]
     rgb = torch.empty((n, 3), dtype=torch.float32, device=points.device)
     sigma = torch.empty((n,), dtype=torch.float32, device=points.device)
     _C.check(_C.lib().qf_texture_shade_points(
         _C.ptr(compressor.records()), int(compressor.alpha.shape[0]), compressor.num_lobes,
         1 if compressor.compression_type == "sigma" else 0, float(compressor.lambda_thres), _C.ptr(records), _C.ptr(points),
-        _C.ptr(index_tri), _C.ptr(dirs), n, _C.ptr(rgb), _C.ptr(sigma), _C.stream()), "qf_texture_shade_points")
+        _C.ptr(tri64), _C.ptr(tri32), _C.ptr(dirs), n, _C.ptr(rgb), _C.ptr(sigma), _C.stream()), "qf_texture_shade_points")
     return rgb, sigma
 
 
