@@ -474,11 +474,12 @@ def sharded_frames(device, rank, world, scene0, n_scenes, frames_per_scene, back
     cuts = shards[0].last_cuts
     return {
         "workload": f"configs[3]: {len(scenes)} seeded scenes x {frames_per_scene} frames, each {W}x{H} frame cut into "
-                    f"{world} cost-balanced row band(s), one all_gather_into_tensor of the bands per frame",
+                    f"{world} cost-balanced row band(s), one collective of the bands per frame",
         "scenes": len(scenes), "frames": n, "ranks": world, "scaling": "strong",
         "latency_ms_per_frame": lat / n * 1e3, "ms_per_frame_pipelined": thr / n * 1e3,
         "rays_per_s": W * H * n / thr, "rays_per_s_latency_mode": W * H * n / lat,
-        "gather": "none (1 rank)" if world == 1 else "all_gather_into_tensor, 20 B/ray, bands padded to the tallest",
+        "gather": "none (1 rank)" if world == 1 else f"parallel.gather_bands mode {parallel.GATHER_MODE!r}: one collective per "
+                  "frame, 20 B/ray (exact = all_to_all_single with split sizes, nothing padded)",
         "band_rows": [cuts[r + 1] - cuts[r] for r in range(world)],
     }
 

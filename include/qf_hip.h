@@ -119,14 +119,19 @@ typedef struct qf_sg_head {
 } qf_sg_head;
 
 /* xyz [n,3] world positions, dirs [n,3] unit view directions (may be NULL for HEAD_NONE /
- * HEAD_SG_FEATURES).  order: NULL, or a permutation of [0,n) giving the order in which points are PROCESSED
+ * HEAD_SG_FEATURES).  n_device (or NULL; also on qf_field_forward_bf16, qf_deform_field_forward,
+ * qf_texture_shade_points and, as total_device, qf_deform_resort_tiles): the point count lives in DEVICE memory
+ * (int64; qf_tile_offsets' / qf_frame_offsets' total) and n is the capacity of the arrays -- min(*n_device, n) points
+ * are processed.  A render-only frame needs no host wait between its tile pack and its field kernel this way, and is a
+ * fixed sequence of launches into worst-case buffers (capturable as a HIP graph).
+ * order: NULL, or a permutation of [0,n) giving the order in which points are PROCESSED
  * (16 consecutive slots share a wave pass; spatially coherent groups hit the caches better, see
  * qf_coherent_order); outputs are indexed by point, so results do not depend on it.
  * Outputs (any may be NULL when not produced by the head):
  *   rgb [n,3]; sigma [n] (density after exp(x-1)*selector); geo [n,15]; features [n,3+7L+1]. */
 int qf_field_forward(const qf_field_desc *desc /* host */, const float *table,
                      const float *base_w, const float *head_ngp_w, const qf_sg_head *head_sg /* host */,
-                     const float *xyz, const float *dirs, int64_t n, const int32_t *order,
+                     const float *xyz, const float *dirs, int64_t n, const int64_t *n_device, const int32_t *order,
                      float *rgb, float *sigma, float *geo, float *features,
                      float *enc_out /* [n,32] or NULL: the hash-grid encoding, for the training step's backward */,
                      void *stream);
@@ -145,7 +150,8 @@ typedef struct qf_sg_head_bf16 {
 int qf_field_forward_bf16(const qf_field_desc *desc /* host */, const uint16_t *table /* [rows,2] bf16 */,
                           const uint16_t *base_w, const uint16_t *head_ngp_w,
                           const qf_sg_head_bf16 *head_sg /* host */, const float *xyz, const float *dirs,
-                          int64_t n, const int32_t *order, float *rgb, float *sigma, float *geo, void *stream);
+                          int64_t n, const int64_t *n_device, const int32_t *order, float *rgb, float *sigma, float *geo,
+                          void *stream);
 
 /* Backward of the two MLPs of NGPRadianceField (ngp.py:757-809), fused: recomputes the forward pass from the grid
  * encodings, back-propagates dL/drgb [n,3] and dL/ddensity [n] to dL/denc [n,32] (-> qf_grid_encode_backward) and
@@ -185,8 +191,9 @@ int qf_sg_features_to_rgb_backward(const float *features, int64_t feat_stride, c
 int qf_deform_field_forward(const qf_grid_desc *grid /* host */, const float *table, float scale,
                             int32_t hidden, const float *w1, const float *b1, const float *w2,
                             const float *b2, const float *wout, const float *bout,
-                            const float *xyz, int64_t n, const int32_t *order, float *out /* [n] */,
-                            float *enc_out /* [n,32] or NULL */, void *stream);
+                            const float *xyz, int64_t n, const int64_t *n_device /* or NULL, see qf_field_forward */,
+                            const int32_t *order, float *out /* [n] */, float *enc_out /* [n,32] or NULL */,
+                            void *stream);
 
 /* Backward of the decoder of qf_deform_field_forward, fused (training: the deformation field of
  * train_finetune.py:387-399 is optimised together with the radiance field).  enc [n,32] = grid encoding of x01 [n,3],
@@ -357,19 +364,24 @@ typedef struct qf_camera {
     float cx, cy;       /* principal point (width/2, height/2 in the reference) */
     int32_t width, height;
 } qf_camera;
-int qf_raster_intersect(const qf_bvh *bvh, const qf_camera *cam /* host */, const float *rays_o,
+/* cull_chunks != 0 (also on qf_raster_intersect_wide): for a camera that sees only PART of the scene -- the row bands
+ * of a frame sharded over several GPUs -- the triangles (stored in BVH leaf order) are first culled in chunks of 64
+ * against the camera's image with the triangle pass's own conservative screen-box test, and only the surviving
+ * chunks are projected (two small extra launches; the per-frame set-up then shrinks with the band).  Same hits.
+ * Culled calls on one handle must be issued on one stream (the handle owns the visible-chunk list).          */
+int qf_raster_intersect(qf_bvh *bvh, const qf_camera *cam /* host */, const float *rays_o,
                         const float *rays_d, int64_t n_rays, int32_t max_hits, int32_t *hit_tri, float *hit_t,
-                        int32_t *hit_count, int32_t *overflow, int32_t sort_lists, void *stream);
+                        int32_t *hit_count, int32_t *overflow, int32_t sort_lists, int32_t cull_chunks, void *stream);
 /* The same pass for dense scenes, where most rays meet more than K = max_hits triangles (thin concentric shells):
  * up to wide_hits >= max_hits candidates per ray are collected in the scratch lists wide_tri / wide_t
  * ([wide_hits, n_rays], slot-major), then every ray's K nearest under (t, tri) -- the rule of qf_bvh_intersect -- go
  * to hit_tri / hit_t [n_rays, max_hits] in arrival order (as with sort_lists = 0) and hit_count is clamped to K.
  * Rays with more than wide_hits candidates keep their raw count (> K) for qf_bvh_repair_overflow; *overflow counts
  * the candidates beyond wide_hits.                                                                           */
-int qf_raster_intersect_wide(const qf_bvh *bvh, const qf_camera *cam /* host */, const float *rays_o,
+int qf_raster_intersect_wide(qf_bvh *bvh, const qf_camera *cam /* host */, const float *rays_o,
                              const float *rays_d, int64_t n_rays, int32_t max_hits, int32_t wide_hits,
                              int32_t *wide_tri, float *wide_t, int32_t *hit_tri, float *hit_t, int32_t *hit_count,
-                             int32_t *overflow, void *stream);
+                             int32_t *overflow, int32_t cull_chunks, void *stream);
 /* The fall-back, per ray: after qf_raster_intersect with sort_lists = 0 (raw counts), re-traverses exactly the rays
  * with hit_count > max_hits through the BVH (exact K nearest under the handle's min_separation rule; their lists and
  * counts are overwritten, in the layout of qf_bvh_intersect) and leaves every other ray's list alone.  No host round
@@ -428,7 +440,9 @@ int qf_frame_offsets(const int32_t *hit_count, int64_t n_rays, int32_t max_hits,
 /* The same for a frame that is only rendered: tile_base (as above) and *total (device int64) alone -- what
  * qf_pack_tiles and qf_composite_tiles take -- in two launches, without the per-ray offsets.              */
 int qf_tile_offsets(const int32_t *hit_count, int32_t max_hits, int32_t width, int32_t height, int64_t *tile_base,
-                    int64_t *total, const int32_t *overflow_in, int64_t *host_out, void *stream);
+                    int64_t *total, const int32_t *overflow_in, int64_t *host_out,
+                    int32_t *zero_word /* or NULL: a device int32 the scan launch zeroes on the way -- the dropped-hit
+                                          counter of the qf_pack_tiles that follows (dropped_is_zero) */, void *stream);
 
 /* Packs the per-ray hit lists into the sample arrays sampling_raytrace_numpy returns
  * (mesh_utils.py:359-387), already sorted by (ray, depth): location = o + t d in float64,
@@ -480,7 +494,10 @@ int qf_pack_tiles(const float *rays_o, const float *rays_d, int32_t width, int32
                   const int32_t *hit_tri, const float *hit_t, const int32_t *hit_count, const int64_t *tile_base,
                   const int64_t *total, float *xyz_c, float *dirs_c, float *depth_c, int32_t *tri_c /* or NULL */,
                   const uint64_t *keep_mask, const int32_t *raw_count, float min_separation, int32_t *final_count,
-                  int32_t *dropped, int64_t *host_out, void *stream);
+                  int32_t *dropped, int64_t *host_out,
+                  int32_t dropped_is_zero /* non-zero, without host_out: *dropped is already zero (qf_tile_offsets
+                                             zero_word) -- no memset launch; the count stays in *dropped */,
+                  void *stream);
 
 /* Spatially coherent PROCESSING order for qf_field_forward when the rays are a row-major width x height image:
  * (8x8 pixel tile, hit rank, pixel in tile).  Two steps around one exclusive scan the caller does:
@@ -502,12 +519,19 @@ int qf_coherent_layout(const int32_t *hit_count, const int64_t *ray_offset, cons
  * without samples get their background from the same launch.  hit_count [w*h] (pixel r has min(hit_count[r],
  * max_hits) samples) and tile_base as qf_frame_offsets / qf_coherent_layout took them; constant step delta_const
  * (find_deltas, mesh_utils.py:225-231).  Same values as qf_derive_properties on the ray-major arrays, bit for bit
- * (same per-ray operation order).  weights_c: the weights in the coherent order, or NULL.             */
+ * (same per-ray operation order).  weights_c: the weights in the coherent order, or NULL.
+ * out_packed (or NULL): [w*h, 5] = rgb | alpha | depth per pixel in ONE array instead of the three (which may then be
+ * NULL) -- the 20 B/ray block a row band of a sharded frame sends to the other ranks.             */
 int qf_composite_tiles(const float *rgb_c /* [n,3] */, const float *sigma_c /* [n] */, const float *depth_c /* [n] */,
                        float delta_const, const int32_t *hit_count /* [w*h] */, int32_t max_hits,
                        const int64_t *tile_base, int32_t width, int32_t height, int32_t bg_mode,
                        const float *bkgd /* [3] or NULL */, float *out_rgb, float *out_alpha, float *out_depth,
-                       float *weights_c, void *stream);
+                       float *weights_c, float *out_packed, void *stream);
+
+/* out_rows[y] = sum over the pixels of row y of min(hit_count, max_hits): quadrature points per pixel row of a frame
+ * (band).  No reference counterpart: the cost profile the band-sharded renderer balances its cuts with.   */
+int qf_row_sample_counts(const int32_t *hit_count, int32_t max_hits, int32_t width, int32_t height, float *out_rows,
+                         void *stream);
 
 /* The "before" evaluation of a frame in the coherent order (train_finetune.py:696; utils.py:555-572 + the re-sort of
  * mesh_utils.py:389-403): every sample is displaced along its ray by tanh(f) * scaling -- f_c [n] = the deformation
@@ -517,8 +541,8 @@ int qf_composite_tiles(const float *rgb_c /* [n,3] */, const float *sigma_c /* [
  * (final_count of qf_pack_tiles), tile_base as there, total = the arrays' slot count (host value).  The displacement is qf_apply_deformation's, bit for bit. */
 int qf_deform_resort_tiles(const float *f_c, float scaling, const float *xyz_c, const float *dirs_c,
                            const float *depth_c, const int32_t *hit_count, int32_t max_hits, const int64_t *tile_base,
-                           int64_t total /* slots of the arrays */, int32_t width, int32_t height, float *xyz_out,
-                           float *depth_out, void *stream);
+                           int64_t total /* slots of the arrays */, const int64_t *total_device /* or NULL */,
+                           int32_t width, int32_t height, float *xyz_out, float *depth_out, void *stream);
 
 /* Stable per-ray re-sort by depth after deformation (sampling_indexing, mesh_utils.py:394-403):
  * perm[i] = source index of the sample that lands at i.  index_ray must be grouped by ray.   */
@@ -612,7 +636,7 @@ int qf_texture_shade_packed(const uint8_t *records, int32_t texture_size, int32_
 int qf_texture_shade_points(const uint8_t *records, int32_t texture_size, int32_t n_lobes, int32_t sigmoid_codec,
                             float lambda_thres, const void *triangle_records, const float *points,
                             const int64_t *index_tri, const int32_t *index_tri32, const float *dirs, int64_t n,
-                            float *rgb, float *sigma, void *stream);
+                            const int64_t *n_device, float *rgb, float *sigma, void *stream);
 
 #ifdef __cplusplus
 }

@@ -65,21 +65,22 @@ _SIGNATURES = {
     "qf_grid_encode_backward_ws": (c_int, [POINTER(GridDesc), _P, _P, _P, c_int64, _P, _P, _P, c_int64, _P]),
     "qf_grid_encode_double_backward": (c_int, [POINTER(GridDesc), _P, _P, _P, _P, c_int64, _P, _P, _P, _P]),
     "qf_grid_mlp_forward": (c_int, [POINTER(GridDesc), _P, _P, _P, c_int64, _P, _P]),
-    "qf_field_forward": (c_int, [POINTER(FieldDesc), _P, _P, _P, POINTER(SGHead), _P, _P, c_int64, _P, _P, _P, _P, _P, _P, _P]),
-    "qf_field_forward_bf16": (c_int, [POINTER(FieldDesc), _P, _P, _P, POINTER(SGHead), _P, _P, c_int64, _P, _P, _P, _P, _P]),
+    "qf_field_forward": (c_int, [POINTER(FieldDesc), _P, _P, _P, POINTER(SGHead), _P, _P, c_int64, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "qf_field_forward_bf16": (c_int, [POINTER(FieldDesc), _P, _P, _P, POINTER(SGHead), _P, _P, c_int64, _P, _P, _P, _P, _P, _P]),
     "qf_ngp_mlp_backward": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int64, _P, _P, _P, _P]),
     "qf_sg_mlp_backward": (c_int, [_P, _P, _P, c_int64, _P, _P, POINTER(SGHead), c_int32, c_int64, _P, _P, POINTER(SGHead), _P]),
     "qf_sg_features_to_rgb": (c_int, [_P, c_int64, _P, c_int64, c_int32, _P, _P]),
     "qf_sg_features_to_rgb_backward": (c_int, [_P, c_int64, _P, _P, c_int64, c_int32, _P, c_int64, _P]),
-    "qf_deform_field_forward": (c_int, [POINTER(GridDesc), _P, c_float, c_int32, _P, _P, _P, _P, _P, _P, _P, c_int64, _P, _P, _P, _P]),
+    "qf_deform_field_forward": (c_int, [POINTER(GridDesc), _P, c_float, c_int32, _P, _P, _P, _P, _P, _P, _P, c_int64, _P, _P, _P, _P, _P]),
     "qf_deform_mlp_backward": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "qf_apply_deformation": (c_int, [_P, c_float, _P, _P, _P, c_int64, _P, _P, _P, _P]),
     "qf_mark_pack_boundaries": (c_int, [_P, c_int64, _P, _P]),
     "qf_exponential_integration": (c_int, [_P, c_int32, _P, _P, c_int64, c_int64, c_int32, _P, _P, _P]),
     "qf_sum_reduce": (c_int, [_P, c_int32, _P, c_int64, c_int64, _P, _P]),
     "qf_derive_properties": (c_int, [_P, _P, _P, _P, c_float, _P, c_int64, c_int64, c_int32, _P, _P, _P, _P, _P, _P, _P]),
-    "qf_deform_resort_tiles": (c_int, [_P, c_float, _P, _P, _P, _P, c_int32, _P, c_int64, c_int32, c_int32, _P, _P, _P]),
-    "qf_composite_tiles": (c_int, [_P, _P, _P, c_float, _P, c_int32, _P, c_int32, c_int32, c_int32, _P, _P, _P, _P, _P, _P]),
+    "qf_deform_resort_tiles": (c_int, [_P, c_float, _P, _P, _P, _P, c_int32, _P, c_int64, _P, c_int32, c_int32, _P, _P, _P]),
+    "qf_composite_tiles": (c_int, [_P, _P, _P, c_float, _P, c_int32, _P, c_int32, c_int32, c_int32, _P, _P, _P, _P, _P, _P, _P]),
+    "qf_row_sample_counts": (c_int, [_P, c_int32, c_int32, c_int32, _P, _P]),
     "qf_derive_properties_backward": (c_int, [_P, _P, _P, _P, c_float, _P, c_int64, c_int64, c_int32, _P, _P, _P, _P, _P, _P, _P, _P]),
     "qf_pack_info": (c_int, [_P, c_int64, c_int64, _P, _P]),
     "qf_exclusive_scan": (c_int, [_P, _P, c_int64, c_int64, c_int32, _P, _P]),
@@ -103,8 +104,8 @@ _SIGNATURES = {
     "qf_bvh_copy_tri_ids": (c_int, [_P, _P, c_int64]),
     "qf_bvh_intersect": (c_int, [_P, _P, _P, c_int64, c_int32, c_int32, _P, _P, _P, _P]),
     "qf_bvh_repair_overflow": (c_int, [_P, _P, _P, c_int64, c_int32, c_int32, _P, _P, _P, _P, _P, _P]),
-    "qf_raster_intersect": (c_int, [_P, POINTER(Camera), _P, _P, c_int64, c_int32, _P, _P, _P, _P, c_int32, _P]),
-    "qf_raster_intersect_wide": (c_int, [_P, POINTER(Camera), _P, _P, c_int64, c_int32, c_int32, _P, _P, _P, _P, _P, _P, _P]),
+    "qf_raster_intersect": (c_int, [_P, POINTER(Camera), _P, _P, c_int64, c_int32, _P, _P, _P, _P, c_int32, c_int32, _P]),
+    "qf_raster_intersect_wide": (c_int, [_P, POINTER(Camera), _P, _P, c_int64, c_int32, c_int32, _P, _P, _P, _P, _P, _P, c_int32, _P]),
     "qf_grid_march_count": (c_int, [POINTER(c_float), POINTER(c_int32), _P, _P, _P, _P, _P, c_int64, c_float, c_float,
                                     c_float, _P, _P]),
     "qf_grid_march_write": (c_int, [POINTER(c_float), POINTER(c_int32), _P, _P, _P, _P, _P, c_int64, c_float, c_float,
@@ -115,8 +116,8 @@ _SIGNATURES = {
     "qf_sample_offsets": (c_int, [_P, c_int64, c_int32, _P, _P, c_int64, _P]),
     "qf_frame_offsets_temp_bytes": (c_int64, [c_int64]),
     "qf_frame_offsets": (c_int, [_P, c_int64, c_int32, c_int32, c_int32, _P, _P, _P, c_int64, _P, _P, _P]),
-    "qf_tile_offsets": (c_int, [_P, c_int32, c_int32, c_int32, _P, _P, _P, _P, _P]),
-    "qf_pack_tiles": (c_int, [_P, _P, c_int32, c_int32, c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_float, _P, _P, _P, _P]),
+    "qf_tile_offsets": (c_int, [_P, c_int32, c_int32, c_int32, _P, _P, _P, _P, _P, _P]),
+    "qf_pack_tiles": (c_int, [_P, _P, c_int32, c_int32, c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_float, _P, _P, _P, c_int32, _P]),
     "qf_pack_samples": (c_int, [_P, _P, c_int64, c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_float, _P, _P]),
     "qf_tile_totals": (c_int, [_P, c_int32, c_int32, _P, _P]),
     "qf_coherent_order": (c_int, [_P, _P, _P, c_int32, c_int32, _P, _P]),
@@ -132,7 +133,7 @@ _SIGNATURES = {
     "qf_texture_shade": (c_int, [POINTER(TextureSet), _P, _P, c_int64, _P, _P, _P]),
     "qf_texture_pack": (c_int, [POINTER(TextureSet), _P, _P]),
     "qf_texture_shade_packed": (c_int, [_P, c_int32, c_int32, c_int32, c_float, _P, _P, c_int64, _P, _P, _P]),
-    "qf_texture_shade_points": (c_int, [_P, c_int32, c_int32, c_int32, c_float, _P, _P, _P, _P, _P, c_int64, _P, _P, _P]),
+    "qf_texture_shade_points": (c_int, [_P, c_int32, c_int32, c_int32, c_float, _P, _P, _P, _P, _P, c_int64, _P, _P, _P, _P]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 ABI_VERSION = 3              # QF_ABI_VERSION of include/qf_hip.h
@@ -201,6 +202,14 @@ def _after_fork_in_child():
 os.register_at_fork(after_in_child=_after_fork_in_child)
 
 
+def raw_stream() -> int:
+    """The current torch HIP stream of the current device as an integer handle.  The public
+    ``torch.cuda.current_stream().cuda_stream`` costs ~9 us of Python per call (device-index and availability look-ups,
+    a Stream object) -- with ~10 launches per 0.3 ms row band of a sharded frame that alone kept the host behind the
+    GPU; the raw getter is one C call."""
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
+
+
 def stream():
     """The current torch HIP stream as a raw handle.  Every kernel launch of the package goes through here, so this is
     also where a FORKED child is stopped: the reference runs its intersector inside DataLoader worker processes
@@ -212,7 +221,7 @@ def stream():
             "quadraturefields_amd was called from a forked child process (a DataLoader worker?): the HIP kernels must run "
             f"in the process that imported the package (pid {_OWNER_PID}).  Use num_workers=0 for the device path, or a "
             "'spawn' multiprocessing context.")
-    return c_void_p(torch.cuda.current_stream().cuda_stream)
+    return c_void_p(raw_stream())
 
 
 def f32c(t: torch.Tensor) -> torch.Tensor:

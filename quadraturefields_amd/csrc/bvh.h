@@ -34,6 +34,12 @@
 struct qf_bvh {
     float *d_nodes8 = nullptr;
     float *d_tris = nullptr;
+    // triangle-chunk culling of the camera-coherent pass (exact.hip: chunk_boxes_kernel / cull_chunks_kernel), allocated
+    // on first use: boxes of 64 consecutive leaf-order triangles; [2 counters | visible chunk ids]
+    float *d_chunk_box = nullptr;
+    int32_t *d_visible = nullptr;
+    bool chunk_dirty = true;         // the triangles changed (build / refit): boxes are recomputed before the next use
+    int cull_parity = 0;
     int64_t n_tri = 0;
     int64_t n_nodes = 0;             // binary build tree
     int64_t n_nodes8 = 0;            // wide tree

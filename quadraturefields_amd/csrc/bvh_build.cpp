@@ -161,6 +161,7 @@ int upload(qf_bvh *bvh, const float *tri_verts)
     if (!bvh->h_nodes8.empty())
         QF_HIP_TRY(hipMemcpy(bvh->d_nodes8, bvh->h_nodes8.data(), bvh->h_nodes8.size() * sizeof(float), hipMemcpyHostToDevice));
     if (!tris.empty()) QF_HIP_TRY(hipMemcpy(bvh->d_tris, tris.data(), tris.size() * sizeof(float), hipMemcpyHostToDevice));
+    bvh->chunk_dirty = true;
     return QF_OK;
 }
 
@@ -513,6 +514,7 @@ extern "C" int qf_bvh_refit_device(qf_bvh *bvh, const float *d_tri_verts, int64_
                            reinterpret_cast<const float4 *>(bvh->d_tris), n0, n1, bvh->eps * 1.25f);
         QF_LAUNCH_CHECK();
     }
+    bvh->chunk_dirty = true;
     // eps was sized from the extent at build / host-refit time; 1.25x covers the bounded vertex motion of training.
     // The host mirrors (h_nodes, h_nodes8) are NOT updated: inspection copies show the build state.
     return QF_OK;
@@ -523,6 +525,8 @@ extern "C" void qf_bvh_destroy(qf_bvh *bvh)
     if (!bvh) return;
     if (bvh->d_nodes8) (void)hipFree(bvh->d_nodes8);
     if (bvh->d_tris) (void)hipFree(bvh->d_tris);
+    if (bvh->d_chunk_box) (void)hipFree(bvh->d_chunk_box);
+    if (bvh->d_visible) (void)hipFree(bvh->d_visible);
     delete bvh;
 }
 

@@ -491,7 +491,7 @@ __global__ __launch_bounds__(64) void composite_tiles_kernel(
     const float *__restrict__ rgb_c, const float *__restrict__ sigma_c, const float *__restrict__ depth_c,
     float delta_const, const int32_t *__restrict__ hit_count, int max_hits, const int64_t *__restrict__ tile_base, int w,
     int h, int tiles_x, int bg_mode, const float *__restrict__ bkgd, float *__restrict__ out_rgb, float *__restrict__ out_alpha,
-    float *__restrict__ out_depth, float *__restrict__ weights_c)
+    float *__restrict__ out_depth, float *__restrict__ weights_c, float *__restrict__ out_packed)
 {
     const int tile = blockIdx.x, lane = threadIdx.x;
     int64_t ray = 0;
@@ -525,11 +525,32 @@ __global__ __launch_bounds__(64) void composite_tiles_kernel(
     } else {                                           // fill_background_kernel's values
         px[0] = px[1] = px[2] = (bg_mode == QF_BG_BLACK || bg_mode == QF_BG_NONE) ? 0.0f : 1.0f;
     }
+    if (out_packed) {                  // [n, 5] = rgb | alpha | depth per pixel: what the band gather sends, no concat launch
+        float *o = out_packed + ray * 5;
+        o[0] = px[0]; o[1] = px[1]; o[2] = px[2]; o[3] = acc.ca; o[4] = acc.cd;
+        return;
+    }
     out_rgb[ray * 3 + 0] = px[0];
     out_rgb[ray * 3 + 1] = px[1];
     out_rgb[ray * 3 + 2] = px[2];
     out_alpha[ray] = acc.ca;
     out_depth[ray] = acc.cd;
+}
+
+// quadrature points per pixel row, sum_x min(hit_count, K): what parallel.ShardedFrameRenderer balances its bands with
+// (one wave per row; replaces a clamp, a reshape and a row sum in torch)
+__global__ __launch_bounds__(64) void row_sample_counts_kernel(const int32_t *__restrict__ hit_count, int max_hits, int w, int h,
+                                                               float *__restrict__ out_rows)
+{
+    const int row = blockIdx.x, lane = threadIdx.x;
+    int sum = 0;
+    for (int x = lane; x < w; x += 64) {
+        const int c = hit_count[(int64_t)row * w + x];
+        sum += c < 0 ? 0 : (c < max_hits ? c : max_hits);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+    if (lane == 0) out_rows[row] = (float)sum;
 }
 
 // The "before" evaluation of a frame in the coherent order (train_finetune.py:696 -> utils.py:555-572 and the re-sort of
@@ -542,10 +563,11 @@ __global__ __launch_bounds__(64) void composite_tiles_kernel(
 __global__ __launch_bounds__(64) void deform_resort_tiles_kernel(
     const float *__restrict__ f_c, float scaling, const float *__restrict__ xyz_c, const float *__restrict__ dirs_c,
     const float *__restrict__ depth_c, const int32_t *__restrict__ hit_count, int max_hits,
-    const int64_t *__restrict__ tile_base, int64_t total, int w, int h, int tiles_x, int n_tiles,
-    float *__restrict__ xyz_out, float *__restrict__ depth_out)
+    const int64_t *__restrict__ tile_base, int64_t total, const int64_t *__restrict__ total_dev, int w, int h, int tiles_x,
+    int n_tiles, float *__restrict__ xyz_out, float *__restrict__ depth_out)
 {
     extern __shared__ float dr_lds[];
+    if (total_dev) { const int64_t td = *total_dev; total = td < total ? (td > 0 ? td : 0) : total; }   // device-side slot count
     const int K = max_hits;
     float *col_t = dr_lds + threadIdx.x;                                  // [K][64] new depth of source rank k
     int *col_s = reinterpret_cast<int *>(dr_lds + (size_t)K * 64) + threadIdx.x;      // [K][64] source rank at sorted place k
@@ -614,8 +636,8 @@ __global__ __launch_bounds__(64) void deform_resort_tiles_kernel(
 
 extern "C" int qf_deform_resort_tiles(const float *f_c, float scaling, const float *xyz_c, const float *dirs_c,
                                       const float *depth_c, const int32_t *hit_count, int32_t max_hits,
-                                      const int64_t *tile_base, int64_t total, int32_t width, int32_t height,
-                                      float *xyz_out, float *depth_out, void *stream)
+                                      const int64_t *tile_base, int64_t total, const int64_t *total_device, int32_t width,
+                                      int32_t height, float *xyz_out, float *depth_out, void *stream)
 {
     if (width < 1 || height < 1 || max_hits < 1 || max_hits > 64) return QF_ERR_INVALID_ARGUMENT;
     if (!f_c || !xyz_c || !dirs_c || !depth_c || !hit_count || !tile_base || total < 0 || !xyz_out || !depth_out)
@@ -623,8 +645,8 @@ extern "C" int qf_deform_resort_tiles(const float *f_c, float scaling, const flo
     if (xyz_out == xyz_c || depth_out == depth_c) return QF_ERR_INVALID_ARGUMENT;          // out of place
     const int tiles_x = (width + 7) / 8, tiles_y = (height + 7) / 8;
     hipLaunchKernelGGL(deform_resort_tiles_kernel, dim3(tiles_x * tiles_y), dim3(64), (size_t)max_hits * 64 * 8, qf_stream(stream),
-                       f_c, scaling, xyz_c, dirs_c, depth_c, hit_count, (int)max_hits, tile_base, total, (int)width, (int)height,
-                       tiles_x, tiles_x * tiles_y, xyz_out, depth_out);
+                       f_c, scaling, xyz_c, dirs_c, depth_c, hit_count, (int)max_hits, tile_base, total, total_device, (int)width,
+                       (int)height, tiles_x, tiles_x * tiles_y, xyz_out, depth_out);
     QF_LAUNCH_CHECK();
     return QF_OK;
 }
@@ -632,16 +654,26 @@ extern "C" int qf_deform_resort_tiles(const float *f_c, float scaling, const flo
 extern "C" int qf_composite_tiles(const float *rgb_c, const float *sigma_c, const float *depth_c, float delta_const,
                                   const int32_t *hit_count, int32_t max_hits, const int64_t *tile_base, int32_t width,
                                   int32_t height, int32_t bg_mode, const float *bkgd, float *out_rgb, float *out_alpha,
-                                  float *out_depth, float *weights_c, void *stream)
+                                  float *out_depth, float *weights_c, float *out_packed, void *stream)
 {
     if (width < 1 || height < 1 || max_hits < 1 || bg_mode < 0 || bg_mode > 3) return QF_ERR_INVALID_ARGUMENT;
-    if (!rgb_c || !sigma_c || !depth_c || !hit_count || !tile_base || !out_rgb || !out_alpha || !out_depth)
-        return QF_ERR_INVALID_ARGUMENT;
+    if (!rgb_c || !sigma_c || !depth_c || !hit_count || !tile_base) return QF_ERR_INVALID_ARGUMENT;
+    if (!out_packed && (!out_rgb || !out_alpha || !out_depth)) return QF_ERR_INVALID_ARGUMENT;
     if (bg_mode == QF_BG_CUSTOM && !bkgd) return QF_ERR_INVALID_ARGUMENT;
     const int tiles_x = (width + 7) / 8, tiles_y = (height + 7) / 8;
     hipLaunchKernelGGL(composite_tiles_kernel, dim3(tiles_x * tiles_y), dim3(64), 0, qf_stream(stream), rgb_c, sigma_c,
                        depth_c, delta_const, hit_count, (int)max_hits, tile_base, (int)width, (int)height, tiles_x, (int)bg_mode, bkgd,
-                       out_rgb, out_alpha, out_depth, weights_c);
+                       out_rgb, out_alpha, out_depth, weights_c, out_packed);
+    QF_LAUNCH_CHECK();
+    return QF_OK;
+}
+
+extern "C" int qf_row_sample_counts(const int32_t *hit_count, int32_t max_hits, int32_t width, int32_t height,
+                                    float *out_rows, void *stream)
+{
+    if (width < 1 || height < 1 || max_hits < 1 || !hit_count || !out_rows) return QF_ERR_INVALID_ARGUMENT;
+    hipLaunchKernelGGL(row_sample_counts_kernel, dim3(height), dim3(64), 0, qf_stream(stream), hit_count, (int)max_hits,
+                       (int)width, (int)height, out_rows);
     QF_LAUNCH_CHECK();
     return QF_OK;
 }
@@ -866,7 +898,7 @@ extern "C" int qf_split_layout(const int64_t *index_ray, int64_t n, int32_t widt
                        hit_count, ray_offset, invalid);
     QF_LAUNCH_CHECK();
     // tile bases: exclusive scan of the 8x8-tile totals (the grand total lands in ray_offset[n_rays], where it already is)
-    int rc = qf_tile_offsets(hit_count, 0x7fffffff, width, height, tile_base, ray_offset + n_rays, nullptr, nullptr, stream);
+    int rc = qf_tile_offsets(hit_count, 0x7fffffff, width, height, tile_base, ray_offset + n_rays, nullptr, nullptr, nullptr, stream);
     if (rc != QF_OK) return rc;
     const int tiles_x = (width + 7) / 8, tiles_y = (height + 7) / 8;
     hipLaunchKernelGGL(split_order_kernel, dim3(tiles_x * tiles_y), dim3(64), 0, st, hit_count, ray_offset, tile_base,

@@ -60,6 +60,64 @@ __device__ __forceinline__ uint64_t hit_key(float t, int id) { return ((uint64_t
 __device__ __forceinline__ float key_t(uint64_t k) { return __uint_as_float((uint32_t)(k >> 32)); }
 __device__ __forceinline__ int key_id(uint64_t k) { return (int)(uint32_t)k; }
 
+// A lane's hit list (cnt <= 32 entries, contiguous in LDS) sorted ascending in t (kTri = false) or (t, tri) (kTri = true)
+// THROUGH REGISTERS: a 32-key bitonic network, every index a compile-time constant, 240 compare-exchanges with no
+// memory in between.  The per-lane insertion sort it replaces walked the row in LDS, one dependent read-modify-write per
+// shift: ~18 us of a tile wave's ~40 us, which is what a row band of a frame sharded over 8 GPUs (one wave per SIMD,
+// nothing to overlap with) waited for.  Same order: t > 0, so the bit pattern of t orders like its value, +inf pads the
+// tail; hits with equal (t, tri) do not exist (a ray meets a triangle once), equal t alone are interchangeable samples.
+template <bool kTri>
+__device__ __forceinline__ void sort_row_32(float *row_t, int32_t *row_i, int cnt)
+{
+    if (kTri) {
+        uint64_t key[32];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) key[k] = k < cnt ? hit_key(row_t[k], row_i[k]) : ~0ull;
+#pragma unroll
+        for (int k = 2; k <= 32; k <<= 1) {
+#pragma unroll
+            for (int i = 0; i < 32; ++i) {
+                const int l = i ^ (k - 1);
+                if (l > i) { const uint64_t a = key[i], b = key[l]; key[i] = a < b ? a : b; key[l] = a < b ? b : a; }
+            }
+#pragma unroll
+            for (int j = k >> 2; j > 0; j >>= 1) {
+#pragma unroll
+                for (int i = 0; i < 32; ++i) {
+                    const int l = i ^ j;
+                    if (l > i) { const uint64_t a = key[i], b = key[l]; key[i] = a < b ? a : b; key[l] = a < b ? b : a; }
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 32; ++k)
+            if (k < cnt) { row_t[k] = key_t(key[k]); row_i[k] = key_id(key[k]); }
+    } else {
+        float key[32];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) key[k] = k < cnt ? row_t[k] : INFINITY;
+#pragma unroll
+        for (int k = 2; k <= 32; k <<= 1) {
+#pragma unroll
+            for (int i = 0; i < 32; ++i) {
+                const int l = i ^ (k - 1);
+                if (l > i) { const float a = key[i], b = key[l]; key[i] = fminf(a, b); key[l] = fmaxf(a, b); }
+            }
+#pragma unroll
+            for (int j = k >> 2; j > 0; j >>= 1) {
+#pragma unroll
+                for (int i = 0; i < 32; ++i) {
+                    const int l = i ^ j;
+                    if (l > i) { const float a = key[i], b = key[l]; key[i] = fminf(a, b); key[l] = fmaxf(a, b); }
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 32; ++k)
+            if (k < cnt) row_t[k] = key[k];
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // Wide-BVH multi-hit traversal: EIGHT LANES PER RAY.  A node of the 8-wide tree (bvh.h) is 8 children x 32 B; lane j of
 // a ray's octet loads child j (the octet reads the node's 256 contiguous bytes), tests its box, and the octet's hit
@@ -490,16 +548,13 @@ struct RasterCam {
 constexpr float kRasterGuard = 0.25f;
 
 // kWide: the lists are [slot][ray] (capacity max_hits = the wide capacity), for select_nearest_kernel's coalesced reads.
+// One triangle against the pixels of its screen box, lane ``sub`` of kRasterLanes (the body of both raster kernels).
 template <int kRasterLanes, bool kWide>
-__global__ __launch_bounds__(256) void raster_kernel(const float4 *__restrict__ tris, int64_t n_tri, RasterCam cam,
-                                                     const float *__restrict__ rays_o, const float *__restrict__ rays_d,
-                                                     int max_hits, int32_t *__restrict__ hit_tri, float *__restrict__ hit_t,
-                                                     int32_t *__restrict__ hit_count, int32_t *__restrict__ overflow)
+__device__ __forceinline__ void raster_triangle(const float4 *__restrict__ tris, int64_t tri_i, int sub, const RasterCam &cam,
+                                                const float *__restrict__ rays_o, const float *__restrict__ rays_d,
+                                                int max_hits, int32_t *__restrict__ hit_tri, float *__restrict__ hit_t,
+                                                int32_t *__restrict__ hit_count, int32_t *__restrict__ overflow)
 {
-    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t tri_i = gid / kRasterLanes;
-    const int sub = (int)(gid % kRasterLanes);
-    if (tri_i >= n_tri) return;
     const float4 a = tris[tri_i * 3 + 0], b = tris[tri_i * 3 + 1], c = tris[tri_i * 3 + 2];
     const int id = __float_as_int(a.w);
     // conservative screen box of the triangle (projection of a convex set is inside the box of its vertices)
@@ -581,6 +636,109 @@ __global__ __launch_bounds__(256) void raster_kernel(const float4 *__restrict__ 
         } else {
             atomicAdd(overflow, 1);      // more than max_hits candidates: the caller re-runs the exact K-nearest BVH path
         }
+    }
+}
+
+template <int kRasterLanes, bool kWide>
+__global__ __launch_bounds__(256) void raster_kernel(const float4 *__restrict__ tris, int64_t n_tri, RasterCam cam,
+                                                     const float *__restrict__ rays_o, const float *__restrict__ rays_d,
+                                                     int max_hits, int32_t *__restrict__ hit_tri, float *__restrict__ hit_t,
+                                                     int32_t *__restrict__ hit_count, int32_t *__restrict__ overflow)
+{
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t tri_i = gid / kRasterLanes;
+    const int sub = (int)(gid % kRasterLanes);
+    if (tri_i >= n_tri) return;
+    raster_triangle<kRasterLanes, kWide>(tris, tri_i, sub, cam, rays_o, rays_d, max_hits, hit_tri, hit_t, hit_count, overflow);
+}
+
+// ---- triangle culling for cameras that see a PART of the scene (the row bands of parallel.ShardedFrameRenderer: every
+// rank used to project all F triangles for its eighth of the rows).  The triangles are stored in BVH leaf order, so a
+// chunk of kCullChunk consecutive ones is a compact piece of surface; chunk_boxes_kernel (once per build / refit) keeps
+// its bounding box, cull_chunks_kernel (per frame, one lane per chunk) projects the box's corners with the triangle
+// projection above and drops the chunk when its screen box misses the image by more than the guard band -- the same
+// conservative reject raster_triangle applies per triangle, so no hit can be lost -- and raster_culled_kernel walks the
+// compacted list with a resident grid.  The order in which hits arrive at a pixel's list changes; the lists are sorted
+// afterwards (and were never in a defined order).
+constexpr int kCullChunk = 64;
+
+__global__ __launch_bounds__(256) void chunk_boxes_kernel(const float4 *__restrict__ tris, int64_t n_tri, int n_chunks,
+                                                          float4 *__restrict__ boxes)
+{
+    const int chunk = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6), lane = threadIdx.x & 63;
+    if (chunk >= n_chunks) return;
+    const int64_t t = (int64_t)chunk * kCullChunk + lane;
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    if (t < n_tri) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float4 v = tris[t * 3 + k];
+            lo[0] = fminf(lo[0], v.x); lo[1] = fminf(lo[1], v.y); lo[2] = fminf(lo[2], v.z);
+            hi[0] = fmaxf(hi[0], v.x); hi[1] = fmaxf(hi[1], v.y); hi[2] = fmaxf(hi[2], v.z);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            lo[k] = fminf(lo[k], __shfl_xor(lo[k], off, 64));
+            hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], off, 64));
+        }
+    }
+    if (lane == 0) {
+        boxes[chunk * 2 + 0] = make_float4(lo[0], lo[1], lo[2], 0.0f);
+        boxes[chunk * 2 + 1] = make_float4(hi[0], hi[1], hi[2], 0.0f);
+    }
+}
+
+// counters[2]: this call appends to counters[parity] and zeroes counters[parity ^ 1] for the next call on the handle
+// (stream order: the previous call's raster kernel, which read it, is done) -- no memset launch per frame.
+__global__ void cull_chunks_kernel(const float4 *__restrict__ boxes, int n_chunks, RasterCam cam, int32_t *__restrict__ visible,
+                                   int32_t *__restrict__ counters, int parity)
+{
+    const int chunk = blockIdx.x * blockDim.x + threadIdx.x;
+    if (chunk == 0) counters[parity ^ 1] = 0;
+    if (chunk >= n_chunks) return;
+    const float4 lo = boxes[chunk * 2], hi = boxes[chunk * 2 + 1];
+    if (!(lo.x <= hi.x)) return;                                  // empty chunk
+    float minx = INFINITY, maxx = -INFINITY, miny = INFINITY, maxy = -INFINITY;
+    bool keep = false;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const float dx = ((k & 1) ? hi.x : lo.x) - cam.cx, dy = ((k & 2) ? hi.y : lo.y) - cam.cy, dz = ((k & 4) ? hi.z : lo.z) - cam.cz;
+        const float xc = cam.r00 * dx + cam.r10 * dy + cam.r20 * dz;
+        const float yc = cam.r01 * dx + cam.r11 * dy + cam.r21 * dz;
+        const float zc = cam.r02 * dx + cam.r12 * dy + cam.r22 * dz;
+        const float zv = -zc;
+        if (!(zv > 1e-4f)) { keep = true; continue; }             // a corner at or behind the camera plane: no finite box
+        const float sx = cam.fx * (xc / zv) + cam.px0, sy = -cam.fy * (yc / zv) + cam.py0;
+        minx = fminf(minx, sx); maxx = fmaxf(maxx, sx);
+        miny = fminf(miny, sy); maxy = fmaxf(maxy, sy);
+    }
+    // the convex hull of the projected corners contains every projected triangle of the chunk; one extra pixel of margin
+    // on top of the per-triangle guard band covers the rounding of these eight projections
+    const float g = kRasterGuard + 1.0f;
+    if (!keep)
+        keep = (maxx + g >= 0.0f) && (maxy + g >= 0.0f) && (minx - g <= (float)(cam.w - 1)) && (miny - g <= (float)(cam.h - 1));
+    if (keep) visible[atomicAdd(&counters[parity], 1)] = chunk;
+}
+
+template <int kRasterLanes, bool kWide>
+__global__ __launch_bounds__(256) void raster_culled_kernel(const float4 *__restrict__ tris, int64_t n_tri, RasterCam cam,
+                                                            const float *__restrict__ rays_o, const float *__restrict__ rays_d,
+                                                            int max_hits, int32_t *__restrict__ hit_tri, float *__restrict__ hit_t,
+                                                            int32_t *__restrict__ hit_count, int32_t *__restrict__ overflow,
+                                                            const int32_t *__restrict__ visible, const int32_t *__restrict__ n_visible)
+{
+    constexpr int kTrisPerBlock = 256 / kRasterLanes;
+    constexpr int kBlocksPerChunk = kCullChunk / kTrisPerBlock;       // 1 / 2 / 4 for 4 / 8 / 16 lanes per triangle
+    const int n_items = *n_visible * kBlocksPerChunk;
+    const int sub = threadIdx.x % kRasterLanes;
+    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {  // workgroup-uniform
+        const int chunk = visible[item / kBlocksPerChunk];
+        const int64_t tri_i = (int64_t)chunk * kCullChunk + (item % kBlocksPerChunk) * kTrisPerBlock + threadIdx.x / kRasterLanes;
+        if (tri_i < n_tri)
+            raster_triangle<kRasterLanes, kWide>(tris, tri_i, sub, cam, rays_o, rays_d, max_hits, hit_tri, hit_t, hit_count, overflow);
     }
 }
 
@@ -718,13 +876,17 @@ __global__ __launch_bounds__(kFilterRays) void filter_hits_kernel(int64_t n_rays
         if (cnt > K) cnt = K;
         float *row_t = s_t + tid * Kp;
         int32_t *row_i = s_tri + tid * Kp;
-        for (int i = 1; i < cnt; ++i) {
-            const float t = row_t[i];
-            const int id = row_i[i];
-            int j = i - 1;
-            while (j >= 0 && hit_less(t, id, row_t[j], row_i[j])) { row_t[j + 1] = row_t[j]; row_i[j + 1] = row_i[j]; --j; }
-            row_t[j + 1] = t;
-            row_i[j + 1] = id;
+        if (K <= 32) {
+            if (cnt > 1) sort_row_32<true>(row_t, row_i, cnt);
+        } else {
+            for (int i = 1; i < cnt; ++i) {
+                const float t = row_t[i];
+                const int id = row_i[i];
+                int j = i - 1;
+                while (j >= 0 && hit_less(t, id, row_t[j], row_i[j])) { row_t[j + 1] = row_t[j]; row_i[j + 1] = row_i[j]; --j; }
+                row_t[j + 1] = t;
+                row_i[j + 1] = id;
+            }
         }
         if (min_sep > 0.0f && cnt > 1) {
             int kept = 1;
@@ -799,13 +961,17 @@ __global__ __launch_bounds__(kPackRays) void pack_samples_kernel(
         if (cnt > K) cnt = K;
         float *row_t = s_t + tid * Kp;
         int32_t *row_i = s_tri + tid * Kp;
-        for (int i = 1; i < cnt; ++i) {                       // (t, tri) ascending
-            const float t = row_t[i];
-            const int id = row_i[i];
-            int j = i - 1;
-            while (j >= 0 && hit_less(t, id, row_t[j], row_i[j])) { row_t[j + 1] = row_t[j]; row_i[j + 1] = row_i[j]; --j; }
-            row_t[j + 1] = t;
-            row_i[j + 1] = id;
+        if (K <= 32) {                                        // (t, tri) ascending, through registers
+            if (cnt > 1) sort_row_32<true>(row_t, row_i, cnt);
+        } else {
+            for (int i = 1; i < cnt; ++i) {
+                const float t = row_t[i];
+                const int id = row_i[i];
+                int j = i - 1;
+                while (j >= 0 && hit_less(t, id, row_t[j], row_i[j])) { row_t[j + 1] = row_t[j]; row_i[j + 1] = row_i[j]; --j; }
+                row_t[j + 1] = t;
+                row_i[j + 1] = id;
+            }
         }
         if (keep_mask) {                                      // the re-origin rule, decided by qf_bvh_repair_overflow
             const uint64_t mask = keep_mask[ray];
@@ -953,17 +1119,21 @@ __global__ __launch_bounds__(64) void pack_tiles_kernel(
     float dn[3] = {0.0f, 0.0f, 0.0f};
     int n_dropped = 0;
     if (inside) {
-        for (int i = 1; i < cnt; ++i) {                       // t (or (t, tri)) ascending
-            const float t = row_t[i];
-            const int id = kTri ? row_i[i] : 0;
-            int j = i - 1;
-            while (j >= 0 && (kTri ? hit_less(t, id, row_t[j], row_i[j]) : t < row_t[j])) {
-                row_t[j + 1] = row_t[j];
-                if (kTri) row_i[j + 1] = row_i[j];
-                --j;
+        if (K <= 32) {                                        // t (or (t, tri)) ascending, through registers
+            if (cnt > 1) sort_row_32<kTri>(row_t, row_i, cnt);
+        } else {
+            for (int i = 1; i < cnt; ++i) {
+                const float t = row_t[i];
+                const int id = kTri ? row_i[i] : 0;
+                int j = i - 1;
+                while (j >= 0 && (kTri ? hit_less(t, id, row_t[j], row_i[j]) : t < row_t[j])) {
+                    row_t[j + 1] = row_t[j];
+                    if (kTri) row_i[j + 1] = row_i[j];
+                    --j;
+                }
+                row_t[j + 1] = t;
+                if (kTri) row_i[j + 1] = id;
             }
-            row_t[j + 1] = t;
-            if (kTri) row_i[j + 1] = id;
         }
         if (keep_mask) {                                      // the re-origin rule, decided by qf_bvh_repair_overflow
             const uint64_t mask = keep_mask[ray];
@@ -1391,8 +1561,10 @@ __global__ __launch_bounds__(256) void texture_shade_packed_kernel(const uint8_t
                                                                    float *__restrict__ rgb, float *__restrict__ sigma,
                                                                    const TexelRecord *__restrict__ tri_records,
                                                                    const float *__restrict__ points,
-                                                                   const TriT *__restrict__ index_tri)
+                                                                   const TriT *__restrict__ index_tri,
+                                                                   const int64_t *__restrict__ n_dev)
 {
+    if (n_dev) { const int64_t nd = *n_dev; n = nd < n ? (nd > 0 ? nd : 0) : n; }    // device-side count (render-only frame)
     __shared__ float s_sigma[256], s_col[256], s_caz[256], s_saz[256], s_sel[256], s_cel[256], s_lam[256];
     {
         const int c = threadIdx.x;
@@ -1679,7 +1851,8 @@ extern "C" int qf_pack_tiles(const float *rays_o, const float *rays_d, int32_t w
                              const int32_t *hit_tri, const float *hit_t, const int32_t *hit_count, const int64_t *tile_base,
                              const int64_t *total, float *xyz_c, float *dirs_c, float *depth_c, int32_t *tri_c,
                              const uint64_t *keep_mask, const int32_t *raw_count, float min_separation,
-                             int32_t *final_count, int32_t *dropped, int64_t *host_out, void *stream)
+                             int32_t *final_count, int32_t *dropped, int64_t *host_out, int32_t dropped_is_zero,
+                             void *stream)
 {
     if ((keep_mask == nullptr) != (raw_count == nullptr)) return QF_ERR_INVALID_ARGUMENT;
     if (width < 1 || height < 1 || max_hits < 1 || max_hits > kMaxHits) return QF_ERR_INVALID_ARGUMENT;
@@ -1690,7 +1863,7 @@ extern "C" int qf_pack_tiles(const float *rays_o, const float *rays_d, int32_t w
     if (rule_here && (!final_count || !dropped)) return QF_ERR_INVALID_ARGUMENT;     // the counts change: they must go somewhere
     if (host_out && !dropped) return QF_ERR_INVALID_ARGUMENT;
     hipStream_t st = qf_stream(stream);
-    if (dropped && !host_out) QF_HIP_TRY(hipMemsetAsync(dropped, 0, sizeof(int32_t), st));
+    if (dropped && !host_out && !dropped_is_zero) QF_HIP_TRY(hipMemsetAsync(dropped, 0, sizeof(int32_t), st));
     const int tiles_x = (width + 7) / 8, tiles_y = (height + 7) / 8;
     const float sep = rule_here ? min_separation : 0.0f;
     if (tri_c) {
@@ -1813,14 +1986,14 @@ extern "C" int qf_texture_shade_packed(const uint8_t *records, int32_t texture_s
     if (!texel || !dirs || !rgb || !sigma) return QF_ERR_INVALID_ARGUMENT;
     QF_SIMPLE_LAUNCH((texture_shade_packed_kernel<false, int64_t>), n, records, (int)texture_size, (int)n_lobes,
                      (int)sigmoid_codec, lambda_thres, texel, dirs, n, rgb, sigma, (const TexelRecord *)nullptr,
-                     (const float *)nullptr, (const int64_t *)nullptr);
+                     (const float *)nullptr, (const int64_t *)nullptr, (const int64_t *)nullptr);
     return QF_OK;
 }
 
 extern "C" int qf_texture_shade_points(const uint8_t *records, int32_t texture_size, int32_t n_lobes, int32_t sigmoid_codec,
                                        float lambda_thres, const void *triangle_records, const float *points,
                                        const int64_t *index_tri, const int32_t *index_tri32, const float *dirs, int64_t n,
-                                       float *rgb, float *sigma, void *stream)
+                                       const int64_t *n_device, float *rgb, float *sigma, void *stream)
 {
     if (!records || !triangle_records || texture_size < 1 || n < 0) return QF_ERR_INVALID_ARGUMENT;
     if (n_lobes < 1 || n_lobes > QF_MAX_LOBES) return QF_ERR_UNSUPPORTED;
@@ -1830,18 +2003,18 @@ extern "C" int qf_texture_shade_points(const uint8_t *records, int32_t texture_s
     if (index_tri32) {
         QF_SIMPLE_LAUNCH((texture_shade_packed_kernel<true, int32_t>), n, records, (int)texture_size, (int)n_lobes,
                          (int)sigmoid_codec, lambda_thres, (const int64_t *)nullptr, dirs, n, rgb, sigma, tr, points,
-                         index_tri32);
+                         index_tri32, n_device);
     } else {
         QF_SIMPLE_LAUNCH((texture_shade_packed_kernel<true, int64_t>), n, records, (int)texture_size, (int)n_lobes,
                          (int)sigmoid_codec, lambda_thres, (const int64_t *)nullptr, dirs, n, rgb, sigma, tr, points,
-                         index_tri);
+                         index_tri, n_device);
     }
     return QF_OK;
 }
 
-static int raster_launch(const qf_bvh *bvh, const qf_camera *cam, const float *rays_o, const float *rays_d, int64_t n_rays,
+static int raster_launch(qf_bvh *bvh, const qf_camera *cam, const float *rays_o, const float *rays_d, int64_t n_rays,
                          int capacity, bool wide, int32_t *hit_tri, float *hit_t, int32_t *hit_count, int32_t *overflow,
-                         hipStream_t st)
+                         bool cull, hipStream_t st)
 {
     if (overflow == hit_count + n_rays) {    // the caller put the counter right behind the counts: one fill launch
         QF_HIP_TRY(hipMemsetAsync(hit_count, 0, (size_t)(n_rays + 1) * sizeof(int32_t), st));
@@ -1867,6 +2040,54 @@ static int raster_launch(const qf_bvh *bvh, const qf_camera *cam, const float *r
         const int64_t threads = bvh->n_tri * lanes;
         const int64_t blocks = qf_div_up(threads, 256);
         if (blocks > 0x7fffffff) return QF_ERR_UNSUPPORTED;
+        if (cull) {
+            // chunk boxes (once per build / refit), the visible-chunk list of this camera, then a resident grid over it
+            const int64_t n_chunks = qf_div_up(bvh->n_tri, kCullChunk);
+            if (n_chunks > 0x3fffffff) return QF_ERR_UNSUPPORTED;
+            if (!bvh->d_chunk_box) {
+                QF_HIP_TRY(hipMalloc((void **)&bvh->d_chunk_box, (size_t)n_chunks * 2 * sizeof(float4)));
+                QF_HIP_TRY(hipMalloc((void **)&bvh->d_visible, (size_t)(n_chunks + 2) * sizeof(int32_t)));
+                QF_HIP_TRY(hipMemsetAsync(bvh->d_visible, 0, 2 * sizeof(int32_t), st));        // the two counters
+                bvh->chunk_dirty = true;
+                bvh->cull_parity = 0;
+            }
+            const float4 *tris4 = reinterpret_cast<const float4 *>(bvh->d_tris);
+            float4 *boxes = reinterpret_cast<float4 *>(bvh->d_chunk_box);
+            if (bvh->chunk_dirty) {
+                hipLaunchKernelGGL(chunk_boxes_kernel, dim3((unsigned)qf_div_up(n_chunks * 64, 256)), dim3(256), 0, st, tris4,
+                                   bvh->n_tri, (int)n_chunks, boxes);
+                QF_LAUNCH_CHECK();
+                bvh->chunk_dirty = false;
+            }
+            int32_t *counters = bvh->d_visible, *visible = bvh->d_visible + 2;
+            const int parity = bvh->cull_parity;
+            bvh->cull_parity ^= 1;
+            hipLaunchKernelGGL(cull_chunks_kernel, dim3((unsigned)qf_div_up(n_chunks, 256)), dim3(256), 0, st, boxes,
+                               (int)n_chunks, rc, visible, counters, parity);
+            QF_LAUNCH_CHECK();
+            const int64_t items = n_chunks * (kCullChunk * lanes / 256);
+            const int64_t cap = (int64_t)qf_cu_count_cached() * 8;
+            const unsigned grid = (unsigned)(items < cap ? items : cap);
+#define QF_RASTER_CULLED(L, WIDE)                                                                                      \
+    hipLaunchKernelGGL((raster_culled_kernel<L, WIDE>), dim3(grid), dim3(256), 0, st, tris4, bvh->n_tri, rc, rays_o,  \
+                       rays_d, capacity, hit_tri, hit_t, hit_count, overflow, visible, counters + parity)
+            if (wide) {
+                switch (lanes) {
+                case 16: QF_RASTER_CULLED(16, true); break;
+                case 8: QF_RASTER_CULLED(8, true); break;
+                default: QF_RASTER_CULLED(4, true); break;
+                }
+            } else {
+                switch (lanes) {
+                case 16: QF_RASTER_CULLED(16, false); break;
+                case 8: QF_RASTER_CULLED(8, false); break;
+                default: QF_RASTER_CULLED(4, false); break;
+                }
+            }
+#undef QF_RASTER_CULLED
+            QF_LAUNCH_CHECK();
+            return QF_OK;
+        }
 #define QF_RASTER_LAUNCH(L, WIDE)                                                                                     \
     hipLaunchKernelGGL((raster_kernel<L, WIDE>), dim3((unsigned)blocks), dim3(256), 0, st,                           \
                        reinterpret_cast<const float4 *>(bvh->d_tris), bvh->n_tri, rc, rays_o, rays_d, capacity,      \
@@ -1897,30 +2118,32 @@ static bool raster_args_ok(const qf_bvh *bvh, const qf_camera *cam, int64_t n_ra
     return cam->fx > 0.0f && cam->fy > 0.0f;
 }
 
-extern "C" int qf_raster_intersect(const qf_bvh *bvh, const qf_camera *cam, const float *rays_o, const float *rays_d,
+extern "C" int qf_raster_intersect(qf_bvh *bvh, const qf_camera *cam, const float *rays_o, const float *rays_d,
                                    int64_t n_rays, int32_t max_hits, int32_t *hit_tri, float *hit_t, int32_t *hit_count,
-                                   int32_t *overflow, int32_t sort_lists, void *stream)
+                                   int32_t *overflow, int32_t sort_lists, int32_t cull_chunks, void *stream)
 {
     if (!raster_args_ok(bvh, cam, n_rays, max_hits)) return QF_ERR_INVALID_ARGUMENT;
     if (!rays_o || !rays_d || !hit_tri || !hit_t || !hit_count || !overflow) return QF_ERR_INVALID_ARGUMENT;
     hipStream_t st = qf_stream(stream);
-    const int rc = raster_launch(bvh, cam, rays_o, rays_d, n_rays, (int)max_hits, false, hit_tri, hit_t, hit_count, overflow, st);
+    const int rc = raster_launch(bvh, cam, rays_o, rays_d, n_rays, (int)max_hits, false, hit_tri, hit_t, hit_count, overflow,
+                                 cull_chunks != 0, st);
     if (rc != QF_OK) return rc;
     if (sort_lists && n_rays > 0) return filter_launch(n_rays, max_hits, bvh->min_sep, hit_tri, hit_t, hit_count, st);
     return QF_OK;
 }
 
-extern "C" int qf_raster_intersect_wide(const qf_bvh *bvh, const qf_camera *cam, const float *rays_o, const float *rays_d,
+extern "C" int qf_raster_intersect_wide(qf_bvh *bvh, const qf_camera *cam, const float *rays_o, const float *rays_d,
                                         int64_t n_rays, int32_t max_hits, int32_t wide_hits, int32_t *wide_tri,
                                         float *wide_t, int32_t *hit_tri, float *hit_t, int32_t *hit_count,
-                                        int32_t *overflow, void *stream)
+                                        int32_t *overflow, int32_t cull_chunks, void *stream)
 {
     if (!raster_args_ok(bvh, cam, n_rays, max_hits)) return QF_ERR_INVALID_ARGUMENT;
     if (wide_hits < max_hits || wide_hits > 4096) return QF_ERR_INVALID_ARGUMENT;
     if (!rays_o || !rays_d || !wide_tri || !wide_t || !hit_tri || !hit_t || !hit_count || !overflow)
         return QF_ERR_INVALID_ARGUMENT;
     hipStream_t st = qf_stream(stream);
-    const int rc = raster_launch(bvh, cam, rays_o, rays_d, n_rays, (int)wide_hits, true, wide_tri, wide_t, hit_count, overflow, st);
+    const int rc = raster_launch(bvh, cam, rays_o, rays_d, n_rays, (int)wide_hits, true, wide_tri, wide_t, hit_count, overflow,
+                                 cull_chunks != 0, st);
     if (rc != QF_OK) return rc;
     if (n_rays == 0) return QF_OK;
     const size_t lds = (size_t)select_capacity(max_hits, wide_hits, bvh->min_sep) * kSelectBlock * 2 * sizeof(float);

@@ -39,6 +39,7 @@ struct FieldArgs {
     const float *xyz;
     const float *dirs;
     int64_t n;
+    const int64_t *n_dev;  // optional: the point count lives in device memory (min(*n_dev, n) points are processed)
     float *rgb;
     float *sigma;
     float *geo;
@@ -152,7 +153,11 @@ __global__ __launch_bounds__(kBlock, 4) void field_kernel(const FieldArgs a)
     // Workgroups are dealt round-robin to the 8 XCDs, each with its own L2.  Give every XCD one CONTIGUOUS eighth
     // of the (spatially coherent) processing order instead of every eighth chunk of it: an L2 then only sees the
     // table rows of its own slab of the scene, which is what lets the mid-resolution levels stay resident.
-    const int64_t n_groups = (a.n + 15) >> 4;
+    // a render-only frame's sample count is data dependent and stays on the device (qf_tile_offsets' total): no host
+    // wait between the tile pack and this kernel; a.n is then the capacity of the arrays
+    int64_t n_pts = a.n;
+    if (a.n_dev) { const int64_t nd = *a.n_dev; n_pts = nd < a.n ? (nd > 0 ? nd : 0) : a.n; }
+    const int64_t n_groups = (n_pts + 15) >> 4;
     int64_t grp_begin, grp_end, wave_stride;
     if ((gridDim.x & 7) == 0) {
         const int64_t per_xcd = (n_groups + 7) >> 3;
@@ -168,8 +173,8 @@ __global__ __launch_bounds__(kBlock, 4) void field_kernel(const FieldArgs a)
 
     for (int64_t grp = grp_begin; grp < grp_end; grp += wave_stride) {
         const int64_t pt_raw = grp * 16 + p;
-        const bool valid = pt_raw < a.n;
-        int64_t pt = valid ? pt_raw : a.n - 1;
+        const bool valid = pt_raw < n_pts;
+        int64_t pt = valid ? pt_raw : n_pts - 1;
         if (a.order) pt = a.order[pt];   // processing permutation (spatially coherent groups); results unchanged
 
         const float X = a.xyz[pt * 3 + 0], Y = a.xyz[pt * 3 + 1], Z = a.xyz[pt * 3 + 2];
@@ -459,6 +464,7 @@ struct DeformArgs {
     const float *xyz;
     const int32_t *order;
     int64_t n;
+    const int64_t *n_dev;   // see FieldArgs
     float *out;
     float *enc_out;     // optional [n,32], see FieldArgs
 };
@@ -503,7 +509,11 @@ __global__ __launch_bounds__(kBlock, 4) void deform_kernel(const DeformArgs a)
     __syncthreads();
 
     // one contiguous eighth of the processing order per XCD (see field_kernel)
-    const int64_t n_groups = (a.n + 15) >> 4;
+    // a render-only frame's sample count is data dependent and stays on the device (qf_tile_offsets' total): no host
+    // wait between the tile pack and this kernel; a.n is then the capacity of the arrays
+    int64_t n_pts = a.n;
+    if (a.n_dev) { const int64_t nd = *a.n_dev; n_pts = nd < a.n ? (nd > 0 ? nd : 0) : a.n; }
+    const int64_t n_groups = (n_pts + 15) >> 4;
     int64_t grp_begin, grp_end, wave_stride;
     if ((gridDim.x & 7) == 0) {
         const int64_t per_xcd = (n_groups + 7) >> 3;
@@ -518,8 +528,8 @@ __global__ __launch_bounds__(kBlock, 4) void deform_kernel(const DeformArgs a)
     }
     for (int64_t grp = grp_begin; grp < grp_end; grp += wave_stride) {
         const int64_t pt_raw = grp * 16 + p;
-        const bool valid = pt_raw < a.n;
-        int64_t pt = valid ? pt_raw : a.n - 1;
+        const bool valid = pt_raw < n_pts;
+        int64_t pt = valid ? pt_raw : n_pts - 1;
         if (a.order) pt = a.order[pt];
         // (x - (-s)) / (s - (-s)), field.py:195
         const float x01 = (a.xyz[pt * 3 + 0] + a.scale) / (a.scale + a.scale);
@@ -625,8 +635,8 @@ extern "C" int qf_grid_encode(const qf_grid_desc *desc, const float *table, cons
 
 extern "C" int qf_field_forward(const qf_field_desc *desc, const float *table, const float *base_w,
                                 const float *head_ngp_w, const qf_sg_head *head_sg, const float *xyz,
-                                const float *dirs, int64_t n, const int32_t *order, float *rgb, float *sigma,
-                                float *geo, float *features, float *enc_out, void *stream)
+                                const float *dirs, int64_t n, const int64_t *n_device, const int32_t *order, float *rgb,
+                                float *sigma, float *geo, float *features, float *enc_out, void *stream)
 {
     if (!desc || !table || !base_w || n < 0 || n > 0x7fffffff) return QF_ERR_INVALID_ARGUMENT;
     FieldArgs a = {};
@@ -643,6 +653,7 @@ extern "C" int qf_field_forward(const qf_field_desc *desc, const float *table, c
     a.xyz = xyz;
     a.dirs = dirs;
     a.n = n;
+    a.n_dev = n_device;
     a.rgb = rgb;
     a.sigma = sigma;
     a.geo = geo;
@@ -695,7 +706,8 @@ extern "C" int qf_sg_features_to_rgb(const float *features, int64_t feat_stride,
 extern "C" int qf_deform_field_forward(const qf_grid_desc *grid, const float *table, float scale, int32_t hidden,
                                        const float *w1, const float *b1, const float *w2, const float *b2,
                                        const float *wout, const float *bout, const float *xyz, int64_t n,
-                                       const int32_t *order, float *out, float *enc_out, void *stream)
+                                       const int64_t *n_device, const int32_t *order, float *out, float *enc_out,
+                                       void *stream)
 {
     if (!grid || !table || n < 0 || !(scale > 0.0f)) return QF_ERR_INVALID_ARGUMENT;
     if (hidden != 32) return QF_ERR_UNSUPPORTED;
@@ -711,6 +723,7 @@ extern "C" int qf_deform_field_forward(const qf_grid_desc *grid, const float *ta
     a.xyz = xyz;
     a.order = order;
     a.n = n;
+    a.n_dev = n_device;
     a.out = out;
     a.enc_out = enc_out;
     const size_t lds_bytes = (size_t)(kDeformMfma * 64 + 64 + 8 * QF_MAX_LEVELS) * sizeof(float);

@@ -29,6 +29,7 @@ struct FieldArgsB {
     const float *xyz;
     const float *dirs;
     int64_t n;
+    const int64_t *n_dev;   // optional device-side point count, see FieldArgs (field_eval.hip)
     const int32_t *order;
     float *rgb;
     float *sigma;
@@ -132,7 +133,9 @@ __global__ __launch_bounds__(kBlockB, 4) void field_kernel_bf16(const FieldArgsB
     const uint4 *img_base = reinterpret_cast<const uint4 *>(ldsb);
 
     // one contiguous eighth of the processing order per XCD (see field_kernel in field_eval.hip)
-    const int64_t n_groups = (a.n + 15) >> 4;
+    int64_t n_pts = a.n;
+    if (a.n_dev) { const int64_t nd = *a.n_dev; n_pts = nd < a.n ? (nd > 0 ? nd : 0) : a.n; }
+    const int64_t n_groups = (n_pts + 15) >> 4;
     int64_t grp_begin, grp_end, wave_stride;
     if ((gridDim.x & 7) == 0) {
         const int64_t per_xcd = (n_groups + 7) >> 3;
@@ -147,8 +150,8 @@ __global__ __launch_bounds__(kBlockB, 4) void field_kernel_bf16(const FieldArgsB
     }
     for (int64_t grp = grp_begin; grp < grp_end; grp += wave_stride) {
         const int64_t pt_raw = grp * 16 + p;
-        const bool valid = pt_raw < a.n;
-        int64_t pt = valid ? pt_raw : a.n - 1;
+        const bool valid = pt_raw < n_pts;
+        int64_t pt = valid ? pt_raw : n_pts - 1;
         if (a.order) pt = a.order[pt];
         const float X = a.xyz[pt * 3 + 0], Y = a.xyz[pt * 3 + 1], Z = a.xyz[pt * 3 + 2];
         const float x01 = (X - a.aabb_lo[0]) / (a.aabb_hi[0] - a.aabb_lo[0]);
@@ -326,8 +329,8 @@ int launch_field_b(const FieldArgsB &a, hipStream_t st)
 
 extern "C" int qf_field_forward_bf16(const qf_field_desc *desc, const uint16_t *table, const uint16_t *base_w,
                                      const uint16_t *head_ngp_w, const qf_sg_head_bf16 *head_sg, const float *xyz,
-                                     const float *dirs, int64_t n, const int32_t *order, float *rgb, float *sigma,
-                                     float *geo, void *stream)
+                                     const float *dirs, int64_t n, const int64_t *n_device, const int32_t *order,
+                                     float *rgb, float *sigma, float *geo, void *stream)
 {
     if (!desc || !table || !base_w || n < 0 || n > 0x7fffffff) return QF_ERR_INVALID_ARGUMENT;
     FieldArgsB a = {};
@@ -343,6 +346,7 @@ extern "C" int qf_field_forward_bf16(const qf_field_desc *desc, const uint16_t *
     a.xyz = xyz;
     a.dirs = dirs;
     a.n = n;
+    a.n_dev = n_device;
     a.order = order;
     a.rgb = rgb;
     a.sigma = sigma;

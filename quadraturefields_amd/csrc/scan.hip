@@ -78,11 +78,10 @@ __global__ __launch_bounds__(kFoThreads) void frame_partials_kernel(const int32_
 }
 
 // one workgroup; every thread owns a CONTIGUOUS run of each array, so an array is scanned with one block scan
-__global__ __launch_bounds__(kFoThreads) void frame_scan_kernel(int64_t *partial, int n_blocks, int64_t *tile_total, int n_tiles,
-                                                                int64_t *grand_total, const int32_t *overflow_in,
-                                                                int64_t *host_out)
+__device__ __forceinline__ void frame_scan_body(int64_t *partial, int n_blocks, int64_t *tile_total, int n_tiles,
+                                                int64_t *grand_total, const int32_t *overflow_in, int64_t *host_out,
+                                                int64_t *s_wave)
 {
-    __shared__ int64_t s_wave[kFoThreads / 64];
     for (int pass = 0; pass < 2; ++pass) {
         int64_t *a = pass == 0 ? partial : tile_total;
         const int m = pass == 0 ? n_blocks : n_tiles;
@@ -109,6 +108,20 @@ __global__ __launch_bounds__(kFoThreads) void frame_scan_kernel(int64_t *partial
             }
         }
     }
+}
+
+// zero_word (or NULL): a device int32 this launch zeroes for a later kernel of the frame -- the dropped-hit counter of
+// qf_pack_tiles, which then needs neither a memset launch nor a publishing launch of its own.
+// (A "last workgroup does the tail" fusion of the two launches of qf_tile_offsets, and of the tile pack with its
+// publishing launch, was measured and dropped: one same-address ticket atomic per workgroup costs ~37 ns, i.e. 0.47 ms
+// for the 12 500 workgroups of an 800x800 frame.)
+__global__ __launch_bounds__(kFoThreads) void frame_scan_kernel(int64_t *partial, int n_blocks, int64_t *tile_total, int n_tiles,
+                                                                int64_t *grand_total, const int32_t *overflow_in,
+                                                                int64_t *host_out, int32_t *zero_word)
+{
+    __shared__ int64_t s_wave[kFoThreads / 64];
+    if (zero_word && threadIdx.x == 0) *zero_word = 0;
+    frame_scan_body(partial, n_blocks, tile_total, n_tiles, grand_total, overflow_in, host_out, s_wave);
 }
 
 __global__ __launch_bounds__(kFoThreads) void frame_ray_offsets_kernel(const int32_t *__restrict__ hit_count, int64_t n_rays,
@@ -158,7 +171,7 @@ extern "C" int qf_frame_offsets(const int32_t *hit_count, int64_t n_rays, int32_
         QF_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(frame_scan_kernel, dim3(1), dim3(kFoThreads), 0, st, partial, n_blocks, tile_base, n_tiles,
-                       ray_offset + n_rays, overflow_in, host_out);
+                       ray_offset + n_rays, overflow_in, host_out, (int32_t *)nullptr);
     QF_LAUNCH_CHECK();
     if (n_blocks > 0) {
         hipLaunchKernelGGL(frame_ray_offsets_kernel, dim3((unsigned)n_blocks), dim3(kFoThreads), 0, st, hit_count, n_rays,
@@ -172,7 +185,7 @@ extern "C" int qf_frame_offsets(const int32_t *hit_count, int64_t n_rays, int32_
 // no per-ray offsets -- the tile part of step 1 and a scan over the tile totals alone.
 extern "C" int qf_tile_offsets(const int32_t *hit_count, int32_t max_hits, int32_t width, int32_t height,
                                int64_t *tile_base, int64_t *total, const int32_t *overflow_in, int64_t *host_out,
-                               void *stream)
+                               int32_t *zero_word, void *stream)
 {
     if (max_hits < 1 || width < 1 || height < 1 || !hit_count || !tile_base || !total) return QF_ERR_INVALID_ARGUMENT;
     const int64_t n_rays = (int64_t)width * height;
@@ -184,7 +197,7 @@ extern "C" int qf_tile_offsets(const int32_t *hit_count, int32_t max_hits, int32
     hipLaunchKernelGGL(frame_partials_kernel, dim3((unsigned)tile_blocks), dim3(kFoThreads), 0, st, hit_count, n_rays, max_hits,
                        0, (int)width, (int)height, tiles_x, n_tiles, (int64_t *)nullptr, tile_base);
     hipLaunchKernelGGL(frame_scan_kernel, dim3(1), dim3(kFoThreads), 0, st, (int64_t *)nullptr, 0, tile_base, n_tiles, total,
-                       overflow_in, host_out);
+                       overflow_in, host_out, zero_word);
     QF_LAUNCH_CHECK();
     return QF_OK;
 }

@@ -95,7 +95,7 @@ class Field(nn.Module):
                                           activation=torch.nn.ReLU(), bias=bias, num_layers=2,
                                           hidden_dim=hidden_size, skip=[], bias_last=bias_last)
 
-    def density(self, x, order=None):
+    def density(self, x, order=None, n_device=None):
         """[N,3] in [-scale, scale] -> [N,1].  field.py:186-203, one fused launch.  ``order`` (extension): int32
         processing permutation (``RayIntersector.coherent_order``), cache locality only."""
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
@@ -106,13 +106,13 @@ class Field(nn.Module):
             x01 = (x.reshape(-1, 3) - self.xyz_min) / (self.xyz_max - self.xyz_min)
             h = self.xyz_encoder(x01 if self.back_prop else x01.detach())
             return self.decoder_field(torch.cat([x01, h], 1))
-        return self._density_fused(x, order)
+        return self._density_fused(x, order, n_device=n_device)
 
     #: Training route of ``density`` when only the parameters want gradients: True = fused HIP backward
     #: (``_DeformTrainFn``); the input-gradient / second-order route always goes through the hash-grid autograd Function.
     fused_backward = True
 
-    def _density_fused(self, x, order=None, enc_out=None):
+    def _density_fused(self, x, order=None, enc_out=None, n_device=None):
         x = _C.f32c(x.reshape(-1, 3))
         n = x.shape[0]
         out = torch.empty((n,), dtype=torch.float32, device=x.device)
@@ -121,17 +121,19 @@ class Field(nn.Module):
                                            d.layers[1].bias, d.lout.weight, d.lout.bias)]
         _C.check(_C.lib().qf_deform_field_forward(
             self.xyz_encoder.grid.desc, _C.ptr(self.xyz_encoder.params.detach()), float(self.scale), 32,
-            *[_C.ptr(t) for t in w], _C.ptr(x), n, _C.ptr(order, torch.int32) if order is not None and order.shape[0] == n else None,
+            *[_C.ptr(t) for t in w], _C.ptr(x), n, _C.ptr(n_device, torch.int64),
+            _C.ptr(order, torch.int32) if order is not None and order.shape[0] == n else None,
             _C.ptr(out), _C.ptr(enc_out), _C.stream()), "qf_deform_field_forward")
         return out[:, None]
 
-    def field(self, x, order=None):
-        return self.density(x, order)[:, 0:self.output_dim]
+    def field(self, x, order=None, n_device=None):
+        return self.density(x, order, n_device)[:, 0:self.output_dim]
 
-    def forward(self, x, return_grad=True, order=None):
-        """(field [N,1], field_grad [N,3] or None).  field.py:206-223."""
+    def forward(self, x, return_grad=True, order=None, n_device=None):
+        """(field [N,1], field_grad [N,3] or None).  field.py:206-223.  ``order`` / ``n_device`` (extensions, inference
+        only): see ``NGPRadianceField.forward``."""
         if not return_grad:
-            return self.field(x, order), None
+            return self.field(x, order, n_device), None
         if not x.requires_grad:
             x.requires_grad = True
         field = self.field(x)

@@ -44,6 +44,8 @@ def _on_device(fn):
 
     @functools.wraps(fn)
     def wrapped(self, *args, **kwargs):
+        if torch._C._cuda_getDevice() == self.device.index:      # already current: skip the context manager (~5 us a call)
+            return fn(self, *args, **kwargs)
         with torch.cuda.device(self.device):
             return fn(self, *args, **kwargs)
     return wrapped
@@ -135,6 +137,7 @@ class RayIntersector:
         self.last_layout = None          # (inverse, xyz, dirs) of the most recent image-shaped pack, in the coherent order
         self.last_frame = None           # what utils.composite_frame needs of that pack (depths in the coherent order, ...)
         self.last_image_shape = None     # (width, height) of the most recent image-shaped batch (see split_layout)
+        self._deferred_policy = None     # (event, pinned block, n_rays, k) of a frame packed without a host wait
         self._split_scratch = {}
         self._handle = ctypes.c_void_p()
         tri = np.ascontiguousarray(mesh.vertices.astype(np.float32)[mesh.faces].reshape(-1, 9))
@@ -265,7 +268,7 @@ class RayIntersector:
         overflow = torch.empty((1,), dtype=torch.int32, device=self.device)
         _C.check(_C.lib().qf_raster_intersect(self._handle, ctypes.byref(camera), _C.ptr(o), _C.ptr(d), n, k,
                                               _C.ptr(hit_tri), _C.ptr(hit_t), _C.ptr(hit_count), _C.ptr(overflow),
-                                              1 if sort_lists else 0, _C.stream()), "qf_raster_intersect")
+                                              1 if sort_lists else 0, 0, _C.stream()), "qf_raster_intersect")
         return hit_tri, hit_t, hit_count, overflow
 
     @_on_device
@@ -305,7 +308,7 @@ class RayIntersector:
         # frames in flight on different streams, or two consecutive frames of a front / back pipeline (``scratch_slot``
         # alternates: the next frame's offsets kernel must not overwrite the pinned block the host has not read yet),
         # do not share it
-        key = (torch.cuda.current_stream().cuda_stream, self.scratch_slot)
+        key = (_C.raw_stream(), self.scratch_slot)
         s = self._scratch.get(key)
         if s is None:
             host = torch.zeros((4,), dtype=torch.int64).pin_memory()
@@ -334,8 +337,10 @@ class RayIntersector:
         counts = torch.empty((n + 1,), dtype=torch.int32, device=self.device)
         hit_count, overflow = counts[:n], counts[n:]
         wide = max(int(self.raster_wide), 0)
+        # a camera that sees part of the scene (parallel.band_camera sets .cull): cull the triangles in chunks first
+        cull = 1 if getattr(camera, "cull", False) else 0
         if wide > k:
-            key = (n, wide, torch.cuda.current_stream().cuda_stream)
+            key = (n, wide, _C.raw_stream())
             lists = self._wide_scratch.get(key)
             if lists is None:
                 self._wide_scratch.clear()
@@ -343,12 +348,12 @@ class RayIntersector:
                                                    torch.empty((wide, n), dtype=torch.float32, device=self.device))
             _C.check(_C.lib().qf_raster_intersect_wide(self._handle, ctypes.byref(camera), _C.ptr(o), _C.ptr(d), n, k, wide,
                                                        _C.ptr(lists[0]), _C.ptr(lists[1]), _C.ptr(hit_tri), _C.ptr(hit_t),
-                                                       _C.ptr(hit_count), _C.ptr(overflow), _C.stream()),
+                                                       _C.ptr(hit_count), _C.ptr(overflow), cull, _C.stream()),
                      "qf_raster_intersect_wide")
         else:
             _C.check(_C.lib().qf_raster_intersect(self._handle, ctypes.byref(camera), _C.ptr(o), _C.ptr(d), n, k,
                                                   _C.ptr(hit_tri), _C.ptr(hit_t), _C.ptr(hit_count), _C.ptr(overflow),
-                                                  0, _C.stream()), "qf_raster_intersect")
+                                                  0, cull, _C.stream()), "qf_raster_intersect")
         # pixels that collected more than K candidates: exact K nearest through the BVH, those rays only, no host
         # round trip (afterwards every count is <= K).  With the reference's re-origin rule on, the same launch decides
         # it for every other ray as a keep-mask over its sorted list (the lists are not rewritten); the mask rides on
@@ -394,12 +399,14 @@ class RayIntersector:
 
     @_on_device
     def pack_hits_begin(self, o, d, k, hit_tri, hit_t, hit_count, overflow, width, lean=False, layout=True,
-                        want_tri=False):
+                        want_tri=False, publish=True):
         """Enqueue scan, readback, pack and ordering on the current stream; no host wait.  ``lean`` (image-shaped
         batches only): a caller that only renders reads the streamed copies in ``last_layout`` / ``last_frame``, so the
         tile kernel (``qf_pack_tiles``) writes just those and the six ray-major arrays come back as None.
         ``want_tri`` (lean frames): also the samples' triangle ids in that order (``last_frame.tri_c``; the baked-texture
-        render looks its texels up by triangle).  ``layout=False``: no processing order at all."""
+        render looks its texels up by triangle).  ``layout=False``: no processing order at all.  ``publish=False`` (lean
+        frames packed by ``pack_hits_device``): the tile pack's dropped-hit count stays in device memory -- no
+        publishing launch; ``frame_samples()`` copies it when asked."""
         n = o.shape[0]
         dev = self.device
         buf, temp, host, (ev, ev_flag), dropped = self._frame_scratch(n)
@@ -414,7 +421,7 @@ class RayIntersector:
         if bool(lean) and image:              # render-only frame: tile bases + total, no per-ray offsets
             _C.check(_C.lib().qf_tile_offsets(_C.ptr(hit_count), k, int(width), n // int(width), _C.ptr(tile_base),
                                               _C.ptr(buf[n:]), _C.ptr(overflow), ctypes.c_void_p(host.data_ptr()),
-                                              _C.stream()), "qf_tile_offsets")
+                                              _C.ptr(dropped), _C.stream()), "qf_tile_offsets")     # (zeroes ``dropped``)
         else:
             _C.check(_C.lib().qf_frame_offsets(_C.ptr(hit_count), n, k, int(width) if image else 0, n // width if image else 0,
                                                _C.ptr(buf), _C.ptr(tile_base), _C.ptr(temp), temp.numel(), _C.ptr(overflow),
@@ -436,7 +443,8 @@ class RayIntersector:
             dirs_c = torch.empty((cap, 3), dtype=torch.float32, device=dev)
             depth_c = torch.empty((cap,), dtype=torch.float32, device=dev)
             frame = SimpleNamespace(depth_c=depth_c, hit_count=hit_count, max_hits=int(k), tile_base=tile_base,
-                                    width=int(width), height=n // int(width), total=0, tri_c=None)
+                                    width=int(width), height=n // int(width), total=0, tri_c=None,
+                                    total_dev=buf[n:n + 1])      # the slot count, on the device (int64)
         if lean:
             # render-only frame: the tile kernel writes the coherent copies directly; no ray-major arrays, no order,
             # no inverse map exist for it (the six sample arrays come back as None).  It also applies the re-origin
@@ -451,9 +459,11 @@ class RayIntersector:
                                             _C.ptr(xyz_c), _C.ptr(dirs_c), _C.ptr(depth_c), _C.ptr(frame.tri_c),
                                             _C.ptr(keep[0]), _C.ptr(keep[1]),
                                             float(self.min_separation) if keep[0] is None else 0.0,
-                                            _C.ptr(final_count), _C.ptr(dropped), ctypes.c_void_p(host.data_ptr()),
-                                            _C.stream()), "qf_pack_tiles")
+                                            _C.ptr(final_count), _C.ptr(dropped),
+                                            ctypes.c_void_p(host.data_ptr()) if publish else None, 1, _C.stream()),
+                     "qf_pack_tiles")
             frame.hit_count = final_count
+            frame.dropped_dev = None if publish else dropped
             ev_flag.record()
         else:
             xyz = torch.empty((cap, 3), dtype=torch.float32, device=dev)
@@ -497,14 +507,7 @@ class RayIntersector:
                 ev_flag.synchronize()
                 if int(host[2]) != 0:
                     return self._repack_exact(pending)
-        if ovf:                                # already repaired on the device (qf_bvh_repair_overflow); policy only
-            self.repaired_frames += 1
-            if ovf > 0.05 * o.shape[0]:        # much of the image overflows (dense shells)
-                wide = min(self.RASTER_WIDE_FACTOR * k, self.RASTER_WIDE_MAX)
-                if self.raster_wide < wide and wide > k:
-                    self.raster_wide = wide    # from the next frame on: wide candidate lists + K-nearest selection
-                else:
-                    self.raster_overflowed()   # even the wide lists overflow: the camera-coherent pass is wasted
+        self._overflow_policy(ovf, o.shape[0], k)
         self.last_layout = self.last_frame = None
         if total == 0:
             return None, None
@@ -521,6 +524,48 @@ class RayIntersector:
             self.last_frame = frame
         return [None if t is None else t[:total] for t in arrays], (order[:total] if order is not None else None)
 
+    def _overflow_policy(self, ovf: int, n_rays: int, k: int) -> None:
+        """``ovf`` candidates beyond K in the camera-coherent pass of a frame (those rays were already repaired on the
+        device, qf_bvh_repair_overflow): steer the next frames' intersector."""
+        if ovf:
+            self.repaired_frames += 1
+            if ovf > 0.05 * n_rays:            # much of the image overflows (dense shells)
+                wide = min(self.RASTER_WIDE_FACTOR * k, self.RASTER_WIDE_MAX)
+                if self.raster_wide < wide and wide > k:
+                    self.raster_wide = wide    # from the next frame on: wide candidate lists + K-nearest selection
+                else:
+                    self.raster_overflowed()   # even the wide lists overflow: the camera-coherent pass is wasted
+
+    def _settle_deferred_policy(self) -> None:
+        """A frame packed by ``pack_hits_device`` never made the host wait for its 16-byte block; the overflow count in it
+        only steers policy, so it is read here, when the NEXT frame is about to be sampled (the event has long passed:
+        the block is written by the second launch of the frame it belongs to)."""
+        pend, self._deferred_policy = self._deferred_policy, None
+        if pend is not None:
+            ev, host, n_rays, k = pend
+            ev.synchronize()
+            self._overflow_policy(int(host[1]), n_rays, k)
+
+    def pack_hits_device(self, pending):
+        """Second half of a RENDER-ONLY frame (``pack_hits_begin(..., lean=True)``) WITHOUT the host wait: the sample
+        count stays on the device (``frame.total_dev``; every consumer takes it as ``n_device``), the coherent arrays
+        are handed on at their worst-case capacity (``n_rays * K`` slots) and the frame is a fixed sequence of launches
+        -- nothing between the rays and the pixels returns to the host.  Returns ``last_frame`` (``last_layout`` holds
+        the capacity-sized position / direction arrays).  ``frame_samples()`` still answers, by waiting then."""
+        o, d, k, width, lean, host, (ev, ev_flag), arrays, order, layout, _lists, frame = pending
+        if not lean[0] or frame is None or layout is None:
+            raise ValueError("pack_hits_device: a lean image-shaped pack is required")
+        self._rule_pending = None
+        self._deferred_policy = (ev, host, o.shape[0], k)
+        self.last_layout = layout                       # (None, xyz_c, dirs_c) at capacity
+        frame.total = int(frame.depth_c.shape[0])       # slots of the arrays = capacity; the live count is total_dev
+        frame.samples = None
+        frame.total_src = (ev, host)
+        frame.dropped_src = (ev_flag, host)
+        frame._keep = _lists                            # the hit lists stay referenced until their readers ran
+        self.last_frame = frame
+        return frame
+
     def frame_samples(self) -> int:
         """Quadrature points of the most recent image-shaped pack (``last_frame``): for a render-only frame the slots
         of the coherent arrays minus the hits its re-origin rule dropped."""
@@ -528,9 +573,21 @@ class RayIntersector:
         if f is None:
             return 0
         if f.samples is None:
-            ev_flag, host = f.dropped_src
-            ev_flag.synchronize()
-            f.samples = f.total - int(host[2])
+            total = f.total
+            src = getattr(f, "total_src", None)
+            if src is not None:                 # packed without a host wait: the count is read now
+                src[0].synchronize()
+                total = int(src[1][0])
+                f.total_src = None
+            if getattr(f, "dropped_dev", None) is not None:
+                # packed without the publishing launch: the counter is still the frame's until the next frame's tile
+                # offsets zero it, so this must be asked before the next frame is sampled on this stream
+                f.samples = total - int(f.dropped_dev.item())
+                f.dropped_dev = None
+            else:
+                ev_flag, host = f.dropped_src
+                ev_flag.synchronize()
+                f.samples = total - int(host[2])
             f.dropped_src = None
         return f.samples
 
@@ -578,6 +635,7 @@ class RayIntersector:
             return None
         if camera is not None:
             image_width = camera.width
+        self._settle_deferred_policy()
         if self.want_raster(camera):
             hit_tri, hit_t, hit_count, overflow = self._hits_raster_frame(o, d, k, camera)
         else:
@@ -586,6 +644,28 @@ class RayIntersector:
         data, self.last_order = self.pack_hits(o, d, k, hit_tri, hit_t, hit_count, overflow, int(image_width), lean,
                                                layout, defer_rule_check, want_tri)
         return data
+
+    @_on_device
+    def sample_frame_device(self, origins, vectors, max_hits: Optional[int] = None, camera=None, want_tri: bool = False):
+        """A render-only camera frame with NO host wait: intersection, tile offsets and tile pack are enqueued and the
+        frame comes back at once -- ``last_frame`` (``total_dev`` = the slot count on the device) and ``last_layout`` =
+        (None, xyz_c, dirs_c) at worst-case capacity.  See ``pack_hits_device``."""
+        if camera is None:
+            raise ValueError("sample_frame_device: the rays must be a camera's pixel grid")
+        k = self.max_hits if max_hits is None else int(max_hits)
+        o = _as_device_f32(origins, self.device).reshape(-1, 3)
+        d = _as_device_f32(vectors, self.device).reshape(-1, 3)
+        if o.shape[0] != camera.width * camera.height:
+            raise ValueError("sample_frame_device: origins / vectors must be the camera's full pixel grid")
+        self._settle_deferred_policy()
+        if self.want_raster(camera):
+            hit_tri, hit_t, hit_count, overflow = self._hits_raster_frame(o, d, k, camera)
+        else:
+            hit_tri, hit_t, hit_count = self._hits_bvh(o, d, k, camera.width)
+            overflow = None
+        self.last_order = None
+        return self.pack_hits_device(self.pack_hits_begin(o, d, k, hit_tri, hit_t, hit_count, overflow, int(camera.width),
+                                                          lean=True, layout=True, want_tri=want_tri, publish=False))
 
     @_on_device
     def coherent_layout(self, hit_count, ray_offset, total: int, width: int, tile_base=None, want_order=True):
@@ -621,7 +701,7 @@ class RayIntersector:
         if n == 0:
             empty = torch.empty((0,), dtype=torch.int32, device=self.device)
             return (empty if want_order else None), empty.clone(), torch.zeros((1,), dtype=torch.int32, device=self.device)
-        key = (n_rays, int(width), torch.cuda.current_stream().cuda_stream)
+        key = (n_rays, int(width), _C.raw_stream())
         sc = self._split_scratch.get(key)
         if sc is None:
             if len(self._split_scratch) > 4:

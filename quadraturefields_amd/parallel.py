@@ -12,10 +12,14 @@ contiguous ROW BANDS, one per rank:
 * every per-ray result depends on that ray alone (hits, samples, field values, the compositing sum in rank order),
   so the bands' pixels are bit-identical to the 1-rank frame whatever the cuts are (tested on the GPU);
 * the cuts are multiples of 8 rows (tile rows stay tile rows) and are balanced by a per-row cost profile taken from
-  the gathered alpha of an earlier frame (object rows cost ~25x background rows).  The profile is applied with a
-  fixed lag, so every rank cuts every frame identically without a collective;
-* the finished bands (rgb3 + alpha1 + depth1 = 20 B/ray) are exchanged with ONE ``all_gather_into_tensor`` per frame
-  of the bands padded to the tallest one.  At 800x800 that is 12.8 MB in total: latency-, not bandwidth-bound on xGMI.
+  the per-row SAMPLE COUNTS of an earlier frame, which the bands report in an extra padded row of the frame's own
+  collective (``COST_RAY`` per pixel + ``COST_SAMPLE`` per quadrature point; gathered alpha only stands in when a
+  renderer reports no counts).  The profile is applied with a fixed lag, so every rank cuts every frame identically
+  without a further collective;
+* the finished bands (rgb3 + alpha1 + depth1 = 20 B/ray) are exchanged with ONE collective per frame:
+  ``all_to_all_single`` with split sizes (every band arrives at its own length, in place: 12.8 MB on the wire at
+  800x800, latency- rather than bandwidth-bound on xGMI); the round-2 ``all_gather_into_tensor`` of bands padded to the
+  tallest one remains selectable (``GATHER_MODE``).
 
 The 8x8-tile round-robin sharding of round 1 (``shard_tiles`` ...) is kept for arbitrary (non-pinhole) ray sets.
 """
@@ -77,17 +81,33 @@ def band_camera(c2w, focal: float, width: int, height: int, y0: int, y1: int):
     cam = make_camera(c2w, focal, width, height)
     cam.cy = height / 2.0 - float(y0)
     cam.height = int(y1 - y0)
+    # the band sees a part of the scene: have the camera-coherent pass cull the triangles in chunks before it projects
+    # them (qf_raster_intersect cull_chunks), so that its set-up work shrinks with the band
+    cam.cull = (y1 - y0) < height
     return cam
 
 
+#: how the finished bands are exchanged.  "exact" (default): ``all_to_all_single`` with split sizes -- every rank sends
+#: its band (+ its per-row numbers) to every rank and receives each band at its own length straight into place in the
+#: frame: the bytes on the wire are the frame's own 20 B/ray, nothing is padded, nothing is concatenated afterwards.
+#: "padded": one ``all_gather_into_tensor`` of the bands padded to the tallest (round 2; with cost-balanced cuts of an
+#: 800-row frame over 8 ranks -- [224, 72, 56, 48, 48, 56, 72, 224] rows -- that moved 28.7 MB for a 12.8 MB frame).
+GATHER_MODE = "exact"
+
+
+def _meta_slots(rows: int, c: int) -> int:
+    """dim-0 entries of a [*, c] array that hold ``rows`` per-row numbers"""
+    return (rows + c - 1) // c
+
+
 def gather_bands(local: torch.Tensor, cuts: Sequence[int], width: int, rank: int, world_size: int,
-                 async_op: bool = False, meta: Optional[torch.Tensor] = None):
-    """local [rows_r * width, C] (this rank's band, row-major) -> the full frame [H * width, C] on every rank with
-    one ``all_gather_into_tensor`` of the bands padded to the tallest band.  ``async_op``: returns a zero-argument
-    callable instead; the collective runs on the backend's own stream (RCCL) beside whatever is launched next, and
-    calling the callable makes the current stream wait for it and assembles the frame.
+                 async_op: bool = False, meta: Optional[torch.Tensor] = None, mode: Optional[str] = None):
+    """local [rows_r * width, C] (this rank's band, row-major) -> the full frame [H * width, C] on every rank with ONE
+    collective (see ``GATHER_MODE``).  ``async_op``: returns a zero-argument callable instead; the collective runs on
+    the backend's own stream (RCCL) beside whatever is launched next, and calling the callable makes the current stream
+    wait for it and hands out the frame.
     ``meta`` (every rank or none): float32 [rows_r], one number per row of the band (the band's per-row sample counts);
-    it rides in a few extra padded rows of the same collective and comes back as [H]: the result is then
+    it rides behind the band in the same collective and comes back as [H]: the result is then
     ``(frame, meta_of_every_row)``."""
     rows = [cuts[r + 1] - cuts[r] for r in range(world_size)]
     if local.shape[0] != rows[rank] * width:
@@ -97,7 +117,38 @@ def gather_bands(local: torch.Tensor, cuts: Sequence[int], width: int, rank: int
     if world_size == 1:
         result = local if meta is None else (local, meta.to(torch.float32).reshape(-1))
         return (lambda: result) if async_op else result
+    mode = GATHER_MODE if mode is None else mode
     c = local.shape[1]
+    staged = local.is_cuda and dist.get_backend() == "gloo"     # rehearsal on one GPU: gloo moves host memory
+    if mode == "exact":
+        # chunk of rank r = its band followed by ceil(rows_r / C) entries of per-row numbers (only with meta)
+        sizes = [rows[r] * width + (_meta_slots(rows[r], c) if meta is not None else 0) for r in range(world_size)]
+        mine = torch.zeros((sizes[rank], c), dtype=local.dtype, device=local.device)
+        mine[:local.shape[0]] = local
+        if meta is not None:
+            mine[local.shape[0]:].view(-1)[:rows[rank]] = meta.to(device=local.device, dtype=local.dtype).reshape(-1)
+        if staged:
+            mine = mine.cpu()
+        send = mine.repeat(world_size, 1)                       # the same chunk to every rank (a 13 MB copy at 800x800)
+        buf = torch.empty((sum(sizes), c), dtype=send.dtype, device=send.device)
+        work = dist.all_to_all_single(buf, send, output_split_sizes=sizes, input_split_sizes=[sizes[rank]] * world_size,
+                                      async_op=async_op)
+
+        def finish_exact():
+            if work is not None:
+                work.wait()                   # current stream waits for the collective; send / buf stay referenced here
+            if meta is None:
+                frame = buf                   # the bands lie back to back: this IS the frame
+                return frame.to(local.device) if staged else frame
+            starts = [sum(sizes[:r]) for r in range(world_size)]
+            frame = torch.cat([buf[starts[r]:starts[r] + rows[r] * width] for r in range(world_size)], dim=0)
+            m = torch.cat([buf[starts[r] + rows[r] * width:starts[r] + sizes[r]].reshape(-1)[:rows[r]]
+                           for r in range(world_size)], dim=0)
+            return (frame.to(local.device), m.to(local.device)) if staged else (frame, m)
+
+        return finish_exact if async_op else finish_exact()
+    if mode != "padded":
+        raise ValueError(f"gather mode {mode!r}")
     band_cap = max(rows) * width
     meta_rays = 0 if meta is None else ((max(rows) + c - 1) // c + width - 1) // width * width      # whole padded rows
     cap = band_cap + meta_rays
@@ -105,7 +156,6 @@ def gather_bands(local: torch.Tensor, cuts: Sequence[int], width: int, rank: int
     send[:local.shape[0]] = local
     if meta is not None:
         send[band_cap:].view(-1)[:rows[rank]] = meta.to(device=local.device, dtype=local.dtype).reshape(-1)
-    staged = local.is_cuda and dist.get_backend() == "gloo"     # rehearsal on one GPU: gloo moves host memory
     if staged:
         send = send.cpu()
     send = send.contiguous()
@@ -156,11 +206,18 @@ class ShardedFrameRenderer:
             return torch.empty((0, 5), dtype=torch.float32, device=origins.device)
         cam = band_camera(c2w, focal, width, height, y0, y1)
         o, d = origins[y0 * width:y1 * width], viewdirs[y0 * width:y1 * width]
-        rgb, alpha, depth, _ = self.renderer.render(o, d, camera=cam)
+        # no host wait inside a band when the renderer offers it (FrameRenderer.render_async): at 8 ranks a band is
+        # ~0.3 ms of kernels, too short to hide a mid-frame round trip
+        draw = getattr(self.renderer, "render_async", None)
+        if callable(draw):
+            local = draw(o, d, cam, packed=True)[0]            # [rows*W, 5] straight from the compositor
+        else:
+            rgb, alpha, depth, _ = self.renderer.render(o, d, camera=cam)
+            local = torch.cat([rgb, alpha, depth], dim=1)
         # the band's quadrature points per row, for the next frames' cuts (a renderer without the hook reports none)
         hook = getattr(self.renderer, "row_samples", None)
-        self._band_samples = hook() if callable(hook) else None
-        return torch.cat([rgb, alpha, depth], dim=1)
+        self._band_samples = hook() if (callable(hook) and self.balance) else None
+        return local
 
     def render(self, origins, viewdirs, c2w, focal, width: int, height: int) -> torch.Tensor:
         return self.render_async(origins, viewdirs, c2w, focal, width, height)()

@@ -187,7 +187,7 @@ class _FusedFieldBase(nn.Module):
         return selector, x
 
     def _launch(self, head, n_lobes, xyz, dirs, want_rgb=False, want_sigma=False, want_geo=False, want_features=0,
-                head_ngp=None, head_sg=None, order=None, enc_out=None):
+                head_ngp=None, head_sg=None, order=None, enc_out=None, n_device=None):
         xyz = _C.f32c(xyz.reshape(-1, 3))
         n = xyz.shape[0]
         dev = xyz.device
@@ -213,7 +213,7 @@ class _FusedFieldBase(nn.Module):
                                _C.ptr(c["sg"][3]), _C.ptr(head_sg[5]))
             _C.check(_C.lib().qf_field_forward_bf16(
                 ctypes.byref(desc), _C.ptr(c["table"]), _C.ptr(c["base"]), _C.ptr(c.get("head")),
-                ctypes.byref(sg) if sg is not None else None, _C.ptr(xyz), _C.ptr(dirs), n,
+                ctypes.byref(sg) if sg is not None else None, _C.ptr(xyz), _C.ptr(dirs), n, _C.ptr(n_device, torch.int64),
                 _C.ptr(order, torch.int32), _C.ptr(rgb), _C.ptr(sigma), _C.ptr(geo), _C.stream()), "qf_field_forward_bf16")
             return rgb, sigma, geo, feats
         if head_sg is not None:
@@ -221,7 +221,8 @@ class _FusedFieldBase(nn.Module):
         _C.check(_C.lib().qf_field_forward(
             ctypes.byref(desc), _C.ptr(self.mlp_base.grid_params()), _C.ptr(self.mlp_base.network_params()),
             _C.ptr(head_ngp), ctypes.byref(sg) if sg is not None else None, _C.ptr(xyz), _C.ptr(dirs), n,
-            _C.ptr(order, torch.int32), _C.ptr(rgb), _C.ptr(sigma), _C.ptr(geo), _C.ptr(feats), _C.ptr(enc_out), _C.stream()),
+            _C.ptr(n_device, torch.int64), _C.ptr(order, torch.int32), _C.ptr(rgb), _C.ptr(sigma), _C.ptr(geo), _C.ptr(feats),
+            _C.ptr(enc_out), _C.stream()),
                  "qf_field_forward")
         return rgb, sigma, geo, feats
 
@@ -435,9 +436,12 @@ class NGPRadianceField(_FusedFieldBase):
         rgb = self.mlp_head(h).reshape(list(embedding.shape[:-1]) + [3]).to(embedding)
         return torch.sigmoid(rgb) if apply_act else rgb
 
-    def forward(self, positions: torch.Tensor, directions: torch.Tensor = None, order: torch.Tensor = None):
+    def forward(self, positions: torch.Tensor, directions: torch.Tensor = None, order: torch.Tensor = None,
+                n_device: torch.Tensor = None):
         """(rgb [..,3], density [..,1]).  ngp.py:798-809.  ``order`` (int32 permutation, optional) only changes the
-        order in which points are processed (cache locality), never the result."""
+        order in which points are processed (cache locality), never the result.  ``n_device`` (extension, inference
+        only): a device int64 scalar -- only the first ``min(n_device, len(positions))`` points are evaluated, the
+        arrays are worst-case buffers (a render-only frame whose sample count never reaches the host)."""
         if directions is None:
             raise ValueError("NGPRadianceField.forward needs view directions")
         assert positions.shape == directions.shape, f"{positions.shape} v.s. {directions.shape}"
@@ -451,7 +455,7 @@ class NGPRadianceField(_FusedFieldBase):
             rgb = torch.sigmoid(self.mlp_head(torch.cat([sh, feat], dim=-1)))
             return rgb.reshape(lead + [3]), density.reshape(lead + [1])
         rgb, sigma, _, _ = self._launch(_C.HEAD_NGP, 0, positions, directions, want_rgb=True, want_sigma=True,
-                                        head_ngp=self.mlp_head.params.detach(), order=order)
+                                        head_ngp=self.mlp_head.params.detach(), order=order, n_device=n_device)
         return rgb.reshape(lead + [3]), sigma.reshape(lead + [1])
 
 
@@ -552,8 +556,9 @@ class NGPRadianceFieldSGNew(_FusedFieldBase):
                                                 self.num_g_lobes, _C.ptr(rgb), _C.stream()), "qf_sg_features_to_rgb")
         return rgb
 
-    def forward(self, positions: torch.Tensor, directions: torch.Tensor = None, order: torch.Tensor = None):
-        """(rgb, density), ngp.py:463-470."""
+    def forward(self, positions: torch.Tensor, directions: torch.Tensor = None, order: torch.Tensor = None,
+                n_device: torch.Tensor = None):
+        """(rgb, density), ngp.py:463-470.  ``order`` / ``n_device``: see ``NGPRadianceField.forward``."""
         if directions is None:
             raise ValueError("NGPRadianceFieldSGNew.forward needs view directions")
         lead = list(positions.shape[:-1])
@@ -572,5 +577,5 @@ class NGPRadianceFieldSGNew(_FusedFieldBase):
             rgb = self.features_to_rgb(f[:, :-1], directions)
             return rgb.reshape(lead + [3]), f[:, -1:].reshape(lead + [1])
         rgb, sigma, _, _ = self._launch(_C.HEAD_SG, self.num_g_lobes, positions, directions, want_rgb=True,
-                                        want_sigma=True, head_sg=self._sg_params(), order=order)
+                                        want_sigma=True, head_sg=self._sg_params(), order=order, n_device=n_device)
         return rgb.reshape(lead + [3]), sigma.reshape(lead + [1])

@@ -10,7 +10,7 @@ from typing import Optional
 
 import torch
 
-from . import utils
+from . import _C, utils
 from .datasets.utils import Rays
 from .field import Field as _Field
 
@@ -37,8 +37,10 @@ class FrameRenderer:
         frame = self.mesh_intersect.rayintersector.last_frame
         if frame is None:
             return None
-        counts = frame.hit_count.clamp(max=frame.max_hits)
-        return counts.view(frame.height, frame.width).sum(dim=1, dtype=torch.float32)
+        out = torch.empty((frame.height,), dtype=torch.float32, device=frame.hit_count.device)
+        _C.check(_C.lib().qf_row_sample_counts(_C.ptr(frame.hit_count), frame.max_hits, frame.width, frame.height,
+                                               _C.ptr(out), _C.stream()), "qf_row_sample_counts")
+        return out
 
     @torch.no_grad()
     def quadrature_points(self, origins: torch.Tensor, viewdirs: torch.Tensor, image_width: int = 0, camera=None):
@@ -112,6 +114,37 @@ class FrameRenderer:
             bg_color=self.bg_color, order=ri.last_order,
             order_inverse=ri.last_layout[0] if ri.last_layout is not None else None)
         return rgb, alpha, depth, n_samples
+
+    @torch.no_grad()
+    def render_async(self, origins: torch.Tensor, viewdirs: torch.Tensor, camera, scaling: float = 0.0,
+                     render_bkgd: Optional[torch.Tensor] = None, packed: bool = False):
+        """``render`` for a camera frame WITHOUT any host wait: (rgb, alpha, depth, frame) -- with ``packed``
+        (rgb | alpha | depth in ONE [R,5] array, None, None, frame).  The frame's sample count
+        stays on the device -- the tile pack leaves it next to the tile bases and the field / deformation kernels read
+        it there (``n_device``) -- so the whole frame is a fixed sequence of ~10 launches into worst-case buffers and
+        the host is free to enqueue the next frame (or band) at once; ``frame`` answers
+        ``mesh_intersect.rayintersector.frame_samples()`` later, if anyone asks.  Same pixels as ``render``."""
+        ri = self.mesh_intersect.rayintersector
+        fused = getattr(self.radiance_field, "discretize", False) is False
+        if not fused:
+            rgb, alpha, depth, _ = self.render(origins, viewdirs, scaling=scaling, render_bkgd=render_bkgd, camera=camera)
+            if packed:
+                return torch.cat([rgb, alpha, depth], dim=1), None, None, ri.last_frame
+            return rgb, alpha, depth, ri.last_frame
+        frame = ri.sample_frame_device(origins, viewdirs, self.mesh_intersect.num_intersections, camera)
+        _, xyz_c, dirs_c = ri.last_layout
+        nd = frame.total_dev
+        if self.field_net is not None and scaling != 0 and isinstance(self.field_net, _Field):
+            f = self.field_net(xyz_c, return_grad=False, n_device=nd)[0]
+            xyz_c, depth_s = utils.deform_frame(f, scaling, xyz_c, dirs_c, frame, total_device=nd)
+            frame = copy.copy(frame)
+            frame.depth_c = depth_s
+        elif self.field_net is not None and scaling != 0:
+            raise ValueError("render_async: a deformation module other than Field has no device-count route")
+        rgbs, sigmas = self.radiance_field(xyz_c, dirs_c, n_device=nd)
+        rgb, alpha, depth, _ = utils.composite_frame(rgbs, sigmas, frame, self.render_step_size, render_bkgd=render_bkgd,
+                                                     bg_color=self.bg_color, packed=packed)
+        return rgb, alpha, depth, frame
 
     @torch.no_grad()
     def render_baked(self, origins, viewdirs, uv, compressor, image_width: int = 0, camera=None):

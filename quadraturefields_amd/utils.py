@@ -152,12 +152,14 @@ def derive_properties(color, density, depths, deltas, boundary, index_ray, rende
 
 @torch.no_grad()
 def composite_frame(color_c, density_c, frame, render_step_size: float, render_bkgd=None, bg_color="white",
-                    want_weights: bool = False):
+                    want_weights: bool = False, packed: bool = False):
     """``derive_properties`` for a whole frame whose colours / densities come straight from the field kernel, i.e. in the
     intersector's coherent order: ``frame`` = ``RayIntersector.last_frame`` (depths in that order, per-pixel sample
     counts, tile bases, image size).  One launch (``qf_composite_tiles``), every load a contiguous run; the same
     values as ``derive_properties(..., sample_index=inverse)`` bit for bit.  Returns (rgb [N,3], alpha [N,1],
-    depth [N,1], weights in the coherent order [S,1] or None).  Inference only."""
+    depth [N,1], weights in the coherent order [S,1] or None).  ``packed``: ONE [N,5] array (rgb | alpha | depth per
+    pixel, what a row band of a sharded frame sends) comes back in place of the three: (packed, None, None, weights).
+    Inference only."""
     color_c = _C.f32c(color_c.reshape(-1, 3))
     density_c = _C.f32c(density_c.reshape(-1))
     dev = color_c.device
@@ -167,33 +169,39 @@ def composite_frame(color_c, density_c, frame, render_step_size: float, render_b
     n_rays = frame.width * frame.height
     mode = _BG.get(bg_color, _C.BG_CUSTOM)
     bk = _C.f32c(render_bkgd.detach().reshape(3).to(dev)) if mode == _C.BG_CUSTOM else None
-    rgb = torch.empty((n_rays, 3), dtype=torch.float32, device=dev)
-    alpha = torch.empty((n_rays, 1), dtype=torch.float32, device=dev)
-    depth = torch.empty((n_rays, 1), dtype=torch.float32, device=dev)
+    rgb = alpha = depth = out5 = None
+    if packed:
+        out5 = torch.empty((n_rays, 5), dtype=torch.float32, device=dev)
+    else:
+        rgb = torch.empty((n_rays, 3), dtype=torch.float32, device=dev)
+        alpha = torch.empty((n_rays, 1), dtype=torch.float32, device=dev)
+        depth = torch.empty((n_rays, 1), dtype=torch.float32, device=dev)
     weights = torch.empty((n, 1), dtype=torch.float32, device=dev) if want_weights else None
     _C.check(_C.lib().qf_composite_tiles(
         _C.ptr(color_c), _C.ptr(density_c), _C.ptr(frame.depth_c), float(render_step_size), _C.ptr(frame.hit_count),
         frame.max_hits, _C.ptr(frame.tile_base), frame.width, frame.height, mode, _C.ptr(bk), _C.ptr(rgb), _C.ptr(alpha),
-        _C.ptr(depth), _C.ptr(weights), _C.stream()), "qf_composite_tiles")
+        _C.ptr(depth), _C.ptr(weights), _C.ptr(out5), _C.stream()), "qf_composite_tiles")
+    if packed:
+        return out5, None, None, weights
     return rgb, alpha, depth, weights
 
 
 @torch.no_grad()
-def deform_frame(f_c, scaling: float, xyz_c, dirs_c, frame):
+def deform_frame(f_c, scaling: float, xyz_c, dirs_c, frame, total_device=None):
     """The "before" evaluation's displacement + re-sort (utils.py:555-572, mesh_utils.py:389-403) on a frame in the
     intersector's coherent order: ``f_c`` = the deformation field's output at ``xyz_c``; returns (xyz, depth) in the
     same order, every ray's samples displaced by ``tanh(f) * scaling`` along the ray and back in depth order
     (``qf_deform_resort_tiles``).  Inference only."""
     f_c = _C.f32c(f_c.detach().reshape(-1))
-    n = frame.total
+    n = frame.total                    # slots of the arrays (their capacity when the count stays on the device)
     if f_c.shape[0] != n or xyz_c.shape[0] != n:
         raise ValueError(f"deform_frame: {n} slots in the frame, {f_c.shape[0]} field outputs, {xyz_c.shape[0]} positions")
     xyz_out = torch.empty_like(xyz_c)
     depth_out = torch.empty_like(frame.depth_c)
     _C.check(_C.lib().qf_deform_resort_tiles(
         _C.ptr(f_c), float(scaling), _C.ptr(_C.f32c(xyz_c)), _C.ptr(_C.f32c(dirs_c)), _C.ptr(frame.depth_c),
-        _C.ptr(frame.hit_count), frame.max_hits, _C.ptr(frame.tile_base), n, frame.width, frame.height, _C.ptr(xyz_out),
-        _C.ptr(depth_out), _C.stream()), "qf_deform_resort_tiles")
+        _C.ptr(frame.hit_count), frame.max_hits, _C.ptr(frame.tile_base), n, _C.ptr(total_device, torch.int64),
+        frame.width, frame.height, _C.ptr(xyz_out), _C.ptr(depth_out), _C.stream()), "qf_deform_resort_tiles")
     return xyz_out, depth_out
 
 
@@ -425,7 +433,7 @@ def texel_indices(mesh_intersect, uv, points, index_tri, texture_size: int, pack
 
 
 @torch.no_grad()
-def shade_baked_points(mesh_intersect, uv, compressor, points, index_tri, dirs):
+def shade_baked_points(mesh_intersect, uv, compressor, points, index_tri, dirs, n_device=None):
     """(rgb [n,3], sigma [n]) of samples given by position and triangle: ``texel_indices`` + ``compressor.shade`` in one
     launch (``qf_texture_shade_points``: the texel is looked up inside the shading kernel, no index array in between).
     Same values as the two calls."""
@@ -440,7 +448,8 @@ def shade_baked_points(mesh_intersect, uv, compressor, points, index_tri, dirs):
     _C.check(_C.lib().qf_texture_shade_points(
         _C.ptr(compressor.records()), int(compressor.alpha.shape[0]), compressor.num_lobes,
         1 if compressor.compression_type == "sigma" else 0, float(compressor.lambda_thres), _C.ptr(records), _C.ptr(points),
-        _C.ptr(tri64), _C.ptr(tri32), _C.ptr(dirs), n, _C.ptr(rgb), _C.ptr(sigma), _C.stream()), "qf_texture_shade_points")
+        _C.ptr(tri64), _C.ptr(tri32), _C.ptr(dirs), n, _C.ptr(n_device, torch.int64), _C.ptr(rgb), _C.ptr(sigma), _C.stream()),
+        "qf_texture_shade_points")
     return rgb, sigma
 
 

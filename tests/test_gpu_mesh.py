@@ -729,8 +729,10 @@ def test_frame_offsets_equal_a_cumsum(device):
             tiles2 = torch.empty_like(tiles)
             total2 = torch.full((1,), -1, dtype=torch.int64, device=device)
             host2 = torch.full((4,), -1, dtype=torch.int64).pin_memory()
+            zero_me = torch.full((1,), 77, dtype=torch.int32, device=device)
             _C.check(_C.lib().qf_tile_offsets(_C.ptr(cnt), k, w, h, _C.ptr(tiles2), _C.ptr(total2), _C.ptr(ovf),
-                                              ctypes.c_void_p(host2.data_ptr()), _C.stream()), "qf_tile_offsets")
+                                              ctypes.c_void_p(host2.data_ptr()), _C.ptr(zero_me), _C.stream()), "qf_tile_offsets")
+            assert int(zero_me) == 0                        # zero_word: the tile pack's dropped-hit counter, zeroed on the way
             torch.cuda.synchronize()
             assert torch.equal(tiles2, tiles) and int(total2) == int(c.sum())
             assert int(host2[0]) == int(c.sum()) and int(host2[1]) == 7

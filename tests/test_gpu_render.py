@@ -436,3 +436,41 @@ def test_config3_bf16_frame_at_k25_and_t21_on_a_crop(device):
     got = rgb.cpu()[idx]
     assert float((got - rgb_o).abs().max()) <= 1e-2
     assert psnr(got, rgb_o) >= 50.0
+
+
+@pytest.mark.parametrize("scaling", [0.0, 0.05])
+def test_frame_without_host_wait_equals_the_frame_with_it(device, scaling):
+    """FrameRenderer.render_async: the sample count never reaches the host (the field / deformation kernels read it from
+    device memory, the arrays are worst-case buffers).  Pixels, alpha and depth bit-identical to ``render``; the sample
+    count is still available afterwards; a frame that hits nothing is the background; several frames can be enqueued
+    back to back before anything is read."""
+    from quadraturefields_amd import synthetic
+    from quadraturefields_amd.field import Field
+    from quadraturefields_amd.mesh_utils import make_camera
+    from quadraturefields_amd.render import FrameRenderer
+    mesh, mi, field = _scene(device)
+    torch.manual_seed(0)
+    field_net = Field(scale=1.5, precision=16, log2_T=14, L=16, max_res=512, min_res=16, output_dim=1, hidden_size=32,
+                      num_features=2, back_prop=False, nl="relu").to(device)
+    field_net.xyz_encoder.params.data.uniform_(-0.5, 0.5)
+    fr = FrameRenderer(mi, field, field_net=field_net if scaling else None)
+    w, h = 120, 88
+    focal = synthetic.lego_focal(800) * w / 800.0
+    cams = synthetic.orbit_cameras(3, seed=21)
+    queued = []
+    for c2w in cams:                                   # three frames enqueued before any result is looked at
+        o, d = synthetic.camera_rays(c2w, focal, w, h, device=device)
+        cam = make_camera(c2w, focal, w, h)
+        queued.append((o, d, cam, fr.render_async(o, d, cam, scaling=scaling)))
+    ri = mi.rayintersector
+    n_last = ri.frame_samples()
+    for o, d, cam, (rgb_a, alpha_a, depth_a, frame) in queued:
+        rgb, alpha, depth, n = fr.render(o, d, scaling=scaling, camera=cam)
+        assert torch.equal(rgb, rgb_a) and torch.equal(alpha, alpha_a) and torch.equal(depth, depth_a)
+        assert frame.total_dev.dtype == torch.int64 and frame.depth_c.shape[0] == w * h * 25      # worst-case buffers
+    assert n_last == n > 1000
+    # nothing hit: background, no samples
+    o, d = synthetic.camera_rays(cams[0], focal, w, h, device=device)
+    rgb_a, alpha_a, _, _ = fr.render_async(o + 100.0, d, make_camera(cams[0], focal, w, h), scaling=scaling)
+    assert torch.equal(rgb_a, torch.ones_like(rgb_a)) and float(alpha_a.abs().max()) == 0.0
+    assert ri.frame_samples() == 0

@@ -115,20 +115,24 @@ def _band_worker(rank, world, port, w, h, q):
         cuts.append(list(sr.last_cuts))
     # per-row numbers ride in the same collective (the bands' sample counts): uneven bands, more rows than one padded
     # row of the payload holds
-    uneven = [0, 8 * (h // 24 + 1), h]
+    uneven = [0, 8 * (h // 24 + 1), h] if world == 2 else [0, 8, 8 * (h // 16), h]
     rows = uneven[rank + 1] - uneven[rank]
     local = torch.full((rows * w, 5), float(rank))
-    fr, m = parallel.gather_bands(local, uneven, w, rank, world, meta=torch.arange(uneven[rank], uneven[rank + 1]).float())
-    ok = ok and torch.equal(m, torch.arange(h).float()) and fr.shape == (h * w, 5)
-    ok = ok and bool((fr[:uneven[1] * w] == 0).all()) and bool((fr[uneven[1] * w:] == 1).all())
+    for mode in ("exact", "padded"):         # all_to_all_single with split sizes; all_gather of padded bands
+        fr, m = parallel.gather_bands(local, uneven, w, rank, world, meta=torch.arange(uneven[rank], uneven[rank + 1]).float(),
+                                      mode=mode)
+        ok = ok and torch.equal(m, torch.arange(h).float()) and fr.shape == (h * w, 5)
+        ok = ok and all(bool((fr[uneven[r] * w:uneven[r + 1] * w] == r).all()) for r in range(world))
+        fr2 = parallel.gather_bands(local, uneven, w, rank, world, mode=mode, async_op=True)()      # without meta, async
+        ok = ok and torch.equal(fr2, fr)
     q.put((rank, ok, cuts))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("w,h", [(24, 64), (17, 43), (2, 80)])
-def test_two_rank_band_render_and_gather(w, h):
-    world, port = 2, _free_port()
+@pytest.mark.parametrize("w,h,world", [(24, 64, 2), (17, 43, 2), (2, 80, 2), (24, 64, 3)])
+def test_two_rank_band_render_and_gather(w, h, world):
+    port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_band_worker, args=(r, world, port, w, h, q)) for r in range(world)]
@@ -139,9 +143,9 @@ def test_two_rank_band_render_and_gather(w, h):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(ok for _, ok, _ in results)
-    assert results[0][2] == results[1][2]                    # both ranks cut every frame identically
+    assert all(r[2] == results[0][2] for r in results)       # every rank cuts every frame identically
     cuts = results[0][2]
-    assert cuts[0] == cuts[1] == parallel.band_cuts(h, 2)    # uniform until the lagged profile arrives
+    assert cuts[0] == cuts[1] == parallel.band_cuts(h, world)    # uniform until the lagged profile arrives
     assert cuts[2][0] == 0 and cuts[2][-1] == h and cuts[2][1] % parallel.BAND_ALIGN == 0
 
 
