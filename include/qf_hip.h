@@ -73,7 +73,9 @@ int qf_grid_encode_backward(const qf_grid_desc *desc /* host */, const float *ta
  * Python layer): from 2^15 points on the table gradient is computed by the LDS-partitioned scatter -- every
  * (level, 20 000-row partition, point chunk) accumulates in a workgroup's LDS and is added to grad_table with
  * contiguous atomics, instead of one scattered memory-side atomic request per corner pair.  Same result up to fp32
- * summation order.  workspace NULL / too small or a small batch: falls back to qf_grid_encode_backward.          */
+ * summation order.  workspace NULL / too small or a small batch: falls back to qf_grid_encode_backward.
+ * The walk costs O(partitions x points) per level, so a level with more than 64 partitions (1.28 M rows: every
+ * hashed level of the deformation field's T = 2^24 table) keeps the quad atomics -- decided per level.            */
 int64_t qf_grid_backward_workspace_bytes(int64_t n);
 int qf_grid_encode_backward_ws(const qf_grid_desc *desc, const float *table, const float *x01,
                                const float *dfeat, int64_t n, float *grad_table, float *grad_x01,
@@ -86,7 +88,10 @@ int qf_grid_encode_backward_ws(const qf_grid_desc *desc, const float *table, con
  * ACCUMULATED into with fp32 atomics.                                                            */
 int qf_grid_encode_double_backward(const qf_grid_desc *desc /* host */, const float *table, const float *x01,
                                    const float *dfeat, const float *v, int64_t n, float *g_dfeat,
-                                   float *g_x01, float *grad_table, void *stream);
+                                   float *g_x01, float *grad_table,
+                                   void *workspace /* or NULL; qf_grid_backward_workspace_bytes(n): large batches take
+                                                      the partitioned table scatter of qf_grid_encode_backward_ws */,
+                                   int64_t workspace_bytes, void *stream);
 
 /* Grid + 1-hidden-layer 64-wide MLP: x01 [n,3] -> raw [n,16].  Replaces
  * tcnn.NetworkWithInputEncoding.forward for mlp_base (ngp.py:764-768); base_w as below.       */
@@ -204,6 +209,15 @@ int qf_deform_mlp_backward(const float *enc, const float *x01, const float *d_ou
                            const float *b1, const float *w2, const float *b2, const float *wout, int64_t n,
                            float *d_enc, float *d_x01, float *g_w1, float *g_b1, float *g_w2, float *g_b2,
                            float *g_wout, float *g_bout, void *stream);
+
+/* One step of torch.optim.Adam (the reference's optimiser, train_finetune.py:402-417; amsgrad off) on one flat fp32
+ * parameter tensor, in ONE launch: the update of torch's foreach implementation element for element --
+ *   m += (1-b1)(g-m); v = v b2 + (1-b2) g g; p += -(lr/(1-b1^t)) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+ * (weight_decay: g += wd p first; maximize: g = -g) -- where torch issues eleven launches and seven passes.  step = t,
+ * counted from 1.  All four arrays 16-byte aligned.  Values agree with torch to rounding (each operation individually
+ * rounded here; torch's kernels leave contraction to the compiler).                                    */
+int qf_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, float lr, float beta1,
+                 float beta2, float eps, float weight_decay, int32_t maximize, int64_t step, void *stream);
 
 /* xyz_out = xyz + dh, ts_out = ts + dd with dd = tanh(f)*scaling*(1,1,1) . dir and dh = dd * dir (utils.py:566-571,
  * every operation rounded on its own as the reference's tensor ops are).  In place when xyz_out == xyz / ts_out == ts.

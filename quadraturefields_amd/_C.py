@@ -63,7 +63,7 @@ _SIGNATURES = {
     "qf_grid_encode_backward": (c_int, [POINTER(GridDesc), _P, _P, _P, c_int64, _P, _P, _P]),
     "qf_grid_backward_workspace_bytes": (c_int64, [c_int64]),
     "qf_grid_encode_backward_ws": (c_int, [POINTER(GridDesc), _P, _P, _P, c_int64, _P, _P, _P, c_int64, _P]),
-    "qf_grid_encode_double_backward": (c_int, [POINTER(GridDesc), _P, _P, _P, _P, c_int64, _P, _P, _P, _P]),
+    "qf_grid_encode_double_backward": (c_int, [POINTER(GridDesc), _P, _P, _P, _P, c_int64, _P, _P, _P, _P, c_int64, _P]),
     "qf_grid_mlp_forward": (c_int, [POINTER(GridDesc), _P, _P, _P, c_int64, _P, _P]),
     "qf_field_forward": (c_int, [POINTER(FieldDesc), _P, _P, _P, POINTER(SGHead), _P, _P, c_int64, _P, _P, _P, _P, _P, _P, _P, _P]),
     "qf_field_forward_bf16": (c_int, [POINTER(FieldDesc), _P, _P, _P, POINTER(SGHead), _P, _P, c_int64, _P, _P, _P, _P, _P, _P]),
@@ -73,6 +73,7 @@ _SIGNATURES = {
     "qf_sg_features_to_rgb_backward": (c_int, [_P, c_int64, _P, _P, c_int64, c_int32, _P, c_int64, _P]),
     "qf_deform_field_forward": (c_int, [POINTER(GridDesc), _P, c_float, c_int32, _P, _P, _P, _P, _P, _P, _P, c_int64, _P, _P, _P, _P, _P]),
     "qf_deform_mlp_backward": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "qf_adam_step": (c_int, [_P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_float, c_int32, c_int64, _P]),
     "qf_apply_deformation": (c_int, [_P, c_float, _P, _P, _P, c_int64, _P, _P, _P, _P]),
     "qf_mark_pack_boundaries": (c_int, [_P, c_int64, _P, _P]),
     "qf_exponential_integration": (c_int, [_P, c_int32, _P, _P, c_int64, c_int64, c_int32, _P, _P, _P]),

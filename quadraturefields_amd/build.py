@@ -24,6 +24,7 @@ SOURCES = [
     ("mlp_train.hip", []),
     ("scan.hip", []),
     ("composite.hip", []),
+    ("optim.hip", []),
     ("exact.hip", ["-ffp-contract=off"]),
     ("bvh_build.cpp", ["-x", "hip"]),
     ("misc.cpp", ["-x", "hip"]),

@@ -27,13 +27,20 @@ __device__ __forceinline__ LevelConst level_const(const GridArgs &ga, int level)
 // 16 contiguous bytes (rows idx, idx+1 x two features, whenever the x-neighbour is the next row) in the SAME atomic
 // instruction, and the memory pipeline carries same-line lanes of one instruction as one request: 3.7 ms per 2^20
 // points against 13.3 ms with one lane per (point, level) issuing its 16 atomics one after the other.
-__global__ void grid_backward_table_kernel(GridArgs ga, const float *x01, const float *dfeat, int64_t n, float *grad_table)
+// LevelSel: the levels this launch serves (all of them, or the ones the partitioned scatter below leaves to the atomics).
+struct LevelSel {
+    int n;
+    int8_t level[QF_MAX_LEVELS];
+};
+
+__global__ void grid_backward_table_kernel(GridArgs ga, LevelSel sel, const float *x01, const float *dfeat, int64_t n,
+                                           float *grad_table)
 {
-    const int64_t total = n * QF_MAX_LEVELS * 4;
+    const int64_t total = n * sel.n * 4;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
         const int sub = (int)(e & 3), cx = sub >> 1, f = sub & 1;
-        const int64_t pl = e >> 2, pt = pl >> 4;
-        const int level = (int)(pl & 15);
+        const int64_t pl = e >> 2, pt = pl / sel.n;
+        const int level = sel.level[(int)(pl - pt * sel.n)];
         const float gf = dfeat[pt * 32 + 2 * level + f];
         if (gf == 0.0f) continue;
         const LevelConst lc = level_const(ga, level);
@@ -64,7 +71,15 @@ __global__ void grid_backward_table_kernel(GridArgs ga, const float *x01, const 
 // point lands, and gets ~100 point chunks; a hashed level's 26 partitions get 4 each (with 3 chunks everywhere the
 // three workgroups of level 0 ran 7.1 ms while the rest of the chip idled).  1.97 ms per 2^20 points, T = 2^19,
 // against 3.69 ms for the quad-atomic kernel (tools/train_bench.py).
+//
+// The walk is O(partitions x points) per level: ~2.9 us per partition and 10^6 points, against 0.21 ms per level and
+// 10^6 points for the quad atomics (4 requests per point and level at 1.9e10/s).  A level therefore takes this route
+// only while it has at most kMaxLdsParts partitions; above that -- every hashed level of the deformation field's
+// T = 2^24 table: 839 partitions each -- it goes to grid_backward_table_kernel.  Round 2 sent ALL levels here and the
+// reference-sized deformation table (train_finetune.py:387-399, 101.6 M rows = 5 300 partitions) cost 13.4 ms per
+// 0.8 M points; with the split 1.3 ms.
 constexpr int kLdsRows = 20000;
+constexpr int kMaxLdsParts = 64;
 constexpr int kScatterThreads = 1024;
 constexpr int kScatterUnroll = 8;
 
@@ -91,9 +106,13 @@ __global__ __launch_bounds__(256) void dfeat_level_major_kernel(const float *__r
     }
 }
 
+// kSecond: the table part of the SECOND order (grid_double_backward_table_kernel's sums): corner c contributes
+// D_l(c) * dfeat instead of w_c * dfeat, D_l(c) = scale_l * sum_d v_d (dw_c / dfrac_d) with v [n,3] = dL/d(field_grad).
+template <bool kSecond>
 __global__ __launch_bounds__(kScatterThreads) void grid_backward_table_lds_kernel(GridArgs ga, ScatterPlan plan,
                                                                                 const float *__restrict__ x01,
                                                                                 const float2 *__restrict__ dfeat_lm,
+                                                                                const float *__restrict__ v,
                                                                                 int64_t n, float *__restrict__ grad_table)
 {
     extern __shared__ float2 acc[];
@@ -114,6 +133,7 @@ __global__ __launch_bounds__(kScatterThreads) void grid_backward_table_lds_kerne
     for (int64_t base = p_lo + threadIdx.x; base < p_hi; base += (int64_t)kScatterUnroll * kScatterThreads) {
         float2 gf[kScatterUnroll];
         float px[kScatterUnroll], py[kScatterUnroll], pz[kScatterUnroll];
+        float vx[kSecond ? kScatterUnroll : 1], vy[kSecond ? kScatterUnroll : 1], vz[kSecond ? kScatterUnroll : 1];
 #pragma unroll
         for (int u = 0; u < kScatterUnroll; ++u) {
             const int64_t pt = base + (int64_t)u * kScatterThreads;
@@ -124,6 +144,7 @@ __global__ __launch_bounds__(kScatterThreads) void grid_backward_table_lds_kerne
             px[u] = x01[q * 3];
             py[u] = x01[q * 3 + 1];
             pz[u] = x01[q * 3 + 2];
+            if (kSecond) { vx[u] = v[q * 3]; vy[u] = v[q * 3 + 1]; vz[u] = v[q * 3 + 2]; }
         }
 #pragma unroll
         for (int u = 0; u < kScatterUnroll; ++u) {
@@ -146,8 +167,17 @@ __global__ __launch_bounds__(kScatterThreads) void grid_backward_table_lds_kerne
 #pragma unroll
                     for (int k = 1; k < 8; ++k) id = (c == k) ? idx[k] : id;
                     const uint32_t r = id - lc.offset - row_lo;
-                    const float w = (((c & 1) ? frac[0] : 1.0f - frac[0]) * ((c & 2) ? frac[1] : 1.0f - frac[1])) *
-                                    ((c & 4) ? frac[2] : 1.0f - frac[2]);
+                    float w;
+                    if (kSecond) {                     // the expression of grid_double_backward_table_kernel
+                        const float ax = (c & 1) ? frac[0] : 1.0f - frac[0], sx = (c & 1) ? 1.0f : -1.0f;
+                        const float ay = (c & 2) ? frac[1] : 1.0f - frac[1], sy = (c & 2) ? 1.0f : -1.0f;
+                        const float az = (c & 4) ? frac[2] : 1.0f - frac[2], sz = (c & 4) ? 1.0f : -1.0f;
+                        w = lc.scale * (vx[kSecond ? u : 0] * sx * ay * az + vy[kSecond ? u : 0] * sy * ax * az +
+                                        vz[kSecond ? u : 0] * sz * ax * ay);
+                    } else {
+                        w = (((c & 1) ? frac[0] : 1.0f - frac[0]) * ((c & 2) ? frac[1] : 1.0f - frac[1])) *
+                            ((c & 4) ? frac[2] : 1.0f - frac[2]);
+                    }
                     atomicAdd(&acc[r].x, w * gf[u].x);
                     atomicAdd(&acc[r].y, w * gf[u].y);
                 }
@@ -206,14 +236,14 @@ __global__ void grid_backward_input_kernel(GridArgs ga, const float2 *table, con
 // sign_d sign_e times the third factor).
 // table part of the second order: dL/dtable[c][f] += D_l(c) dfeat_{l,f}, four lanes per (point, level) like
 // grid_backward_table_kernel
-__global__ void grid_double_backward_table_kernel(GridArgs ga, const float *x01, const float *dfeat, const float *v,
-                                                  int64_t n, float *grad_table)
+__global__ void grid_double_backward_table_kernel(GridArgs ga, LevelSel sel, const float *x01, const float *dfeat,
+                                                  const float *v, int64_t n, float *grad_table)
 {
-    const int64_t total = n * QF_MAX_LEVELS * 4;
+    const int64_t total = n * sel.n * 4;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
         const int sub = (int)(e & 3), cx = sub >> 1, f = sub & 1;
-        const int64_t pl = e >> 2, pt = pl >> 4;
-        const int level = (int)(pl & 15);
+        const int64_t pl = e >> 2, pt = pl / sel.n;
+        const int level = sel.level[(int)(pl - pt * sel.n)];
         const float df = dfeat[pt * 32 + 2 * level + f];
         if (df == 0.0f) continue;
         const LevelConst lc = level_const(ga, level);
@@ -283,8 +313,11 @@ extern "C" int qf_grid_encode_backward(const qf_grid_desc *desc, const float *ta
     if (n == 0) return QF_OK;
     if (!x01 || !dfeat || (!grad_table && !grad_x01) || (grad_x01 && !table)) return QF_ERR_INVALID_ARGUMENT;
     if (grad_table) {
+        LevelSel all;
+        all.n = QF_MAX_LEVELS;
+        for (int l = 0; l < QF_MAX_LEVELS; ++l) all.level[l] = (int8_t)l;
         hipLaunchKernelGGL(grid_backward_table_kernel, dim3(qf_grid_1d(n * 64, 256, 32)), dim3(256), 0, qf_stream(stream),
-                           ga, x01, dfeat, n, grad_table);
+                           ga, all, x01, dfeat, n, grad_table);
         QF_LAUNCH_CHECK();
     }
     if (grad_x01) {
@@ -296,6 +329,60 @@ extern "C" int qf_grid_encode_backward(const qf_grid_desc *desc, const float *ta
 }
 
 extern "C" int64_t qf_grid_backward_workspace_bytes(int64_t n) { return n < 0 ? -1 : n * 32 * (int64_t)sizeof(float); }
+
+// The table scatter of a large batch, first (v == NULL) or second order: levels with few partitions through the LDS walk,
+// the others through the quad atomics (see kMaxLdsParts).  workspace: qf_grid_backward_workspace_bytes(n) bytes.
+static int table_scatter_ws(const GridArgs &ga, const float *x01, const float *dfeat, const float *v, int64_t n,
+                            float *grad_table, void *workspace, hipStream_t st)
+{
+    float2 *lm = reinterpret_cast<float2 *>(workspace);
+    ScatterPlan plan;
+    // ~96 workgroups per level on 256 CUs (measured 32 / 64 / 96 / 128 / 256 per level: 2.35 / 2.05 / 1.96 / 1.98 / 2.07 ms)
+    const int per_level = 3 * qf_cu_count_cached() / 8 > 16 ? 3 * qf_cu_count_cached() / 8 : 16;
+    int item = 0;
+    LevelSel atomics;                  // levels with too many partitions for the walk: quad atomics
+    atomics.n = 0;
+    for (int l = 0; l < QF_MAX_LEVELS; ++l) {
+        const int parts = (int)qf_div_up(ga.rows[l], kLdsRows);
+        plan.first_item[l] = item;
+        if (parts > kMaxLdsParts) {
+            plan.chunks[l] = 1;        // no workgroups: first_item[l + 1] == first_item[l]
+            atomics.level[atomics.n++] = (int8_t)l;
+            continue;
+        }
+        int chunks = (per_level + parts / 2) / parts;
+        if (chunks < 1) chunks = 1;
+        plan.chunks[l] = chunks;
+        item += parts * chunks;
+    }
+    plan.first_item[QF_MAX_LEVELS] = item;
+    if (atomics.n > 0) {
+        if (v)
+            hipLaunchKernelGGL(grid_double_backward_table_kernel, dim3(qf_grid_1d(n * atomics.n * 4, 256, 32)), dim3(256), 0, st,
+                               ga, atomics, x01, dfeat, v, n, grad_table);
+        else
+            hipLaunchKernelGGL(grid_backward_table_kernel, dim3(qf_grid_1d(n * atomics.n * 4, 256, 32)), dim3(256), 0, st, ga,
+                               atomics, x01, dfeat, n, grad_table);
+        QF_LAUNCH_CHECK();
+    }
+    if (item == 0) return QF_OK;
+    hipLaunchKernelGGL(dfeat_level_major_kernel, dim3((unsigned)qf_div_up(n, 64)), dim3(256), 0, st, dfeat, n, lm);
+    QF_LAUNCH_CHECK();
+    const size_t lds = (size_t)kLdsRows * sizeof(float2);
+    if (v) {
+        static QfLdsAttr attr2;                      // per device
+        QF_HIP_TRY(qf_ensure_dynamic_lds(attr2, reinterpret_cast<const void *>(grid_backward_table_lds_kernel<true>), lds));
+        hipLaunchKernelGGL(grid_backward_table_lds_kernel<true>, dim3((unsigned)item), dim3(kScatterThreads), lds, st, ga, plan,
+                           x01, lm, v, n, grad_table);
+    } else {
+        static QfLdsAttr attr;                       // per device
+        QF_HIP_TRY(qf_ensure_dynamic_lds(attr, reinterpret_cast<const void *>(grid_backward_table_lds_kernel<false>), lds));
+        hipLaunchKernelGGL(grid_backward_table_lds_kernel<false>, dim3((unsigned)item), dim3(kScatterThreads), lds, st, ga, plan,
+                           x01, lm, (const float *)nullptr, n, grad_table);
+    }
+    QF_LAUNCH_CHECK();
+    return QF_OK;
+}
 
 extern "C" int qf_grid_encode_backward_ws(const qf_grid_desc *desc, const float *table, const float *x01,
                                           const float *dfeat, int64_t n, float *grad_table, float *grad_x01,
@@ -311,28 +398,8 @@ extern "C" int qf_grid_encode_backward_ws(const qf_grid_desc *desc, const float 
     if (rc != QF_OK) return rc;
     if (!x01 || !dfeat || (grad_x01 && !table)) return QF_ERR_INVALID_ARGUMENT;
     hipStream_t st = qf_stream(stream);
-    float2 *lm = reinterpret_cast<float2 *>(workspace);
-    hipLaunchKernelGGL(dfeat_level_major_kernel, dim3((unsigned)qf_div_up(n, 64)), dim3(256), 0, st, dfeat, n, lm);
-    QF_LAUNCH_CHECK();
-    ScatterPlan plan;
-    // ~96 workgroups per level on 256 CUs (measured 32 / 64 / 96 / 128 / 256 per level: 2.35 / 2.05 / 1.96 / 1.98 / 2.07 ms)
-    const int per_level = 3 * qf_cu_count_cached() / 8 > 16 ? 3 * qf_cu_count_cached() / 8 : 16;
-    int item = 0;
-    for (int l = 0; l < QF_MAX_LEVELS; ++l) {
-        const int parts = (int)qf_div_up(ga.rows[l], kLdsRows);
-        int chunks = (per_level + parts / 2) / parts;
-        if (chunks < 1) chunks = 1;
-        plan.chunks[l] = chunks;
-        plan.first_item[l] = item;
-        item += parts * chunks;
-    }
-    plan.first_item[QF_MAX_LEVELS] = item;
-    const size_t lds = (size_t)kLdsRows * sizeof(float2);
-    static QfLdsAttr attr;                           // per device
-    QF_HIP_TRY(qf_ensure_dynamic_lds(attr, reinterpret_cast<const void *>(grid_backward_table_lds_kernel), lds));
-    hipLaunchKernelGGL(grid_backward_table_lds_kernel, dim3((unsigned)item), dim3(kScatterThreads), lds, st, ga, plan, x01,
-                       lm, n, grad_table);
-    QF_LAUNCH_CHECK();
+    rc = table_scatter_ws(ga, x01, dfeat, nullptr, n, grad_table, workspace, st);
+    if (rc != QF_OK) return rc;
     if (grad_x01) {
         hipLaunchKernelGGL(grid_backward_input_kernel, dim3(qf_grid_1d(n, 256)), dim3(256), 0, st, ga,
                            reinterpret_cast<const float2 *>(table), x01, dfeat, n, grad_x01);
@@ -343,7 +410,8 @@ extern "C" int qf_grid_encode_backward_ws(const qf_grid_desc *desc, const float 
 
 extern "C" int qf_grid_encode_double_backward(const qf_grid_desc *desc, const float *table, const float *x01,
                                               const float *dfeat, const float *v, int64_t n, float *g_dfeat,
-                                              float *g_x01, float *grad_table, void *stream)
+                                              float *g_x01, float *grad_table, void *workspace, int64_t workspace_bytes,
+                                              void *stream)
 {
     if (!desc || n < 0) return QF_ERR_INVALID_ARGUMENT;
     GridArgs ga;
@@ -357,9 +425,17 @@ extern "C" int qf_grid_encode_double_backward(const qf_grid_desc *desc, const fl
         QF_LAUNCH_CHECK();
     }
     if (grad_table) {
-        hipLaunchKernelGGL(grid_double_backward_table_kernel, dim3(qf_grid_1d(n * 64, 256, 32)), dim3(256), 0,
-                           qf_stream(stream), ga, x01, dfeat, v, n, grad_table);
-        QF_LAUNCH_CHECK();
+        if (workspace && n >= (1 << 15) && workspace_bytes >= qf_grid_backward_workspace_bytes(n)) {
+            rc = table_scatter_ws(ga, x01, dfeat, v, n, grad_table, workspace, qf_stream(stream));
+            if (rc != QF_OK) return rc;
+        } else {
+            LevelSel all;
+            all.n = QF_MAX_LEVELS;
+            for (int l = 0; l < QF_MAX_LEVELS; ++l) all.level[l] = (int8_t)l;
+            hipLaunchKernelGGL(grid_double_backward_table_kernel, dim3(qf_grid_1d(n * 64, 256, 32)), dim3(256), 0,
+                               qf_stream(stream), ga, all, x01, dfeat, v, n, grad_table);
+            QF_LAUNCH_CHECK();
+        }
     }
     return QF_OK;
 }

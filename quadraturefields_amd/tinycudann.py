@@ -101,9 +101,13 @@ class _GridInputGradFn(torch.autograd.Function):
         g_x = torch.empty_like(x01) if need_x else None
         g_t = torch.zeros_like(table) if need_t else None
         if n and (need_d or need_x or need_t):
+            ws, ws_bytes = None, 0
+            if need_t and n >= (1 << 15):          # large batch: the partitioned table scatter (see _C.grid_encode_backward)
+                ws_bytes = int(_C.lib().qf_grid_backward_workspace_bytes(n))
+                ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=x01.device)
             _C.check(_C.lib().qf_grid_encode_double_backward(
                 ctx.desc, _C.ptr(table), _C.ptr(x01), _C.ptr(dfeat), _C.ptr(v), n, _C.ptr(g_d), _C.ptr(g_x), _C.ptr(g_t),
-                _C.stream()), "qf_grid_encode_double_backward")
+                _C.ptr(ws), ws_bytes, _C.stream()), "qf_grid_encode_double_backward")
         return g_d, g_x, g_t, None
 
 

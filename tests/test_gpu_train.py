@@ -42,8 +42,11 @@ def test_oracle_grid_input_gradient_matches_finite_differences():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("log2_t", [12, 16])
-def test_grid_encode_backward_vs_oracle_autograd(device, log2_t):
+@pytest.mark.parametrize("log2_t,n", [(12, 3000), (16, 3000), (19, 40000), (21, 40000)])
+def test_grid_encode_backward_vs_oracle_autograd(device, log2_t, n):
+    """n = 3000: the quad-atomic scatter.  n = 40 000 (>= 2^15): the partitioned scatter -- at T = 2^19 every level takes
+    the LDS walk (<= 27 partitions), at T = 2^21 (22.6 M rows) the dense levels 0-5 take it and the hashed levels 6-15
+    (105 partitions each, above kMaxLdsParts) go to the quad atomics: both routes in one gradient."""
     from quadraturefields_amd import tinycudann as tcnn
     cfg = {"otype": "HashGrid", "n_levels": 16, "n_features_per_level": 2, "log2_hashmap_size": log2_t,
            "base_resolution": 16, "per_level_scale": 1.4472692012786865}
@@ -52,7 +55,6 @@ def test_grid_encode_backward_vs_oracle_autograd(device, log2_t):
     with torch.no_grad():
         enc.params.copy_((torch.rand(enc.params.shape, generator=g) * 2 - 1) * 0.5)
     lv = ofields.grid_levels(16, log2_t, 16, cfg["per_level_scale"])
-    n = 3000
     x = torch.rand(n, 3, generator=g).float()
     x[:8] = torch.tensor([0.0, 0.5, 1.0])[None]                       # cell faces and the box boundary
     gout = torch.randn(n, 32, generator=g).float()
@@ -401,21 +403,23 @@ def test_finetune_loop_end_to_end(device):
 
 
 @pytest.mark.gpu
-def test_field_second_order_gradients(device):
+@pytest.mark.parametrize("log2_t,n_pts", [(13, 1500), (21, 36000)])
+def test_field_second_order_gradients(device, log2_t, n_pts):
     """Field.forward(x, return_grad=True) keeps field_grad in the graph (create_graph=True, field.py:206-238); a loss
     on it (field.py:253-264) back-propagates through the second-order grid kernel.  Against double autograd through
-    the oracle: the table, the decoder and the input."""
+    the oracle: the table, the decoder and the input.  36 000 points at T = 2^21: the second-order table scatter on its
+    partitioned route (LDS walk for the levels with <= 64 partitions, quad atomics for the rest)."""
     from quadraturefields_amd import synthetic
     from quadraturefields_amd.field import Field
-    f = Field(scale=1.5, back_prop=1, log2_T=13, L=16, max_res=512, hidden_size=32, nl="relu")
+    f = Field(scale=1.5, back_prop=1, log2_T=log2_t, L=16, max_res=512, hidden_size=32, nl="relu")
     f.load_state_dict(synthetic.seeded_deform_state(f.xyz_encoder.grid.n_params), strict=False)
     wts = helpers.oracle_deform_weights(f)
     wts.table = _leaf(wts.table)
     wts.layers = [(_leaf(w), _leaf(b)) for w, b in wts.layers]
     f = f.to(device)
-    x, d = helpers.random_points(1500, aabb_half=1.4, seed=12, outside_frac=0.0)
+    x, d = helpers.random_points(n_pts, aabb_half=1.4, seed=12, outside_frac=0.0)
     g = torch.Generator().manual_seed(4)
-    w1, w2 = torch.rand(1500, generator=g), torch.rand(1500, generator=g)
+    w1, w2 = torch.rand(n_pts, generator=g), torch.rand(n_pts, generator=g)
 
     def loss_fn(field, grad, mod, w1, w2, d):
         return mod.compute_field_loss(w1, w2, grad, d) + 0.1 * mod.compute_abs_loss(grad) + 0.01 * field.sum()
@@ -660,3 +664,46 @@ def test_lds_partitioned_table_scatter_equals_the_atomic_one(device):
         scale = float(ga.abs().max())
         assert scale > 0 and float((ga - gb).abs().max()) <= 2e-5 * max(scale, 1.0)
         assert int((ga != 0).sum()) == int((gb != 0).sum()) or n < (1 << 15)
+
+
+@pytest.mark.gpu
+def test_fused_adam_is_torch_adam(device):
+    """quadraturefields_amd.optim.Adam against torch.optim.Adam (the reference's optimiser, train_finetune.py:402-417):
+    same parameters after six steps -- incl. a step with an all-zero gradient (dense Adam keeps moving along the
+    momentum) and a parameter that received no gradient -- to rounding; the state dicts are interchangeable."""
+    from quadraturefields_amd.optim import Adam
+    g = torch.Generator().manual_seed(0)
+    shapes = [(1000003,), (64, 35), (7,)]
+    for kwargs in (dict(lr=1e-2, eps=1e-15), dict(lr=3e-3, betas=(0.8, 0.99), eps=1e-8, weight_decay=0.01)):
+        init = [torch.randn(s, generator=g) for s in shapes]
+        pa = [torch.nn.Parameter(t.clone().to(device)) for t in init]
+        pb = [torch.nn.Parameter(t.clone().to(device)) for t in init]
+        oa, ob = Adam(pa, **kwargs), torch.optim.Adam(pb, **kwargs)
+        for it in range(6):
+            for i, (a, b) in enumerate(zip(pa, pb)):
+                if i == 2 and it % 2:                      # no gradient this step: both optimisers skip the tensor
+                    a.grad = b.grad = None
+                    continue
+                gr = torch.randn(a.shape, generator=g).to(device) * (0.0 if it == 3 else 1.0)
+                gr[::7] = 0.0                              # untouched rows
+                a.grad, b.grad = gr.clone(), gr.clone()
+            oa.step()
+            ob.step()
+        for a, b in zip(pa, pb):
+            assert torch.allclose(a, b, rtol=2e-6, atol=1e-7), float((a - b).abs().max())
+        sa, sb = oa.state_dict(), ob.state_dict()
+        assert sa["state"].keys() == sb["state"].keys()
+        for k in sa["state"]:
+            assert set(sa["state"][k]) == {"step", "exp_avg", "exp_avg_sq"} == set(sb["state"][k])
+            assert float(sa["state"][k]["step"]) == float(sb["state"][k]["step"])
+            assert torch.allclose(sa["state"][k]["exp_avg"], sb["state"][k]["exp_avg"], rtol=2e-6, atol=1e-6)
+            assert torch.allclose(sa["state"][k]["exp_avg_sq"], sb["state"][k]["exp_avg_sq"], rtol=2e-6, atol=1e-7)
+        ob.load_state_dict(sa)                             # a checkpoint of one loads into the other
+        oa.load_state_dict(ob.state_dict())
+        for a, b in zip(pa, pb):
+            a.grad = b.grad = torch.ones_like(a)
+        oa.step(); ob.step()
+        for a, b in zip(pa, pb):
+            assert torch.allclose(a, b, rtol=2e-6, atol=1e-7)
+    with pytest.raises(NotImplementedError):
+        Adam(pa, amsgrad=True)
