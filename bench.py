@@ -153,11 +153,12 @@ class Stages:
         return {k: (float(reduce([a.elapsed_time(b) for a, b in v])) if v else None) for k, v in self.ev.items()}
 
 
-def cpu_baseline(mesh, field, cam_o, cam_d, crop=600):
+def cpu_baseline(mesh, field, cam_o, cam_d, crop=600, single_crop=160):
     """The oracle (CPU restatement of the reference path) timed on this box's host cores on a bounded sample: the
     centre crop x crop pixels of frame 0 through multi-hit intersection on the oracle's host BVH (OpenMP C; the
     reference walks Embree's BVH on the CPU, mesh_utils.py:350-354), torch-CPU field evaluation and compositing.
-    The intersection and the field + compositing legs are reported separately."""
+    The intersection and the field + compositing legs are reported separately.  SURVEY.md 8(d) asks for n = cores AND
+    n = 1: the same path on ONE thread (a smaller centre crop, same BVH) rides along as ``single_core``."""
     from oracle import meshpath as om
     from tests import helpers
     cores = om.host_cores()
@@ -175,15 +176,48 @@ def cpu_baseline(mesh, field, cam_o, cam_d, crop=600):
     rgb = om.render_image_finetune(wts, None, data, crop * crop)[0]
     t2 = time.perf_counter()
     n_pts = data[0].shape[0]
+    # n = 1: one OpenMP thread, one torch thread, on the centre single_crop x single_crop pixels
+    ys = xs = (W - single_crop) // 2
+    idx1 = (torch.arange(ys, ys + single_crop)[:, None] * W + torch.arange(xs, xs + single_crop)[None, :]).reshape(-1)
+    o1, d1 = cam_o[idx1].numpy(), cam_d[idx1].numpy()
+    torch.set_num_threads(1)
+    s0 = time.perf_counter()
+    sample1 = om.sampling_raytrace_numpy(_OneThread(bvh), d1, o1, MAX_HITS)
+    s1 = time.perf_counter()
+    data1 = om.to_loader_tensors(sample1)
+    om.render_image_finetune(wts, None, data1, single_crop * single_crop)
+    s2 = time.perf_counter()
+    torch.set_num_threads(cores)
+    single = {"value": single_crop * single_crop / (s2 - s0), "unit": "rays/s", "cores": 1,
+              "intersection_rays_per_s": single_crop * single_crop / max(s1 - s0, 1e-9),
+              "field_composite_points_per_s": data1[0].shape[0] / max(s2 - s1, 1e-9),
+              "sample": f"centre {single_crop}x{single_crop} crop of frame 0, {data1[0].shape[0]} quadrature points, one thread"}
     return {
         "value": crop * crop / (t2 - t0), "unit": "rays/s", "cores": cores, "kind": "port",
         "intersection_rays_per_s": crop * crop / max(t1 - t0, 1e-9),
         "field_composite_points_per_s": n_pts / max(t2 - t1, 1e-9),
-        "host_bvh_build_s": t0 - tb,
+        "host_bvh_build_s": t0 - tb, "single_core": single,
         "sample": f"centre {crop}x{crop} crop of frame 0 ({crop * crop} rays, {n_pts} quadrature points): multi-hit "
                   f"intersection on the oracle's host BVH over {mesh.faces.shape[0]} triangles {t1 - t0:.2f} s (OpenMP C, "
                   f"{cores} threads; BVH build {t0 - tb:.1f} s, not counted) + torch-CPU field/compositing {t2 - t1:.2f} s",
     }, rgb, idx, (np.asarray(sample[2]), np.asarray(sample[4]))
+
+
+class _OneThread:
+    """The oracle's host BVH intersector with its OpenMP team pinned to one thread (cpu_baseline's n = 1 leg)."""
+
+    def __init__(self, inner):
+        self._inner = inner
+
+    def intersects_id(self, origins, vectors, multiple_hits=True, return_locations=True, max_hits=10):
+        inner = self._inner
+        run = inner._run
+        inner._run = lambda o, d, n, k, n_threads, tri, t, cnt: run(o, d, n, k, 1, tri, t, cnt)
+        try:
+            return inner.intersects_id(origins, vectors, multiple_hits=multiple_hits, return_locations=return_locations,
+                                       max_hits=max_hits)
+        finally:
+            inner._run = run
 
 
 def _min_sep(mesh):

@@ -23,7 +23,7 @@ __device__ __forceinline__ void adam_one(float &p, float g, float &m, float &v, 
     if (a.maximize) g = -g;
     if (a.weight_decay != 0.0f) g = g + a.weight_decay * p;
     m = m + (1.0f - a.beta1) * (g - m);                       // exp_avg.lerp_(grad, 1 - beta1)
-    v = v * a.beta2 + (1.0f - a.beta2) * (g * g);             // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value = 1 - beta2)
+    v = v * a.beta2 + ((1.0f - a.beta2) * g) * g;             // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value = 1 - beta2)
     const float denom = sqrtf(v) / a.bias_correction2_sqrt + a.eps;
     const float step_size = a.lr / a.bias_correction1;
     p = p + (-step_size) * (m / denom);                       // param.addcdiv_(exp_avg, denom, value = -step_size)

@@ -115,6 +115,9 @@ class RayIntersector:
         self.mesh = mesh
         self.max_hits = int(max_hits)
         self.device = torch.device(device)
+        # "trimesh": the separation follows the mesh -- trimesh derives it from the CURRENT mesh's extent, so it is
+        # recomputed whenever the vertices are updated (update_intersector)
+        self._min_separation_auto = isinstance(min_separation, str)
         if min_separation is None:
             min_separation = 0.0
         elif isinstance(min_separation, str):
@@ -187,9 +190,17 @@ class RayIntersector:
         if core.mesh.faces.shape[0] != self.mesh.faces.shape[0] or core.device != self.device:
             raise ValueError("inter: the new intersector must hold the same triangles on the same device")
         self._handle, core._handle = core._handle, self._handle       # ours is destroyed with ``new``
-        self.set_min_separation(self.min_separation)
+        if self._min_separation_auto:
+            self._apply_min_separation(trimesh_ray_offset(core.mesh.vertices))     # follows the adopted mesh's extent
+        else:
+            self._apply_min_separation(self.min_separation)
 
     def set_min_separation(self, min_separation: float) -> None:
+        """A fixed distance (or 0): from now on the separation no longer follows the mesh's extent."""
+        self._min_separation_auto = False
+        self._apply_min_separation(min_separation)
+
+    def _apply_min_separation(self, min_separation: float) -> None:
         self.min_separation = max(float(min_separation or 0.0), 0.0)
         _C.check(_C.lib().qf_bvh_set_min_separation(self._handle, self.min_separation), "qf_bvh_set_min_separation")
 
@@ -199,6 +210,16 @@ class RayIntersector:
         intersector's device is refitted ON the device, stream-ordered (``qf_bvh_refit_device``: no D2H / host refit /
         H2D round trip in the training loop); host arrays take the host refit."""
         n_tri = self.mesh.faces.shape[0]
+        if self._min_separation_auto:
+            # trimesh's re-origin distance is 1e-4 * 100 / (bounding-box diagonal of the mesh it intersects): it moves
+            # with the vertices (ADVICE r2).  Only the extent is needed: two small reductions for a device tensor.
+            if isinstance(vertices, torch.Tensor):
+                vv = vertices.detach().reshape(-1, 3)
+                ext = torch.stack([vv.min(dim=0).values, vv.max(dim=0).values]).double().cpu().numpy()
+            else:
+                vv = np.asarray(vertices, dtype=np.float64).reshape(-1, 3)
+                ext = np.stack([vv.min(axis=0), vv.max(axis=0)])
+            self._apply_min_separation(trimesh_ray_offset(ext))
         if isinstance(vertices, torch.Tensor) and vertices.is_cuda:
             v = vertices.detach().to(device=self.device, dtype=torch.float32)
             if v.numel() == n_tri * 9 and tuple(v.shape) != tuple(self.mesh.vertices.shape):

@@ -772,3 +772,28 @@ def test_filter_hits_applies_the_rule_in_place(device):
     _C.check(_C.lib().qf_filter_hits(ri._handle, n, k, _C.ptr(torch.from_numpy(tri.copy()).to(device)), _C.ptr(d2),
                                      _C.ptr(torch.from_numpy(cnt.copy()).to(device)), _C.stream()), "qf_filter_hits")
     assert torch.equal(d2.cpu(), torch.from_numpy(t))                    # rule off: untouched
+
+
+@pytest.mark.gpu
+def test_trimesh_separation_follows_the_mesh_on_refit(device):
+    """trimesh derives its re-origin distance from the extent of the mesh it currently intersects (1e-4 * 100 / bounding
+    box diagonal): the default ``"trimesh"`` separation is recomputed when the vertices are updated (device and host
+    refit, and the replaced ``inter`` object of train_finetune.py:716-718); a fixed distance stays fixed."""
+    from quadraturefields_amd import synthetic
+    from quadraturefields_amd.intersector import Intersector
+    from quadraturefields_amd.mesh_utils import MeshIntersection, trimesh_ray_offset
+    mesh = synthetic.shell_mesh(n_shells=2, subdivisions=2)
+    mi = MeshIntersection(mesh, simplify_mesh=False, scale=1.0, num_intersections=8, device=device)
+    ri = mi.rayintersector
+    s0 = trimesh_ray_offset(mesh.vertices)
+    assert ri.min_separation == pytest.approx(s0, rel=1e-12)
+    v2 = torch.from_numpy(mesh.vertices.astype(np.float32)).to(device) * 2.0
+    ri.update_intersector(v2)                                           # device refit
+    assert ri.min_separation == pytest.approx(s0 / 2.0, rel=1e-6)
+    ri.update_intersector(mesh.vertices.astype(np.float32) * 4.0)       # host refit
+    assert ri.min_separation == pytest.approx(s0 / 4.0, rel=1e-6)
+    ri.inter = Intersector((mesh.vertices[mesh.faces] * 0.5).reshape(-1), 8, 0)
+    assert ri.min_separation == pytest.approx(s0 * 2.0, rel=1e-6)
+    ri.set_min_separation(1e-3)                                         # a fixed distance no longer follows
+    ri.update_intersector(v2)
+    assert ri.min_separation == 1e-3
