@@ -396,6 +396,18 @@ int qf_raster_intersect_wide(qf_bvh *bvh, const qf_camera *cam /* host */, const
                              const float *rays_d, int64_t n_rays, int32_t max_hits, int32_t wide_hits,
                              int32_t *wide_tri, float *wide_t, int32_t *hit_tri, float *hit_t, int32_t *hit_count,
                              int32_t *overflow, int32_t cull_chunks, void *stream);
+/* qf_raster_intersect_wide without collecting every crossing: the triangle chunks are binned by distance from the camera
+ * into n_slabs (2..16) slabs of equal thickness and rasterised nearest slab first, one launch per slab; a hit is
+ * accepted by the pass of the slab its t falls into, and a pixel that already holds (selection capacity + 1)
+ * candidates when a pass starts is skipped -- its list is a complete depth prefix that contains its K nearest.  The
+ * candidate lists are 8-byte keys (t bits << 32 | tri), wide_keys [wide_hits, n_rays] slot-major; wide_hits only has to
+ * exceed the selection capacity by one slab's worth of crossings (not 4K).  Same result as qf_raster_intersect_wide:
+ * hit_tri / hit_t [n_rays, max_hits] hold each ray's K nearest under (t, tri) in arrival order, rays that lost
+ * candidates keep hit_count > max_hits for qf_bvh_repair_overflow.  For unit-length camera rays (qf_generate_rays).
+ * One stream per handle, as with cull_chunks.                                                          */
+int qf_raster_intersect_slabs(qf_bvh *bvh, const qf_camera *cam /* host */, const float *rays_o, const float *rays_d,
+                              int64_t n_rays, int32_t max_hits, int32_t wide_hits, int32_t n_slabs, uint64_t *wide_keys,
+                              int32_t *hit_tri, float *hit_t, int32_t *hit_count, int32_t *overflow, void *stream);
 /* The fall-back, per ray: after qf_raster_intersect with sort_lists = 0 (raw counts), re-traverses exactly the rays
  * with hit_count > max_hits through the BVH (exact K nearest under the handle's min_separation rule; their lists and
  * counts are overwritten, in the layout of qf_bvh_intersect) and leaves every other ray's list alone.  No host round

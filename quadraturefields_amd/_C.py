@@ -107,6 +107,7 @@ _SIGNATURES = {
     "qf_bvh_repair_overflow": (c_int, [_P, _P, _P, c_int64, c_int32, c_int32, _P, _P, _P, _P, _P, _P]),
     "qf_raster_intersect": (c_int, [_P, POINTER(Camera), _P, _P, c_int64, c_int32, _P, _P, _P, _P, c_int32, c_int32, _P]),
     "qf_raster_intersect_wide": (c_int, [_P, POINTER(Camera), _P, _P, c_int64, c_int32, c_int32, _P, _P, _P, _P, _P, _P, c_int32, _P]),
+    "qf_raster_intersect_slabs": (c_int, [_P, POINTER(Camera), _P, _P, c_int64, c_int32, c_int32, c_int32, _P, _P, _P, _P, _P, _P]),
     "qf_grid_march_count": (c_int, [POINTER(c_float), POINTER(c_int32), _P, _P, _P, _P, _P, c_int64, c_float, c_float,
                                     c_float, _P, _P]),
     "qf_grid_march_write": (c_int, [POINTER(c_float), POINTER(c_int32), _P, _P, _P, _P, _P, c_int64, c_float, c_float,

@@ -40,6 +40,12 @@ struct qf_bvh {
     int32_t *d_visible = nullptr;
     bool chunk_dirty = true;         // the triangles changed (build / refit): boxes are recomputed before the next use
     int cull_parity = 0;
+    // depth-slab pass (qf_raster_intersect_slabs): per-chunk distance range, per-slab chunk lists, control block
+    float *d_slab_range = nullptr;
+    int32_t *d_slab_lists = nullptr;
+    void *d_slab_ctl = nullptr;
+    int32_t *d_slab_snapshot = nullptr;   // the pixels' counts at the start of a slab pass
+    int64_t slab_snapshot_rays = 0;
     int64_t n_tri = 0;
     int64_t n_nodes = 0;             // binary build tree
     int64_t n_nodes8 = 0;            // wide tree

@@ -527,6 +527,10 @@ extern "C" void qf_bvh_destroy(qf_bvh *bvh)
     if (bvh->d_tris) (void)hipFree(bvh->d_tris);
     if (bvh->d_chunk_box) (void)hipFree(bvh->d_chunk_box);
     if (bvh->d_visible) (void)hipFree(bvh->d_visible);
+    if (bvh->d_slab_range) (void)hipFree(bvh->d_slab_range);
+    if (bvh->d_slab_lists) (void)hipFree(bvh->d_slab_lists);
+    if (bvh->d_slab_ctl) (void)hipFree(bvh->d_slab_ctl);
+    if (bvh->d_slab_snapshot) (void)hipFree(bvh->d_slab_snapshot);
     delete bvh;
 }
 

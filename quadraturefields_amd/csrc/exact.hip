@@ -549,11 +549,22 @@ constexpr float kRasterGuard = 0.25f;
 
 // kWide: the lists are [slot][ray] (capacity max_hits = the wide capacity), for select_nearest_kernel's coalesced reads.
 // One triangle against the pixels of its screen box, lane ``sub`` of kRasterLanes (the body of both raster kernels).
-template <int kRasterLanes, bool kWide>
+// kSlab (depth-slab pass, raster_slab_kernel): only hits with slab.t_lo <= t < slab.t_hi are accepted, a pixel that
+// already holds slab.stop_at candidates is skipped before its ray is even loaded, and a candidate is ONE 8-byte key
+// (t bits << 32 | tri) in slab.keys [capacity][n_rays].
+struct SlabArgs {
+    float t_lo, t_hi;
+    int stop_at;
+    uint64_t *keys;
+    const int32_t *count_before;     // the pixels' counts when this slab's pass started (NULL for the first slab)
+};
+
+template <int kRasterLanes, bool kWide, bool kSlab = false>
 __device__ __forceinline__ void raster_triangle(const float4 *__restrict__ tris, int64_t tri_i, int sub, const RasterCam &cam,
                                                 const float *__restrict__ rays_o, const float *__restrict__ rays_d,
                                                 int max_hits, int32_t *__restrict__ hit_tri, float *__restrict__ hit_t,
-                                                int32_t *__restrict__ hit_count, int32_t *__restrict__ overflow)
+                                                int32_t *__restrict__ hit_count, int32_t *__restrict__ overflow,
+                                                const SlabArgs slab = SlabArgs())
 {
     const float4 a = tris[tri_i * 3 + 0], b = tris[tri_i * 3 + 1], c = tris[tri_i * 3 + 2];
     const int id = __float_as_int(a.w);
@@ -624,10 +635,20 @@ __device__ __forceinline__ void raster_triangle(const float4 *__restrict__ tris,
                 continue;
         }
         const int64_t ray = (int64_t)cy_ * cam.w + cx_;
+        // the pixel's K nearest are all in nearer slabs.  Decided on the count the pixel had when this pass STARTED: the
+        // live count also moves with this slab's own hits, and stopping on it would keep an arbitrary subset of them
+        if (kSlab && slab.count_before && slab.count_before[ray] >= slab.stop_at) continue;
         const float ox = rays_o[ray * 3], oy = rays_o[ray * 3 + 1], oz = rays_o[ray * 3 + 2];
         const float dx = rays_d[ray * 3], dy = rays_d[ray * 3 + 1], dz = rays_d[ray * 3 + 2];
         float t;
         if (!mt_hit(a, b, c, ox, oy, oz, dx, dy, dz, &t)) continue;
+        if (kSlab) {
+            if (!(t >= slab.t_lo && t < slab.t_hi)) continue;       // this hit belongs to another slab's pass
+            const int slot = atomicAdd(&hit_count[ray], 1);
+            if (slot < max_hits) slab.keys[(int64_t)slot * ((int64_t)cam.w * cam.h) + ray] = hit_key(t, id);
+            else atomicAdd(overflow, 1);
+            continue;
+        }
         const int slot = atomicAdd(&hit_count[ray], 1);
         if (slot < max_hits) {
             const int64_t at = kWide ? (int64_t)slot * ((int64_t)cam.w * cam.h) + ray : ray * max_hits + slot;
@@ -742,6 +763,137 @@ __global__ __launch_bounds__(256) void raster_culled_kernel(const float4 *__rest
     }
 }
 
+// ---- depth slabs for dense scenes (BASELINE configs[2]: 36 thin shells, up to 72 crossings per ray, K = 25).  The wide
+// pass above collects EVERY crossing of a ray (up to 4K slots, one returning atomic + a scattered write each) only for
+// the selection to drop three quarters of them.  Here the visible triangle chunks are binned by their distance from the
+// camera into n_slabs slabs of equal thickness (a chunk goes to every slab its distance range touches), the slabs are
+// rasterised NEAREST FIRST in separate launches, a hit is accepted only by the pass of the slab its t falls into, and a
+// pixel that holds stop_at candidates when a pass starts is skipped by it: all its hits nearer than this slab are
+// already in its list -- a complete depth prefix -- and they are enough.  Exact: the slab passes partition the hits by t
+// (edges computed by the same expression everywhere), a chunk's slabs cover the t of every hit it can produce (unit
+// camera rays: t is the distance from the camera centre; 0.1 % margin), and stop_at = selection capacity + 1 keeps
+// "the prefix was the whole list" distinguishable in select_nearest_kernel.  A pixel still overshoots by the hits of
+// the slab in which it crosses stop_at, so the candidate lists need stop_at + (crossings per slab) slots, not 4K.
+constexpr int kMaxSlabs = 16;
+
+struct SlabCtl {                       // device control block of one frame
+    uint32_t dist_min_bits, dist_max_bits;     // over the visible chunks; positive floats order like their bit patterns
+    int32_t n_visible;
+    int32_t slab_count[kMaxSlabs];
+};
+
+__device__ __forceinline__ void slab_range(const SlabCtl *ctl, int n_slabs, float *lo, float *width)
+{
+    const float dmin = __uint_as_float(ctl->dist_min_bits) * 0.999f, dmax = __uint_as_float(ctl->dist_max_bits) * 1.001f;
+    *lo = dmin;
+    *width = fmaxf(dmax - dmin, 1e-12f) / (float)n_slabs;
+}
+
+// [edge(j), edge(j+1)) in t; the first slab has no lower and the last no upper bound
+__device__ __forceinline__ void slab_edges(const SlabCtl *ctl, int n_slabs, int j, float *t_lo, float *t_hi)
+{
+#pragma clang fp contract(off)
+    float lo, w;
+    slab_range(ctl, n_slabs, &lo, &w);
+    *t_lo = j == 0 ? -INFINITY : lo + (float)j * w;
+    *t_hi = j == n_slabs - 1 ? INFINITY : lo + (float)(j + 1) * w;
+}
+
+// cull_chunks_kernel + every visible chunk's distance range from the camera centre
+__global__ void slab_cull_kernel(const float4 *__restrict__ boxes, int n_chunks, RasterCam cam, int32_t *__restrict__ visible,
+                                 float2 *__restrict__ range, SlabCtl *ctl)
+{
+    const int chunk = blockIdx.x * blockDim.x + threadIdx.x;
+    if (chunk >= n_chunks) return;
+    const float4 lo = boxes[chunk * 2], hi = boxes[chunk * 2 + 1];
+    if (!(lo.x <= hi.x)) return;
+    float minx = INFINITY, maxx = -INFINITY, miny = INFINITY, maxy = -INFINITY;
+    bool keep = false;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const float dx = ((k & 1) ? hi.x : lo.x) - cam.cx, dy = ((k & 2) ? hi.y : lo.y) - cam.cy, dz = ((k & 4) ? hi.z : lo.z) - cam.cz;
+        const float xc = cam.r00 * dx + cam.r10 * dy + cam.r20 * dz;
+        const float yc = cam.r01 * dx + cam.r11 * dy + cam.r21 * dz;
+        const float zc = cam.r02 * dx + cam.r12 * dy + cam.r22 * dz;
+        const float zv = -zc;
+        if (!(zv > 1e-4f)) { keep = true; continue; }
+        const float sx = cam.fx * (xc / zv) + cam.px0, sy = -cam.fy * (yc / zv) + cam.py0;
+        minx = fminf(minx, sx); maxx = fmaxf(maxx, sx);
+        miny = fminf(miny, sy); maxy = fmaxf(maxy, sy);
+    }
+    const float g = kRasterGuard + 1.0f;
+    if (!keep)
+        keep = (maxx + g >= 0.0f) && (maxy + g >= 0.0f) && (minx - g <= (float)(cam.w - 1)) && (miny - g <= (float)(cam.h - 1));
+    if (!keep) return;
+    // nearest and farthest point of the box from the camera centre
+    const float nx = fmaxf(fmaxf(lo.x - cam.cx, cam.cx - hi.x), 0.0f), ny = fmaxf(fmaxf(lo.y - cam.cy, cam.cy - hi.y), 0.0f);
+    const float nz = fmaxf(fmaxf(lo.z - cam.cz, cam.cz - hi.z), 0.0f);
+    const float fx = fmaxf(fabsf(lo.x - cam.cx), fabsf(hi.x - cam.cx)), fy = fmaxf(fabsf(lo.y - cam.cy), fabsf(hi.y - cam.cy));
+    const float fz = fmaxf(fabsf(lo.z - cam.cz), fabsf(hi.z - cam.cz));
+    const float dmin = sqrtf(nx * nx + ny * ny + nz * nz) * 0.9999f, dmax = sqrtf(fx * fx + fy * fy + fz * fz) * 1.0001f + 1e-30f;
+    visible[atomicAdd(&ctl->n_visible, 1)] = chunk;
+    range[chunk] = make_float2(dmin, dmax);
+    atomicMin(&ctl->dist_min_bits, __float_as_uint(dmin));
+    atomicMax(&ctl->dist_max_bits, __float_as_uint(dmax));
+}
+
+// Every visible chunk goes to the slabs its distance range [dmin, dmax] (margins included) touches: j with
+// edge(j+1) > dmin and edge(j) <= dmax -- decided by comparing with the EDGES the passes bin their hits by, so the
+// assignment is a superset of the slabs a chunk's hits can fall into without a slab of slack either side (a first
+// version added one: every chunk was rasterised three times).  The per-slab list positions are allotted per workgroup
+// (LDS counters, one global atomic per slab and workgroup): 46 000 chunks on eight global counters took 1.4 ms.
+__global__ __launch_bounds__(256) void slab_assign_kernel(const int32_t *__restrict__ visible, const float2 *__restrict__ range,
+                                                          SlabCtl *ctl, int n_slabs, int n_chunks, int32_t *__restrict__ lists)
+{
+    __shared__ int s_cnt[kMaxSlabs], s_base[kMaxSlabs];
+    if (threadIdx.x < kMaxSlabs) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    int chunk = -1, j0 = 0, j1 = -1;
+    if (e < ctl->n_visible) {
+        chunk = visible[e];
+        const float2 r = range[chunk];
+        const float dlo = r.x * 0.999f, dhi = r.y * 1.001f;
+        j0 = n_slabs;
+        for (int j = 0; j < n_slabs; ++j) {
+            float t_lo, t_hi;
+            slab_edges(ctl, n_slabs, j, &t_lo, &t_hi);
+            if (t_hi > dlo && t_lo <= dhi) { j0 = j < j0 ? j : j0; j1 = j; }
+        }
+        for (int j = j0; j <= j1; ++j) atomicAdd(&s_cnt[j], 1);
+    }
+    __syncthreads();
+    if (threadIdx.x < n_slabs) s_base[threadIdx.x] = s_cnt[threadIdx.x] ? atomicAdd(&ctl->slab_count[threadIdx.x], s_cnt[threadIdx.x]) : 0;
+    __syncthreads();
+    for (int j = j0; j <= j1; ++j) lists[(int64_t)j * n_chunks + atomicAdd(&s_base[j], 1)] = chunk;
+}
+
+template <int kRasterLanes>
+__global__ __launch_bounds__(256) void raster_slab_kernel(const float4 *__restrict__ tris, int64_t n_tri, RasterCam cam,
+                                                          const float *__restrict__ rays_o, const float *__restrict__ rays_d,
+                                                          int capacity, uint64_t *__restrict__ keys, int32_t *__restrict__ hit_count,
+                                                          int32_t *__restrict__ overflow, const int32_t *__restrict__ list,
+                                                          const SlabCtl *__restrict__ ctl, int slab_j, int n_slabs, int stop_at,
+                                                          const int32_t *__restrict__ count_before)
+{
+    constexpr int kTrisPerBlock = 256 / kRasterLanes;
+    constexpr int kBlocksPerChunk = kCullChunk / kTrisPerBlock;
+    const int n_items = ctl->slab_count[slab_j] * kBlocksPerChunk;
+    SlabArgs sa;
+    slab_edges(ctl, n_slabs, slab_j, &sa.t_lo, &sa.t_hi);
+    sa.stop_at = stop_at;
+    sa.keys = keys;
+    sa.count_before = count_before;
+    const int sub = threadIdx.x % kRasterLanes;
+    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+        const int chunk = list[item / kBlocksPerChunk];
+        const int64_t tri_i = (int64_t)chunk * kCullChunk + (item % kBlocksPerChunk) * kTrisPerBlock + threadIdx.x / kRasterLanes;
+        if (tri_i < n_tri)
+            raster_triangle<kRasterLanes, true, true>(tris, tri_i, sub, cam, rays_o, rays_d, capacity, nullptr, nullptr,
+                                                      hit_count, overflow, sa);
+    }
+}
+
 // Dense scenes (more than K candidates on most rays): the camera-coherent pass collects up to `wide` candidates per
 // ray in [slot][ray] lists, and this kernel keeps each ray's K nearest under (t, tri) -- the rule of
 // bvh_traverse_kernel -- in the ordinary [ray][K] lists (arrival order; qf_pack_samples sorts).  lane = ray, its K
@@ -754,9 +906,12 @@ __host__ __device__ inline int select_capacity(int max_hits, int wide, float min
     const int cap = min_sep > 0.0f ? max_hits + kSelectHeadroom : max_hits;
     return cap < wide ? cap : wide;
 }
+// kKeys: the candidates are 8-byte keys (t bits << 32 | tri) in wide_key [wide][n_rays] (the depth-slab pass).
+template <bool kKeys>
 __global__ __launch_bounds__(kSelectBlock) void select_nearest_kernel(int64_t n_rays, int wide, int max_hits, float min_sep,
                                                                       const int32_t *__restrict__ wide_tri,
                                                                       const float *__restrict__ wide_t,
+                                                                      const uint64_t *__restrict__ wide_key,
                                                                       int32_t *__restrict__ hit_tri, float *__restrict__ hit_t,
                                                                       int32_t *__restrict__ hit_count)
 {
@@ -772,8 +927,14 @@ __global__ __launch_bounds__(kSelectBlock) void select_nearest_kernel(int64_t n_
     int32_t *row_i = hit_tri + r * max_hits;
     if (cnt <= max_hits) {
         for (int i = 0; i < cnt; ++i) {
-            row_t[i] = wide_t[(int64_t)i * n_rays + r];
-            row_i[i] = wide_tri[(int64_t)i * n_rays + r];
+            if (kKeys) {
+                const uint64_t k = wide_key[(int64_t)i * n_rays + r];
+                row_t[i] = key_t(k);
+                row_i[i] = key_id(k);
+            } else {
+                row_t[i] = wide_t[(int64_t)i * n_rays + r];
+                row_i[i] = wide_tri[(int64_t)i * n_rays + r];
+            }
         }
         return;
     }
@@ -792,8 +953,14 @@ __global__ __launch_bounds__(kSelectBlock) void select_nearest_kernel(int64_t n_
 #pragma unroll
         for (int u = 0; u < kBatch; ++u) {
             const int i = i0 + u < cnt ? i0 + u : cnt - 1;
-            tb[u] = wide_t[(int64_t)i * n_rays + r];
-            ib[u] = wide_tri[(int64_t)i * n_rays + r];
+            if (kKeys) {
+                const uint64_t k = wide_key[(int64_t)i * n_rays + r];
+                tb[u] = key_t(k);
+                ib[u] = key_id(k);
+            } else {
+                tb[u] = wide_t[(int64_t)i * n_rays + r];
+                ib[u] = wide_tri[(int64_t)i * n_rays + r];
+            }
         }
 #pragma unroll
         for (int u = 0; u < kBatch; ++u) {
@@ -2012,6 +2179,42 @@ extern "C" int qf_texture_shade_points(const uint8_t *records, int32_t texture_s
     return QF_OK;
 }
 
+static RasterCam make_raster_cam(const qf_camera *cam)
+{
+    RasterCam rc;
+    const float *m = cam->c2w;     // row-major 3x4
+    rc.r00 = m[0]; rc.r01 = m[1]; rc.r02 = m[2]; rc.cx = m[3];
+    rc.r10 = m[4]; rc.r11 = m[5]; rc.r12 = m[6]; rc.cy = m[7];
+    rc.r20 = m[8]; rc.r21 = m[9]; rc.r22 = m[10]; rc.cz = m[11];
+    rc.fx = cam->fx; rc.fy = cam->fy;
+    rc.px0 = cam->cx - 0.5f;       // camera_dir.x = (x - cx + 0.5) / fx
+    rc.py0 = cam->cy - 0.5f;
+    rc.w = cam->width; rc.h = cam->height;
+    return rc;
+}
+
+// chunk boxes of the handle's triangles (allocated on first use, recomputed after a build / refit)
+static int ensure_chunk_boxes(qf_bvh *bvh, hipStream_t st)
+{
+    const int64_t n_chunks = qf_div_up(bvh->n_tri, kCullChunk);
+    if (n_chunks > 0x3fffffff) return QF_ERR_UNSUPPORTED;
+    if (!bvh->d_chunk_box) {
+        QF_HIP_TRY(hipMalloc((void **)&bvh->d_chunk_box, (size_t)n_chunks * 2 * sizeof(float4)));
+        QF_HIP_TRY(hipMalloc((void **)&bvh->d_visible, (size_t)(n_chunks + 2) * sizeof(int32_t)));
+        QF_HIP_TRY(hipMemsetAsync(bvh->d_visible, 0, 2 * sizeof(int32_t), st));        // the two counters
+        bvh->chunk_dirty = true;
+        bvh->cull_parity = 0;
+    }
+    if (bvh->chunk_dirty) {
+        hipLaunchKernelGGL(chunk_boxes_kernel, dim3((unsigned)qf_div_up(n_chunks * 64, 256)), dim3(256), 0, st,
+                           reinterpret_cast<const float4 *>(bvh->d_tris), bvh->n_tri, (int)n_chunks,
+                           reinterpret_cast<float4 *>(bvh->d_chunk_box));
+        QF_LAUNCH_CHECK();
+        bvh->chunk_dirty = false;
+    }
+    return QF_OK;
+}
+
 static int raster_launch(qf_bvh *bvh, const qf_camera *cam, const float *rays_o, const float *rays_d, int64_t n_rays,
                          int capacity, bool wide, int32_t *hit_tri, float *hit_t, int32_t *hit_count, int32_t *overflow,
                          bool cull, hipStream_t st)
@@ -2022,15 +2225,7 @@ static int raster_launch(qf_bvh *bvh, const qf_camera *cam, const float *rays_o,
         QF_HIP_TRY(hipMemsetAsync(hit_count, 0, (size_t)n_rays * sizeof(int32_t), st));
         QF_HIP_TRY(hipMemsetAsync(overflow, 0, sizeof(int32_t), st));
     }
-    RasterCam rc;
-    const float *m = cam->c2w;     // row-major 3x4
-    rc.r00 = m[0]; rc.r01 = m[1]; rc.r02 = m[2]; rc.cx = m[3];
-    rc.r10 = m[4]; rc.r11 = m[5]; rc.r12 = m[6]; rc.cy = m[7];
-    rc.r20 = m[8]; rc.r21 = m[9]; rc.r22 = m[10]; rc.cz = m[11];
-    rc.fx = cam->fx; rc.fy = cam->fy;
-    rc.px0 = cam->cx - 0.5f;       // camera_dir.x = (x - cx + 0.5) / fx
-    rc.py0 = cam->cy - 0.5f;
-    rc.w = cam->width; rc.h = cam->height;
+    const RasterCam rc = make_raster_cam(cam);
     if (bvh->n_tri > 0) {
         // Lanes per triangle: the per-triangle set-up (projection, edge equations) is replicated in every lane, so few
         // lanes win for pixel-sized triangles (measured on the 983 040-triangle 800x800 frame: 1/2/4/8 lanes ->
@@ -2043,22 +2238,10 @@ static int raster_launch(qf_bvh *bvh, const qf_camera *cam, const float *rays_o,
         if (cull) {
             // chunk boxes (once per build / refit), the visible-chunk list of this camera, then a resident grid over it
             const int64_t n_chunks = qf_div_up(bvh->n_tri, kCullChunk);
-            if (n_chunks > 0x3fffffff) return QF_ERR_UNSUPPORTED;
-            if (!bvh->d_chunk_box) {
-                QF_HIP_TRY(hipMalloc((void **)&bvh->d_chunk_box, (size_t)n_chunks * 2 * sizeof(float4)));
-                QF_HIP_TRY(hipMalloc((void **)&bvh->d_visible, (size_t)(n_chunks + 2) * sizeof(int32_t)));
-                QF_HIP_TRY(hipMemsetAsync(bvh->d_visible, 0, 2 * sizeof(int32_t), st));        // the two counters
-                bvh->chunk_dirty = true;
-                bvh->cull_parity = 0;
-            }
+            const int rc_boxes = ensure_chunk_boxes(bvh, st);
+            if (rc_boxes != QF_OK) return rc_boxes;
             const float4 *tris4 = reinterpret_cast<const float4 *>(bvh->d_tris);
             float4 *boxes = reinterpret_cast<float4 *>(bvh->d_chunk_box);
-            if (bvh->chunk_dirty) {
-                hipLaunchKernelGGL(chunk_boxes_kernel, dim3((unsigned)qf_div_up(n_chunks * 64, 256)), dim3(256), 0, st, tris4,
-                                   bvh->n_tri, (int)n_chunks, boxes);
-                QF_LAUNCH_CHECK();
-                bvh->chunk_dirty = false;
-            }
             int32_t *counters = bvh->d_visible, *visible = bvh->d_visible + 2;
             const int parity = bvh->cull_parity;
             bvh->cull_parity ^= 1;
@@ -2147,8 +2330,94 @@ extern "C" int qf_raster_intersect_wide(qf_bvh *bvh, const qf_camera *cam, const
     if (rc != QF_OK) return rc;
     if (n_rays == 0) return QF_OK;
     const size_t lds = (size_t)select_capacity(max_hits, wide_hits, bvh->min_sep) * kSelectBlock * 2 * sizeof(float);
-    hipLaunchKernelGGL(select_nearest_kernel, dim3((unsigned)qf_div_up(n_rays, kSelectBlock)), dim3(kSelectBlock), lds, st,
-                       n_rays, (int)wide_hits, (int)max_hits, bvh->min_sep, wide_tri, wide_t, hit_tri, hit_t, hit_count);
+    hipLaunchKernelGGL(select_nearest_kernel<false>, dim3((unsigned)qf_div_up(n_rays, kSelectBlock)), dim3(kSelectBlock), lds, st,
+                       n_rays, (int)wide_hits, (int)max_hits, bvh->min_sep, wide_tri, wide_t, (const uint64_t *)nullptr, hit_tri,
+                       hit_t, hit_count);
+    QF_LAUNCH_CHECK();
+    return QF_OK;
+}
+
+namespace {
+__global__ void slab_init_kernel(SlabCtl *ctl)
+{
+    ctl->dist_min_bits = 0x7f800000u;      // +inf
+    ctl->dist_max_bits = 0u;
+    ctl->n_visible = 0;
+    for (int j = 0; j < kMaxSlabs; ++j) ctl->slab_count[j] = 0;
+}
+}  // namespace
+
+extern "C" int qf_raster_intersect_slabs(qf_bvh *bvh, const qf_camera *cam, const float *rays_o, const float *rays_d,
+                                         int64_t n_rays, int32_t max_hits, int32_t wide_hits, int32_t n_slabs,
+                                         uint64_t *wide_keys, int32_t *hit_tri, float *hit_t, int32_t *hit_count,
+                                         int32_t *overflow, void *stream)
+{
+    if (!raster_args_ok(bvh, cam, n_rays, max_hits)) return QF_ERR_INVALID_ARGUMENT;
+    if (n_slabs < 2 || n_slabs > kMaxSlabs) return QF_ERR_INVALID_ARGUMENT;
+    const int sel_cap = select_capacity(max_hits, wide_hits, bvh->min_sep);
+    if (wide_hits <= sel_cap + 1 || wide_hits > 4096) return QF_ERR_INVALID_ARGUMENT;     // room beyond stop_at for one slab's hits
+    if (!rays_o || !rays_d || !wide_keys || !hit_tri || !hit_t || !hit_count || !overflow) return QF_ERR_INVALID_ARGUMENT;
+    hipStream_t st = qf_stream(stream);
+    if (overflow == hit_count + n_rays) {
+        QF_HIP_TRY(hipMemsetAsync(hit_count, 0, (size_t)(n_rays + 1) * sizeof(int32_t), st));
+    } else {
+        QF_HIP_TRY(hipMemsetAsync(hit_count, 0, (size_t)n_rays * sizeof(int32_t), st));
+        QF_HIP_TRY(hipMemsetAsync(overflow, 0, sizeof(int32_t), st));
+    }
+    if (n_rays == 0 || bvh->n_tri == 0) return QF_OK;
+    const int rc_boxes = ensure_chunk_boxes(bvh, st);
+    if (rc_boxes != QF_OK) return rc_boxes;
+    const int64_t n_chunks = qf_div_up(bvh->n_tri, kCullChunk);
+    if (!bvh->d_slab_range) {
+        QF_HIP_TRY(hipMalloc((void **)&bvh->d_slab_range, (size_t)n_chunks * sizeof(float2)));
+        QF_HIP_TRY(hipMalloc((void **)&bvh->d_slab_lists, (size_t)n_chunks * kMaxSlabs * sizeof(int32_t)));
+        QF_HIP_TRY(hipMalloc((void **)&bvh->d_slab_ctl, sizeof(SlabCtl)));
+    }
+    const RasterCam rc = make_raster_cam(cam);
+    const float4 *tris4 = reinterpret_cast<const float4 *>(bvh->d_tris);
+    const float4 *boxes = reinterpret_cast<const float4 *>(bvh->d_chunk_box);
+    int32_t *visible = bvh->d_visible + 2;
+    float2 *range = reinterpret_cast<float2 *>(bvh->d_slab_range);
+    SlabCtl *ctl = reinterpret_cast<SlabCtl *>(bvh->d_slab_ctl);
+    hipLaunchKernelGGL(slab_init_kernel, dim3(1), dim3(1), 0, st, ctl);
+    hipLaunchKernelGGL(slab_cull_kernel, dim3((unsigned)qf_div_up(n_chunks, 256)), dim3(256), 0, st, boxes, (int)n_chunks, rc,
+                       visible, range, ctl);
+    hipLaunchKernelGGL(slab_assign_kernel, dim3((unsigned)qf_div_up(n_chunks, 256)), dim3(256), 0, st, visible, range, ctl,
+                       (int)n_slabs, (int)n_chunks, bvh->d_slab_lists);
+    QF_LAUNCH_CHECK();
+    const int64_t pixels_per_tri = n_rays / bvh->n_tri;
+    const int lanes = pixels_per_tri > 64 ? 16 : (pixels_per_tri > 8 ? 8 : 4);
+    const int64_t items = n_chunks * (kCullChunk * lanes / 256);
+    const int64_t cap = (int64_t)qf_cu_count_cached() * 8;
+    const unsigned grid = (unsigned)(items < cap ? items : cap);
+    const int stop_at = sel_cap + 1;
+    // the counts at the start of each pass: one device-to-device copy between the passes (4 B per ray)
+    if (bvh->slab_snapshot_rays < n_rays) {
+        if (bvh->d_slab_snapshot) (void)hipFree(bvh->d_slab_snapshot);
+        bvh->d_slab_snapshot = nullptr;
+        QF_HIP_TRY(hipMalloc((void **)&bvh->d_slab_snapshot, (size_t)n_rays * sizeof(int32_t)));
+        bvh->slab_snapshot_rays = n_rays;
+    }
+    int32_t *snapshot = bvh->d_slab_snapshot;
+    for (int j = 0; j < n_slabs; ++j) {
+        if (j > 0) QF_HIP_TRY(hipMemcpyAsync(snapshot, hit_count, (size_t)n_rays * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+        const int32_t *list = bvh->d_slab_lists + (int64_t)j * n_chunks;
+#define QF_RASTER_SLAB(L)                                                                                              \
+    hipLaunchKernelGGL((raster_slab_kernel<L>), dim3(grid), dim3(256), 0, st, tris4, bvh->n_tri, rc, rays_o, rays_d,    \
+                       (int)wide_hits, wide_keys, hit_count, overflow, list, ctl, j, (int)n_slabs, stop_at,               \
+                       j == 0 ? (const int32_t *)nullptr : snapshot)
+        switch (lanes) {
+        case 16: QF_RASTER_SLAB(16); break;
+        case 8: QF_RASTER_SLAB(8); break;
+        default: QF_RASTER_SLAB(4); break;
+        }
+#undef QF_RASTER_SLAB
+    }
+    QF_LAUNCH_CHECK();
+    const size_t lds = (size_t)sel_cap * kSelectBlock * 2 * sizeof(float);
+    hipLaunchKernelGGL(select_nearest_kernel<true>, dim3((unsigned)qf_div_up(n_rays, kSelectBlock)), dim3(kSelectBlock), lds, st,
+                       n_rays, (int)wide_hits, (int)max_hits, bvh->min_sep, (const int32_t *)nullptr, (const float *)nullptr,
+                       wide_keys, hit_tri, hit_t, hit_count);
     QF_LAUNCH_CHECK();
     return QF_OK;
 }

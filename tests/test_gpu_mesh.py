@@ -279,18 +279,23 @@ def test_raster_intersector_identical_to_bvh(device, w, h, max_hits):
         assert torch.equal(x, y)
 
 
-@pytest.mark.parametrize("k,wide", [(5, 24), (5, 7), (5, 0), (64, 128)])
-def test_wide_raster_selects_the_k_nearest_like_the_bvh(device, k, wide):
-    """Dense shells (most rays meet more than K triangles): qf_raster_intersect_wide keeps the K nearest of up to `wide`
-    candidates; rays beyond `wide` (wide = 7) are repaired through the BVH; wide = 0: the policy switches it on by itself
-    after the first heavily overflowing frame; K = 64: the largest LDS footprint of the selection kernel (nothing
-    overflows).  Packed samples identical to the BVH path every time."""
+@pytest.mark.parametrize("k,wide,slabs,room", [(5, 24, 0, 32), (5, 7, 0, 32), (5, 0, 0, 32), (64, 128, 0, 32),
+                                               (5, 24, 8, 32), (5, 24, 2, 32), (5, 24, 16, 1), (5, 0, 8, 32), (64, 128, 5, 32)])
+def test_wide_raster_selects_the_k_nearest_like_the_bvh(device, k, wide, slabs, room):
+    """Dense shells (most rays meet more than K triangles).  slabs = 0: qf_raster_intersect_wide keeps the K nearest of up
+    to `wide` candidates; rays beyond `wide` (wide = 7) are repaired through the BVH; wide = 0: the policy switches the
+    dense mode on by itself after the first heavily overflowing frame; K = 64: the largest LDS footprint of the
+    selection kernel (nothing overflows).  slabs > 0: qf_raster_intersect_slabs -- the chunks rasterised in depth slabs,
+    nearest first, a pixel stops accepting candidates once it holds K + 8 + 1; room = 1: a single slot beyond that, so
+    pixels overflow inside a slab and are repaired through the BVH.  Packed samples identical to the BVH path every
+    time."""
     from quadraturefields_amd import synthetic
     from quadraturefields_amd.mesh_utils import RayIntersector, make_camera
     mesh = _scene(3, 8)
     w, h = 72, 56
     ri = RayIntersector(mesh, max_hits=k)
     ri.raster_wide = wide
+    ri.raster_slabs, ri.SLAB_ROOM = slabs, room
     brute = om.BruteForceIntersector(mesh.vertices, mesh.faces)
     for seed in (1, 5, 9):
         c2w = synthetic.orbit_cameras(1, seed=seed)[0]
