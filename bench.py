@@ -139,6 +139,20 @@ class Stages:
             return self.frame(*frame_in, record)
         return rgb, alpha, depth, ri.frame_samples() if layout is not None else index_ray.shape[0]
 
+    def frame_nowait(self, o, d, cam, record=False):
+        """A whole frame WITHOUT a host wait (DESIGN.md sections 3.1 / 6): the sample count stays on the device -- the tile
+        pack leaves it next to the tile bases, the field kernel reads it there -- so nothing between the rays and the
+        pixels returns to the host.  The frame's point count is NOT reported (last element 0): bench.py counts the points
+        of the timed frames afterwards, by rendering them once more through ``frame`` (the count is a property of the
+        frame, not of the timing).  Same pixels as ``frame``."""
+        from quadraturefields_amd import utils
+        ri = self.mi.rayintersector
+        frame = self._timed("traverse", lambda: ri.sample_frame_device(o, d, MAX_HITS, cam), record)
+        _, xyz_c, dirs_c = ri.last_layout
+        rgbs, sigmas = self._timed("field", lambda: self.field(xyz_c, dirs_c, n_device=frame.total_dev), record)
+        rgb, alpha, depth, _ = self._timed("composite", lambda: utils.composite_frame(rgbs, sigmas, frame, STEP), record)
+        return rgb, alpha, depth, 0
+
     def _pack(self, hits):
         """(tools/field_bench.py) hits = (hit_tri, hit_t, hit_count, overflow, o, d) -> packed samples; sets .order."""
         hit_tri, hit_t, hit_count, overflow, o, d = hits
@@ -577,6 +591,9 @@ def main():
                          "Measured in round 2: 1.98 ms/frame against 1.87 -- the field kernel runs 1.80 ms instead of 1.32 "
                          "beside the next frame's atomics and streaming writes (it is bound by the memory system, and so "
                          "are they); round 1's whole-frame pipelining lost 4-5 %% for the same reason")
+    ap.add_argument("--host-wait", action="store_true",
+                    help="round-2 frame: the host waits for every frame's sample count before it launches the field kernel "
+                         "(default since round 3: the count stays on the device, no wait -- 1.650 -> 1.628 ms per frame)")
     ap.add_argument("--no-gather", action="store_true",
                     help="N > 1: do not all_gather the finished frames of the frame-parallel loop")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -621,6 +638,7 @@ def main():
     # compositing (~1.4 ms) run on another; the field kernels of consecutive frames never overlap each other.
     front, back = torch.cuda.Stream(device=device), torch.cuda.Stream(device=device)
     ri0 = mi.rayintersector
+    nowait = not args.host_wait and args.intersector == "raster" and args.pipeline == 1
 
     def run(first, last, record):
         """Frames [first, last); returns (last rgb, total points).  N > 1: every finished frame is all-gathered to
@@ -639,7 +657,16 @@ def main():
                 pending = (torch.distributed.all_gather_into_tensor(gather_bufs[i & 1], mine, async_op=True), mine)
             pts += n_pts
 
-        if args.pipeline == 1:
+        if args.pipeline == 1 and nowait:
+            for i in range(first, last):
+                rgb, alpha, depth, _ = stages.frame_nowait(rays[i][0], rays[i][1], cameras[i], record)
+                if gather:
+                    mine = torch.cat([rgb, alpha, depth], dim=1)
+                    mine = mine.cpu() if staged else mine
+                    if pending is not None:
+                        pending[0].wait()
+                    pending = (torch.distributed.all_gather_into_tensor(gather_bufs[i & 1], mine, async_op=True), mine)
+        elif args.pipeline == 1:
             for i in range(first, last):
                 complete(stages.begin(rays[i][0], rays[i][1], cameras[i], record), i)
         else:
@@ -680,6 +707,9 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     log(f"timed region done: {elapsed:.3f} s for {args.steps} steps")
+    if nowait:              # the no-wait frames do not report their point counts: count the same frames now, untimed
+        pts = sum(stages.frame(rays[i][0], rays[i][1], cameras[i])[3] for i in range(args.warmup, n_frames))
+        torch.cuda.synchronize()
     t = torch.tensor([elapsed, float(pts)], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
     if world > 1:
         tmax = t.clone()
@@ -756,6 +786,7 @@ def main():
             "overflow_repaired_frames": mi.rayintersector.repaired_frames,
             "reorigin_rule_redone_frames": mi.rayintersector.rule_redone_frames,
             "frames_in_flight": args.pipeline,
+            "host_wait_per_frame": not nowait,
             "parallelism": f"{world} rank(s), the frames dealt round-robin to the ranks, one frame per rank per step"
                            + (", all_gather_into_tensor of the finished frames" if gather else ", no data-path collective"),
         },
