@@ -577,7 +577,8 @@ int qf_resort_by_depth(const int64_t *index_ray, const float *depth, int64_t n, 
 
 /* The whole of sampling_indexing (mesh_utils.py:389-412) in one launch: the re-sort above, the gathers of
  * points / depth / origins / vectors / index_tri through the permutation (index_ray is unchanged by a within-ray
- * sort) and kaolin's mark_pack_boundaries (:407).  perm and boundary may be NULL.
+ * sort) and kaolin's mark_pack_boundaries (:407).  perm and boundary may be NULL; so may out_origins / out_index_tri
+ * (with their inputs): a caller that only renders reads neither (utils.py:574-577 discards both).
  * inverse (or NULL; from qf_split_layout / qf_coherent_layout on the same index_ray): the launch also writes the
  * re-sorted positions and directions a second time at out_points_c / out_vectors_c [inverse[i]] -- the copies
  * qf_field_forward streams (see qf_pack_samples).                                                 */

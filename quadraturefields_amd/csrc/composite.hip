@@ -801,7 +801,14 @@ __global__ void split_rays_kernel(const int64_t *__restrict__ index_ray, int64_t
         bad |= (r < 0) | (r >= n_rays) | (i + 1 < n && index_ray[i + 1] < r);
     }
     if (bad) atomicOr(invalid, 1);
+    // a window of a frame holds a quarter of its rays: everything before the first id / behind the last is empty
+    const int64_t r_first = n > 0 ? index_ray[0] : n_rays, r_last = n > 0 ? index_ray[n - 1] : -1;
     for (int64_t r = t0; r <= n_rays; r += stride) {
+        if (r < r_first || r > r_last) {             // (ids out of order are caught above; the layout is then the identity)
+            ray_offset[r] = r < r_first ? 0 : n;
+            if (r < n_rays) hit_count[r] = 0;
+            continue;
+        }
         int64_t lo = 0, hi = n;                      // first i with index_ray[i] >= r
         while (lo < hi) {
             const int64_t mid = (lo + hi) >> 1;

@@ -1502,11 +1502,11 @@ __global__ __launch_bounds__(RS_THREADS) void resort_samples_kernel(
                     const int64_t dst = i + rank;
                     if (perm) perm[dst] = q;
                     out_depth[dst] = dq;
-                    out_index_tri[dst] = index_tri[q];
+                    if (out_index_tri) out_index_tri[dst] = index_tri[q];
                     const int64_t pos_c = inverse ? (int64_t)inverse[dst] : 0;
                     for (int c = 0; c < 3; ++c) {
                         out_points[dst * 3 + c] = points[q * 3 + c];
-                        out_origins[dst * 3 + c] = origins[q * 3 + c];
+                        if (out_origins) out_origins[dst * 3 + c] = origins[q * 3 + c];
                         out_vectors[dst * 3 + c] = vectors[q * 3 + c];
                         if (inverse) {
                             out_points_c[pos_c * 3 + c] = points[q * 3 + c];
@@ -1522,7 +1522,7 @@ __global__ __launch_bounds__(RS_THREADS) void resort_samples_kernel(
             const int64_t src = b0 + s_src[k], dst = b0 + k;
             if (perm) perm[dst] = src;
             out_depth[dst] = s_depth[s_src[k]];
-            out_index_tri[dst] = index_tri[src];
+            if (out_index_tri) out_index_tri[dst] = index_tri[src];
         }
         for (int e = threadIdx.x; e < 3 * staged; e += RS_THREADS) {
             const int k = e / 3, c = e - 3 * k;
@@ -1530,7 +1530,7 @@ __global__ __launch_bounds__(RS_THREADS) void resort_samples_kernel(
             const int64_t src = (b0 + s_src[k]) * 3 + c, dst = b0 * 3 + e;
             const float pv = points[src], vv = vectors[src];
             out_points[dst] = pv;
-            out_origins[dst] = origins[src];
+            if (out_origins) out_origins[dst] = origins[src];
             out_vectors[dst] = vv;
             if (inverse) {                            // second copy at the sample's place in the coherent order
                 const int64_t pc = (int64_t)inverse[b0 + k] * 3 + c;
@@ -2066,8 +2066,8 @@ extern "C" int qf_resort_samples(const int64_t *index_ray, const float *depth, i
 {
     if (n < 0) return QF_ERR_INVALID_ARGUMENT;
     if (n == 0) return QF_OK;
-    if (!index_ray || !depth || !points || !origins || !vectors || !index_tri || !out_points || !out_depth ||
-        !out_origins || !out_vectors || !out_index_tri || (inverse && (!out_points_c || !out_vectors_c)))
+    if (!index_ray || !depth || !points || !vectors || !out_points || !out_depth || !out_vectors ||
+        (out_origins && !origins) || (out_index_tri && !index_tri) || (inverse && (!out_points_c || !out_vectors_c)))
         return QF_ERR_INVALID_ARGUMENT;
     const int64_t n_chunks = (n + RS_CHUNK - 1) / RS_CHUNK;
     hipLaunchKernelGGL(resort_samples_kernel, dim3((unsigned)(n_chunks < 65536 ? n_chunks : 65536)), dim3(RS_THREADS), 0,

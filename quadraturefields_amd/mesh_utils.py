@@ -877,14 +877,17 @@ class MeshIntersection:
         xyz, dirs, index_ray, depth, index_tri, org = [t.cpu().numpy() for t in out]
         return xyz, dirs, index_ray, depth, index_tri, 0, org
 
-    def sampling_indexing(self, points, origins, vectors, index_ray, depth, index_tri, random=0, layout_inverse=None):
+    def sampling_indexing(self, points, origins, vectors, index_ray, depth, index_tri, random=0, layout_inverse=None,
+                          lean=False):
         """Re-sort by (ray, depth) after deformation, boundaries, deltas -- mesh_utils.py:389-412, without
         leaving the device.  Inference: ONE launch (``qf_resort_samples``: sort, gathers and boundaries fused).
         When autograd is recording on the inputs (training) the permutation is applied with differentiable
         indexing instead.
         ``layout_inverse`` (extension, inference only; from ``RayIntersector.split_layout`` on the same ``index_ray``):
         the launch also writes the re-sorted positions / directions in the coherent order; they are left in
-        ``self.last_resort_layout = (points_c, vectors_c)`` (the return value keeps the reference's 8-tuple)."""
+        ``self.last_resort_layout = (points_c, vectors_c)`` (the return value keeps the reference's 8-tuple).
+        ``lean`` (extension, inference only): the caller reads neither the re-sorted origins nor the re-sorted triangle ids
+        (``render_image_finetune_with_occgrid`` discards both, utils.py:574-577): they are not produced (None in the tuple)."""
         self.last_resort_layout = None
         index_ray = _C.i64c(index_ray)
         n = depth.shape[0]
@@ -898,10 +901,14 @@ class MeshIntersection:
             points, depth, origins, vectors = (_permute_rows(t, perm) for t in (points, depth, origins, vectors))
             boundary = spc_render.mark_pack_boundaries(index_ray)
             return points, self.find_deltas(boundary, depth), boundary, vectors, index_ray, depth, index_tri, origins
-        points, depth, origins, vectors = (_C.f32c(t.detach()) for t in (points, depth, origins, vectors))
-        index_tri = _C.i64c(index_tri)
-        o_points, o_origins, o_vectors = torch.empty_like(points), torch.empty_like(origins), torch.empty_like(vectors)
-        o_depth, o_tri = torch.empty_like(depth), torch.empty_like(index_tri)
+        points, depth, vectors = (_C.f32c(t.detach()) for t in (points, depth, vectors))
+        if lean:
+            origins = index_tri = o_origins = o_tri = None
+        else:
+            origins, index_tri = _C.f32c(origins.detach()), _C.i64c(index_tri)
+            o_origins, o_tri = torch.empty_like(origins), torch.empty_like(index_tri)
+        o_points, o_vectors = torch.empty_like(points), torch.empty_like(vectors)
+        o_depth = torch.empty_like(depth)
         boundary = torch.empty((n,), dtype=torch.bool, device=dev)
         points_c = vectors_c = None
         if layout_inverse is not None:

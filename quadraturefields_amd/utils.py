@@ -301,7 +301,7 @@ def render_image_finetune_with_occgrid(
     # scaling == 0 multiplies the displacement by zero in the reference (utils.py:566-571): skipping is exact.
     if auto_inverse is not None:
         points, deltas, boundary, dirs, index_ray, depth, index_tri_s, _ = mesh_intersect.sampling_indexing(
-            xyzs, origins, dirs, index_ray, ts, index_tri, layout_inverse=auto_inverse)
+            xyzs, origins, dirs, index_ray, ts, index_tri, layout_inverse=auto_inverse, lean=True)
     else:
         points, deltas, boundary, dirs, index_ray, depth, index_tri_s, _ = mesh_intersect.sampling_indexing(
             xyzs, origins, dirs, index_ray, ts, index_tri)

@@ -9,10 +9,10 @@ R=$GRAFT_REPO_ROOT
 D=$R/gpurun_out/$OUT
 mkdir -p $D
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $D/trace -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-configs --scenes 0 > $D/bench.json 2> $D/bench.err || echo "trace pass failed"
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $D/trace -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-configs --no-reference-route --scenes 0 > $D/bench.json 2> $D/bench.err || echo "trace pass failed"
 cp $(find $D/trace -name "*kernel_stats.csv" | head -1) $D/kernel_stats.csv
 for C in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 10 400 rocprofv3 --pmc $C --output-format csv -d $D/pmc_$C -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-configs --scenes 0 > $D/pmc_$C.json 2> $D/pmc_$C.err || echo "pmc pass $C failed"
+  timeout -k 10 400 rocprofv3 --pmc $C --output-format csv -d $D/pmc_$C -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-configs --no-reference-route --scenes 0 > $D/pmc_$C.json 2> $D/pmc_$C.err || echo "pmc pass $C failed"
 done
 python3 $R/tools/traffic_json.py $D > $D/field_traffic.json
 cat $D/field_traffic.json
