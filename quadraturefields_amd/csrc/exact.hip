@@ -2231,6 +2231,8 @@ static int raster_launch(qf_bvh *bvh, const qf_camera *cam, const float *rays_o,
         // lanes win for pixel-sized triangles (measured on the 983 040-triangle 800x800 frame: 1/2/4/8 lanes ->
         // 0.33/0.25/0.22/0.23 ms); meshes that are coarse relative to the image get more lanes per triangle.
         const int64_t pixels_per_tri = n_rays / bvh->n_tri;
+        // (a band's pass is latency-, not throughput-bound, but more lanes per triangle did not help it either: N = 8 band
+        // 0.35 / 0.37 / 0.36 ms with 4 / 8 / 16 lanes)
         const int lanes = pixels_per_tri > 64 ? 16 : (pixels_per_tri > 8 ? 8 : 4);
         const int64_t threads = bvh->n_tri * lanes;
         const int64_t blocks = qf_div_up(threads, 256);

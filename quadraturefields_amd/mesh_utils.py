@@ -106,6 +106,10 @@ class RayIntersector:
     """Multi-hit ray/mesh intersector.  Duck-types trimesh's ``RayMeshIntersector`` and the reference's OptiX
     adapter (``intersects_id``, ``update_intersector``; mesh_utils.py:75-109).
 
+    Ray directions: the re-origin distance is compared with the ray PARAMETER ``t``, which is a world-space distance only
+    for unit directions -- what every loader of the path hands over (``viewdirs`` are normalised, nerf_synthetic.py:366;
+    trimesh unitises the directions itself before it offsets).  A caller with non-unit ``vectors`` gets a threshold that
+    is off by ``|d|``; normalise first.
     ``min_separation``: the reference's multi-hit rule (``qf_bvh_set_min_separation``): ``"trimesh"`` (default) =
     ``trimesh_ray_offset(mesh.vertices)``, a float = that distance, ``0`` / ``None`` = every hit counts."""
 
