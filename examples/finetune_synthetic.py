@@ -75,7 +75,8 @@ def main():
             pixels = FrameRenderer(mesh_intersect, reference).render(o, d, camera=make_camera(c2w, focal, w, h))[0]
             views.append((c2w, o, d, pixels))
 
-    optimizer = torch.optim.Adam(list(radiance_field.parameters()) + list(field_net.parameters()), lr=2e-3, eps=1e-15)
+    from quadraturefields_amd.optim import Adam          # torch.optim.Adam's update, one launch per tensor
+    optimizer = Adam(list(radiance_field.parameters()) + list(field_net.parameters()), lr=2e-3, eps=1e-15)
     render_bkgd = torch.ones(3, device=dev)
 
     def evaluate(scaling):

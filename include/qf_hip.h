@@ -214,10 +214,11 @@ int qf_deform_mlp_backward(const float *enc, const float *x01, const float *d_ou
  * parameter tensor, in ONE launch: the update of torch's foreach implementation element for element --
  *   m += (1-b1)(g-m); v = v b2 + (1-b2) g g; p += -(lr/(1-b1^t)) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
  * (weight_decay: g += wd p first; maximize: g = -g) -- where torch issues eleven launches and seven passes.  step = t,
- * counted from 1.  All four arrays 16-byte aligned.  Values agree with torch to rounding (each operation individually
+ * counted from 1.  The hyper-parameters come as doubles: the derived scalars (1 - b1, 1 - b2, the step size, the bias
+ * correction) are evaluated in double as torch's Python does and rounded to fp32 once.  All four arrays 16-byte aligned.  Values agree with torch to rounding (each operation individually
  * rounded here; torch's kernels leave contraction to the compiler).                                    */
-int qf_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, float lr, float beta1,
-                 float beta2, float eps, float weight_decay, int32_t maximize, int64_t step, void *stream);
+int qf_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, double lr, double beta1,
+                 double beta2, double eps, double weight_decay, int32_t maximize, int64_t step, void *stream);
 
 /* xyz_out = xyz + dh, ts_out = ts + dd with dd = tanh(f)*scaling*(1,1,1) . dir and dh = dd * dir (utils.py:566-571,
  * every operation rounded on its own as the reference's tensor ops are).  In place when xyz_out == xyz / ts_out == ts.

@@ -73,7 +73,7 @@ _SIGNATURES = {
     "qf_sg_features_to_rgb_backward": (c_int, [_P, c_int64, _P, _P, c_int64, c_int32, _P, c_int64, _P]),
     "qf_deform_field_forward": (c_int, [POINTER(GridDesc), _P, c_float, c_int32, _P, _P, _P, _P, _P, _P, _P, c_int64, _P, _P, _P, _P, _P]),
     "qf_deform_mlp_backward": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
-    "qf_adam_step": (c_int, [_P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_float, c_int32, c_int64, _P]),
+    "qf_adam_step": (c_int, [_P, _P, _P, _P, c_int64, c_double, c_double, c_double, c_double, c_double, c_int32, c_int64, _P]),
     "qf_apply_deformation": (c_int, [_P, c_float, _P, _P, _P, c_int64, _P, _P, _P, _P]),
     "qf_mark_pack_boundaries": (c_int, [_P, c_int64, _P, _P]),
     "qf_exponential_integration": (c_int, [_P, c_int32, _P, _P, c_int64, c_int64, c_int32, _P, _P, _P]),

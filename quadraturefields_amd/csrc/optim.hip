@@ -11,9 +11,12 @@
 
 namespace {
 
+// Every scalar is evaluated on the host in DOUBLE, as torch's Python does, and rounded to fp32 once: 1 - beta2 computed in
+// fp32 from the fp32 beta2 (0.999) is off by 1.3e-5 relative, which shows in exp_avg_sq after a few steps.
 struct AdamArgs {
-    float lr, beta1, beta2, eps, weight_decay;
-    float bias_correction1, bias_correction2_sqrt;   // 1 - beta1^t, sqrt(1 - beta2^t), evaluated on the host in double
+    float beta2, eps, weight_decay;
+    float one_minus_beta1, one_minus_beta2;          // lerp weight, addcmul value
+    float neg_step_size, bias_correction2_sqrt;      // -lr / (1 - beta1^t), sqrt(1 - beta2^t)
     int maximize;
 };
 
@@ -22,11 +25,10 @@ __device__ __forceinline__ void adam_one(float &p, float g, float &m, float &v, 
 #pragma clang fp contract(off)
     if (a.maximize) g = -g;
     if (a.weight_decay != 0.0f) g = g + a.weight_decay * p;
-    m = m + (1.0f - a.beta1) * (g - m);                       // exp_avg.lerp_(grad, 1 - beta1)
-    v = v * a.beta2 + ((1.0f - a.beta2) * g) * g;             // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value = 1 - beta2)
+    m = m + a.one_minus_beta1 * (g - m);                      // exp_avg.lerp_(grad, 1 - beta1)
+    v = v * a.beta2 + (a.one_minus_beta2 * g) * g;            // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value = 1 - beta2)
     const float denom = sqrtf(v) / a.bias_correction2_sqrt + a.eps;
-    const float step_size = a.lr / a.bias_correction1;
-    p = p + (-step_size) * (m / denom);                       // param.addcdiv_(exp_avg, denom, value = -step_size)
+    p = p + a.neg_step_size * (m / denom);                    // param.addcdiv_(exp_avg, denom, value = -step_size)
 }
 
 __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m,
@@ -53,20 +55,22 @@ __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const 
 
 }  // namespace
 
-extern "C" int qf_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, float lr,
-                            float beta1, float beta2, float eps, float weight_decay, int32_t maximize, int64_t step,
+extern "C" int qf_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, double lr,
+                            double beta1, double beta2, double eps, double weight_decay, int32_t maximize, int64_t step,
                             void *stream)
 {
-    if (n < 0 || step < 1 || !(beta1 >= 0.0f && beta1 < 1.0f) || !(beta2 >= 0.0f && beta2 < 1.0f)) return QF_ERR_INVALID_ARGUMENT;
+    if (n < 0 || step < 1 || !(beta1 >= 0.0 && beta1 < 1.0) || !(beta2 >= 0.0 && beta2 < 1.0)) return QF_ERR_INVALID_ARGUMENT;
     if (n == 0) return QF_OK;
     if (!param || !grad || !exp_avg || !exp_avg_sq) return QF_ERR_INVALID_ARGUMENT;
     if ((reinterpret_cast<uintptr_t>(param) | reinterpret_cast<uintptr_t>(grad) | reinterpret_cast<uintptr_t>(exp_avg) |
          reinterpret_cast<uintptr_t>(exp_avg_sq)) & 15)
         return QF_ERR_INVALID_ARGUMENT;                   // float4 accesses
     AdamArgs a;
-    a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.weight_decay = weight_decay; a.maximize = maximize ? 1 : 0;
-    a.bias_correction1 = (float)(1.0 - pow((double)beta1, (double)step));
-    a.bias_correction2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
+    a.beta2 = (float)beta2; a.eps = (float)eps; a.weight_decay = (float)weight_decay; a.maximize = maximize ? 1 : 0;
+    a.one_minus_beta1 = (float)(1.0 - beta1);
+    a.one_minus_beta2 = (float)(1.0 - beta2);
+    a.neg_step_size = (float)(-(lr / (1.0 - pow(beta1, (double)step))));
+    a.bias_correction2_sqrt = (float)sqrt(1.0 - pow(beta2, (double)step));
     hipLaunchKernelGGL(adam_kernel, dim3(qf_grid_1d((n + 3) / 4, 256, 16)), dim3(256), 0, qf_stream(stream), param, grad,
                        exp_avg, exp_avg_sq, n, a);
     QF_LAUNCH_CHECK();

@@ -696,10 +696,11 @@ def test_fused_adam_is_torch_adam(device):
         for k in sa["state"]:
             assert set(sa["state"][k]) == {"step", "exp_avg", "exp_avg_sq"} == set(sb["state"][k])
             assert float(sa["state"][k]["step"]) == float(sb["state"][k]["step"])
-            assert torch.allclose(sa["state"][k]["exp_avg"], sb["state"][k]["exp_avg"], rtol=1e-5, atol=1e-6)
-            assert torch.allclose(sa["state"][k]["exp_avg_sq"], sb["state"][k]["exp_avg_sq"], rtol=1e-5, atol=1e-7)
-        ob.load_state_dict(sa)                             # a checkpoint of one loads into the other
-        oa.load_state_dict(ob.state_dict())
+            assert torch.allclose(sa["state"][k]["exp_avg"], sb["state"][k]["exp_avg"], rtol=2e-6, atol=1e-6)
+            assert torch.allclose(sa["state"][k]["exp_avg_sq"], sb["state"][k]["exp_avg_sq"], rtol=2e-6, atol=1e-8)
+        import copy                                        # (load_state_dict does not copy tensors that already have the
+        ob.load_state_dict(copy.deepcopy(sa))              #  right dtype / device: without the deepcopy both optimisers
+        oa.load_state_dict(copy.deepcopy(ob.state_dict())) #  would share -- and update twice -- one set of moments)
         for a, b in zip(pa, pb):
             a.grad = b.grad = torch.ones_like(a)
         oa.step(); ob.step()
