@@ -430,6 +430,23 @@ def reference_route_line(device, scene, frames=10, warm=3, texture_size=4096, lo
 
     after_ms, after_pts = timed(lambda i: finetune_frame(i, 0.0))
     before_ms, before_pts = timed(lambda i: finetune_frame(i, 0.0434))
+    # the scripts evaluate at up_sample 2 (run_nerfsynthetic_finetune.sh:9): 1600x1600 rays per item, 16 windows, then the
+    # INTER_AREA down-sample of train_finetune.py:624-627 (a 2x2 box average)
+    from quadraturefields_amd.render import area_downsample
+    ds1, n_rays1 = ds, n_rays
+    ds = SubjectLoader.from_arrays(images[:6], cams[:6], synthetic.lego_focal(W), split="test", mesh_intersect=mi,
+                                   device=device, upsample=2)
+
+    def up2_frame(i):
+        rgb, depth, pts = finetune_frame(i % 6, 0.0)
+        area_downsample(rgb.reshape(2 * H, 2 * W, 3), 2)
+        area_downsample(depth.reshape(2 * H, 2 * W), 2)
+        return rgb, depth, pts
+
+    frames1, warm1, n1 = frames, warm, n
+    frames, warm, n = 4, 2, 6
+    up2_ms, up2_pts = timed(up2_frame)
+    frames, warm, n, ds, n_rays = frames1, warm1, n1, ds1, n_rays1
     mesh_finetune.reset_d()
     del field_net
     torch.cuda.empty_cache()
@@ -459,6 +476,10 @@ def reference_route_line(device, scene, frames=10, warm=3, texture_size=4096, lo
         "finetune_eval_after": {"scaling": 0.0, "ms_per_frame": after_ms, "rays_per_s": n_rays / (after_ms * 1e-3),
                                 "quadrature_points_per_frame": after_pts,
                                 "reference": "train_finetune.py:575-629 (test(0, test_dataset))"},
+        "finetune_eval_after_up_sample_2": {"scaling": 0.0, "rays_per_frame": 4 * n_rays, "ms_per_frame": up2_ms,
+                                            "rays_per_s": 4 * n_rays / (up2_ms * 1e-3), "quadrature_points_per_frame": up2_pts,
+                                            "reference": "the scripts' eval: up_sample 2 (run_nerfsynthetic_finetune.sh:9), 16 windows "
+                                                         "of 160000 rays, INTER_AREA down-sample (train_finetune.py:620-627)"},
         "finetune_eval_before": {"scaling": 0.0434, "deform_log2_T": deform_log2_t, "ms_per_frame": before_ms,
                                  "rays_per_s": n_rays / (before_ms * 1e-3), "quadrature_points_per_frame": before_pts,
                                  "reference": "train_finetune.py:696 (test(args.scaling, train_whole_dataset))"},
