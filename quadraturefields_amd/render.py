@@ -147,6 +147,18 @@ class FrameRenderer:
         return rgb, alpha, depth, frame
 
     @torch.no_grad()
+    def render_baked_async(self, origins, viewdirs, uv, compressor, camera):
+        """``render_baked`` for a camera frame without a host wait (see ``render_async``): (rgb, alpha, depth, frame).
+        The texel lookup + shading launch reads the sample count from device memory (``n_device``)."""
+        ri = self.mesh_intersect.rayintersector
+        frame = ri.sample_frame_device(origins, viewdirs, self.mesh_intersect.num_intersections, camera, want_tri=True)
+        _, xyz_c, dirs_c = ri.last_layout
+        rgbs, sigmas = utils.shade_baked_points(self.mesh_intersect, uv, compressor, xyz_c, frame.tri_c, dirs_c,
+                                                n_device=frame.total_dev)
+        rgb, alpha, depth, _ = utils.composite_frame(rgbs, sigmas, frame, self.render_step_size, bg_color=self.bg_color)
+        return rgb, alpha, depth, frame
+
+    @torch.no_grad()
     def render_baked(self, origins, viewdirs, uv, compressor, image_width: int = 0, camera=None):
         """Baked-texture variant (test_baking_texture_images.py:355-371).  With a ``camera`` (the rays are its pixel
         grid) the frame never leaves the intersector's tile order: tile pack with triangle ids -> texel lookup +

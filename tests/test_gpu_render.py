@@ -174,6 +174,11 @@ def test_baked_texture_render_matches_oracle(device):
     assert torch.equal(depth_f, ref[2].reshape(-1, 1))
     rgb_g = fr.render_baked(o2.to(device), d2.to(device), torch.from_numpy(uv).to(device), comp, image_width=w)[0]
     assert torch.equal(rgb_g, rgb_f)                       # without a camera: the ray-major route
+    # no host wait: the shading launch reads the sample count from device memory, worst-case buffers
+    rgb_a, alpha_a, depth_a, frame = fr.render_baked_async(o2.to(device), d2.to(device), torch.from_numpy(uv).to(device), comp,
+                                                           make_camera(c2w, focal, w, h))
+    assert torch.equal(rgb_a, rgb_f) and torch.equal(alpha_a, alpha_f) and torch.equal(depth_a, depth_f)
+    assert mi.rayintersector.frame_samples() == n_f and frame.tri_c.dtype == torch.int32
 
 
 @pytest.mark.parametrize("w,h,k", [(40, 24, 64), (9, 1, 25), (1, 13, 25), (8, 8, 1)])
