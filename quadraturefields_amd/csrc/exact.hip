@@ -1075,6 +1075,89 @@ __global__ __launch_bounds__(kFilterRays) void filter_hits_kernel(int64_t n_rays
     }
 }
 
+// The same sort fed straight from global memory (the tile kernel): lane = ray reads ITS OWN list -- rows of K entries,
+// as float4s when the rows are 16-byte aligned -- into the network's registers, sorts, and leaves the sorted list in
+// its LDS row for the loops that index it by rank.  Every load of the list is independent of the others, so the wave
+// waits for memory once; the staged variant (coalesced loop -> LDS -> registers) waited once per loop iteration, which
+// is what a tile wave's time was made of (one wave per tile, nothing to overlap with).  kN = 16 or 32: network size,
+// picked per tile from its longest list.  `deepest` (wave-uniform) bounds what is read.
+template <int kN, bool kTri>
+__device__ __forceinline__ void load_sort_row(const float *__restrict__ g_t, const int32_t *__restrict__ g_i, int K,
+                                              bool vec4, int cnt, int deepest, float *row_t, int32_t *row_i)
+{
+    float t[kN];
+    int32_t id[kN];
+    if (vec4) {
+#pragma unroll
+        for (int j = 0; j < kN / 4; ++j) {
+            float4 v = make_float4(INFINITY, INFINITY, INFINITY, INFINITY);
+            int4 w = make_int4(-1, -1, -1, -1);
+            if (4 * j < deepest) {                              // wave-uniform; K % 4 == 0 here, so 4j+3 < K
+                v = reinterpret_cast<const float4 *>(g_t)[j];
+                if (kTri) w = reinterpret_cast<const int4 *>(g_i)[j];
+            }
+            t[4 * j] = v.x; t[4 * j + 1] = v.y; t[4 * j + 2] = v.z; t[4 * j + 3] = v.w;
+            id[4 * j] = w.x; id[4 * j + 1] = w.y; id[4 * j + 2] = w.z; id[4 * j + 3] = w.w;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < kN; ++k) {
+            t[k] = INFINITY;
+            id[k] = -1;
+            if (k < deepest) {                                  // wave-uniform; deepest <= K
+                t[k] = g_t[k];
+                if (kTri) id[k] = g_i[k];
+            }
+        }
+    }
+    if (kTri) {
+        uint64_t key[kN];
+#pragma unroll
+        for (int k = 0; k < kN; ++k) key[k] = k < cnt ? hit_key(t[k], id[k]) : ~0ull;
+#pragma unroll
+        for (int k = 2; k <= kN; k <<= 1) {
+#pragma unroll
+            for (int i = 0; i < kN; ++i) {
+                const int l = i ^ (k - 1);
+                if (l > i) { const uint64_t a = key[i], b = key[l]; key[i] = a < b ? a : b; key[l] = a < b ? b : a; }
+            }
+#pragma unroll
+            for (int j = k >> 2; j > 0; j >>= 1) {
+#pragma unroll
+                for (int i = 0; i < kN; ++i) {
+                    const int l = i ^ j;
+                    if (l > i) { const uint64_t a = key[i], b = key[l]; key[i] = a < b ? a : b; key[l] = a < b ? b : a; }
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < kN; ++k)
+            if (k < cnt) { row_t[k] = key_t(key[k]); row_i[k] = key_id(key[k]); }
+    } else {
+#pragma unroll
+        for (int k = 0; k < kN; ++k) t[k] = k < cnt ? t[k] : INFINITY;
+#pragma unroll
+        for (int k = 2; k <= kN; k <<= 1) {
+#pragma unroll
+            for (int i = 0; i < kN; ++i) {
+                const int l = i ^ (k - 1);
+                if (l > i) { const float a = t[i], b = t[l]; t[i] = fminf(a, b); t[l] = fmaxf(a, b); }
+            }
+#pragma unroll
+            for (int j = k >> 2; j > 0; j >>= 1) {
+#pragma unroll
+                for (int i = 0; i < kN; ++i) {
+                    const int l = i ^ j;
+                    if (l > i) { const float a = t[i], b = t[l]; t[i] = fminf(a, b); t[l] = fmaxf(a, b); }
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < kN; ++k)
+            if (k < cnt) row_t[k] = t[k];
+    }
+}
+
 // sampling_raytrace_numpy (mesh_utils.py:359-387): per-ray hit lists (in ANY order) -> packed samples sorted by
 // (ray, depth).  A workgroup owns 128 consecutive rays, i.e. one contiguous slice of every output array:
 //   1. the rays' [K] rows of hit_t / hit_tri are loaded into LDS with coalesced reads;
@@ -1269,26 +1352,36 @@ __global__ __launch_bounds__(64) void pack_tiles_kernel(
         if (final_count && inside) final_count[ray] = 0;
         return;
     }
-    // stage: the lists of a tile row's pixels lie K apart
-    for (int yy = 0; yy < rows; ++yy) {
-        const int64_t row_ray0 = (int64_t)(py0 + yy) * w + px0;
-        for (int i = lane; i < cols * deepest; i += 64) {
-            const int r = i / deepest, k = i - r * deepest;
-            s_t[(yy * 8 + r) * Kp + k] = hit_t[(row_ray0 + r) * K + k];
-            if (kTri) s_tri[(yy * 8 + r) * Kp + k] = hit_tri[(row_ray0 + r) * K + k];
-        }
-    }
-    __syncthreads();
-
     float *row_t = s_t + lane * Kp;
     int32_t *row_i = s_tri + lane * Kp;                       // only touched when kTri
+    // everything the wave reads from memory is asked for here, before anything waits: the ray, the tile's first slot and
+    // (below) the lists
+    const float ox = rays_o[ray * 3], oy = rays_o[ray * 3 + 1], oz = rays_o[ray * 3 + 2];
+    const float dx = rays_d[ray * 3], dy = rays_d[ray * 3 + 1], dz = rays_d[ray * 3 + 2];
+    int64_t base = tile_base[tile];
+    if (K <= 32) {
+        // lists of up to 32 hits: global memory -> registers -> sorted -> the lane's own LDS row (load_sort_row); no lane
+        // reads another lane's row below, so no barrier
+        const bool vec4 = (K & 3) == 0 && ((reinterpret_cast<uintptr_t>(hit_t) | reinterpret_cast<uintptr_t>(hit_tri)) & 15) == 0;
+        if (deepest <= 16) load_sort_row<16, kTri>(hit_t + ray * K, hit_tri + ray * K, K, vec4, cnt, deepest, row_t, row_i);
+        else load_sort_row<32, kTri>(hit_t + ray * K, hit_tri + ray * K, K, vec4, cnt, deepest, row_t, row_i);
+    } else {
+        // stage: the lists of a tile row's pixels lie K apart
+        for (int yy = 0; yy < rows; ++yy) {
+            const int64_t row_ray0 = (int64_t)(py0 + yy) * w + px0;
+            for (int i = lane; i < cols * deepest; i += 64) {
+                const int r = i / deepest, k = i - r * deepest;
+                s_t[(yy * 8 + r) * Kp + k] = hit_t[(row_ray0 + r) * K + k];
+                if (kTri) s_tri[(yy * 8 + r) * Kp + k] = hit_tri[(row_ray0 + r) * K + k];
+            }
+        }
+        __syncthreads();
+    }
     double o64[3] = {0.0, 0.0, 0.0}, d64[3] = {0.0, 0.0, 0.0};
     float dn[3] = {0.0f, 0.0f, 0.0f};
     int n_dropped = 0;
     if (inside) {
-        if (K <= 32) {                                        // t (or (t, tri)) ascending, through registers
-            if (cnt > 1) sort_row_32<kTri>(row_t, row_i, cnt);
-        } else {
+        if (K > 32) {                                         // t (or (t, tri)) ascending; K <= 32 is sorted already
             for (int i = 1; i < cnt; ++i) {
                 const float t = row_t[i];
                 const int id = kTri ? row_i[i] : 0;
@@ -1322,8 +1415,6 @@ __global__ __launch_bounds__(64) void pack_tiles_kernel(
             cnt = kept;
         }
         if (cnt > 0) {
-            const float ox = rays_o[ray * 3], oy = rays_o[ray * 3 + 1], oz = rays_o[ray * 3 + 2];
-            const float dx = rays_d[ray * 3], dy = rays_d[ray * 3 + 1], dz = rays_d[ray * 3 + 2];
             o64[0] = (double)ox; o64[1] = (double)oy; o64[2] = (double)oz;
             d64[0] = (double)dx; d64[1] = (double)dy; d64[2] = (double)dz;
             // vectors / (|vectors| + 1e-7) in float32 (mesh_utils.py:369-370)
@@ -1357,7 +1448,6 @@ __global__ __launch_bounds__(64) void pack_tiles_kernel(
         }
     }
     if (final_count && inside) final_count[ray] = cnt;
-    int64_t base = tile_base[tile];
     const unsigned long long below = (1ull << lane) - 1ull;
     float first_xyz[3] = {0.0f, 0.0f, 0.0f};                  // this lane's nearest sample, for the gap fill
     for (int k = 0;; ++k) {
