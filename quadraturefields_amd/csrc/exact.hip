@@ -638,8 +638,11 @@ __device__ __forceinline__ void raster_triangle(const float4 *__restrict__ tris,
         // the pixel's K nearest are all in nearer slabs.  Decided on the count the pixel had when this pass STARTED: the
         // live count also moves with this slab's own hits, and stopping on it would keep an arbitrary subset of them
         if (kSlab && slab.count_before && slab.count_before[ray] >= slab.stop_at) continue;
-        const float ox = rays_o[ray * 3], oy = rays_o[ray * 3 + 1], oz = rays_o[ray * 3 + 2];
-        const float dx = rays_d[ray * 3], dy = rays_d[ray * 3 + 1], dz = rays_d[ray * 3 + 2];
+        float ox = rays_o[ray * 3], oy = rays_o[ray * 3 + 1], oz = rays_o[ray * 3 + 2];
+        float dx = rays_d[ray * 3], dy = rays_d[ray * 3 + 1], dz = rays_d[ray * 3 + 2];
+        // origin and direction arrive together: without the pin the compiler sinks the origin's load behind mt_hit's
+        // det != 0 branch, a second memory round trip per pixel (measured: configs[2] intersection 2.90 -> 2.62 ms)
+        asm volatile("" : "+v"(ox), "+v"(oy), "+v"(oz), "+v"(dx), "+v"(dy), "+v"(dz));
         float t;
         if (!mt_hit(a, b, c, ox, oy, oz, dx, dy, dz, &t)) continue;
         if (kSlab) {
@@ -1196,10 +1199,30 @@ __global__ __launch_bounds__(kPackRays) void pack_samples_kernel(
     const int tid = threadIdx.x;
     const int64_t ray0 = (int64_t)blockIdx.x * kPackRays;
     const int nr = (int)((n_rays - ray0) < kPackRays ? (n_rays - ray0) : kPackRays);
-    for (int i = tid; i < nr * K; i += kPackRays) {
-        const int r = i / K, k = i - r * K;
-        s_t[r * Kp + k] = hit_t[ray0 * K + i];
-        s_tri[r * Kp + k] = hit_tri[ray0 * K + i];
+    int cnt = 0;
+    if (tid < nr) {
+        cnt = keep_mask ? raw_count[ray0 + tid] : hit_count[ray0 + tid];
+        if (cnt > K) cnt = K;
+    }
+    if (K <= 32) {
+        // lane = ray reads its own list into registers, sorts it by (t, tri) and leaves it in its LDS row (load_sort_row):
+        // one memory wait per wave instead of one per iteration of a staging loop
+        int deepest = cnt;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const int other = __shfl_xor(deepest, off, 64);
+            deepest = other > deepest ? other : deepest;
+        }
+        const int64_t own = tid < nr ? ray0 + tid : ray0;
+        const bool vec4 = (K & 3) == 0 && ((reinterpret_cast<uintptr_t>(hit_t) | reinterpret_cast<uintptr_t>(hit_tri)) & 15) == 0;
+        if (deepest > 16) load_sort_row<32, true>(hit_t + own * K, hit_tri + own * K, K, vec4, cnt, deepest, s_t + tid * Kp, s_tri + tid * Kp);
+        else if (deepest > 0) load_sort_row<16, true>(hit_t + own * K, hit_tri + own * K, K, vec4, cnt, deepest, s_t + tid * Kp, s_tri + tid * Kp);
+    } else {
+        for (int i = tid; i < nr * K; i += kPackRays) {
+            const int r = i / K, k = i - r * K;
+            s_t[r * Kp + k] = hit_t[ray0 * K + i];
+            s_tri[r * Kp + k] = hit_tri[ray0 * K + i];
+        }
     }
     if (tid == 0) s_region = 0;
     __syncthreads();
@@ -1207,13 +1230,9 @@ __global__ __launch_bounds__(kPackRays) void pack_samples_kernel(
     const int64_t block_base = ray_offset[ray0];
     if (tid < nr) {
         const int64_t ray = ray0 + tid;
-        int cnt = keep_mask ? raw_count[ray] : hit_count[ray];
-        if (cnt > K) cnt = K;
         float *row_t = s_t + tid * Kp;
         int32_t *row_i = s_tri + tid * Kp;
-        if (K <= 32) {                                        // (t, tri) ascending, through registers
-            if (cnt > 1) sort_row_32<true>(row_t, row_i, cnt);
-        } else {
+        if (K > 32) {                                         // (t, tri) ascending; K <= 32 is sorted already
             for (int i = 1; i < cnt; ++i) {
                 const float t = row_t[i];
                 const int id = row_i[i];
