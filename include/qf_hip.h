@@ -560,6 +560,50 @@ int qf_composite_tiles(const float *rgb_c /* [n,3] */, const float *sigma_c /* [
 int qf_row_sample_counts(const int32_t *hit_count, int32_t max_hits, int32_t width, int32_t height, float *out_rows,
                          void *stream);
 
+/* One render-only camera frame as ONE host call: what FrameRenderer.render_async enqueues for a pinhole frame of the
+ * reference's eval loop (the rays of nerf_synthetic.py:310-373 through render_image_finetune_with_occgrid,
+ * examples/utils.py:510-620, scaling = 0), as a fixed sequence of this library's own launches:
+ *   qf_raster_intersect (arrival order) -> qf_bvh_repair_overflow (no masks) -> qf_tile_offsets (zero_word = dropped)
+ *   -> qf_pack_tiles (re-origin rule on the sorted lists; the dropped-hit count stays in *dropped)
+ *   -> [field != NULL] qf_field_forward over min(*total, n_rays * max_hits) points -> qf_composite_tiles.
+ * Nothing in between returns to the host: the sample count lives in total[0] (device), and its copy + the raster
+ * overflow count travel to host_block[0..1] (pinned, device-writable; may be NULL) on their own.  Every pointer is
+ * caller-owned device memory of the stated size; the results are those of the separate calls, bit for bit (the
+ * function only composes them -- a row band of a frame sharded over 8 GPUs is ~0.3 ms of kernels, and a dozen
+ * separately bound calls per band kept the host behind the GPU).  No reference counterpart.                       */
+typedef struct qf_frame_job {
+    const qf_camera *camera;            /* host; the rays are its pixel grid, row-major */
+    const float *rays_o, *rays_d;       /* [n_rays,3] */
+    int64_t n_rays;                     /* == camera->width * camera->height */
+    int32_t max_hits;                   /* K */
+    int32_t cull_chunks;                /* qf_raster_intersect's: the camera sees a part of the scene */
+    float min_separation;               /* the tile pack's re-origin rule (0 = off) */
+    int32_t bg_mode;                    /* QF_BG_* */
+    float delta_const;                  /* render_step_size */
+    int32_t reserved_;
+    /* scratch */
+    int32_t *hit_tri;                   /* [n_rays, K] */
+    float *hit_t;                       /* [n_rays, K] */
+    int32_t *hit_count;                 /* [n_rays + 1]: counts | raster overflow counter */
+    int32_t *final_count;               /* [n_rays]: counts after the rule (what the compositor walks) */
+    int64_t *tile_base;                 /* [ceil(w/8) * ceil(h/8)] */
+    int64_t *total;                     /* [3] device: slots | overflow | - */
+    int64_t *host_block;                /* or NULL: pinned [4] */
+    int32_t *dropped;                   /* [1]: hits the rule dropped (zeroed by the sequence itself) */
+    /* the samples, in the coherent (tile, rank, pixel) order, at capacity n_rays * K */
+    float *xyz_c, *dirs_c, *depth_c;
+    int32_t *tri_c;                     /* or NULL */
+    /* the field (NULL: stop after the samples) and its outputs at the same capacity */
+    const qf_field_desc *field;         /* host */
+    const float *table, *base_w, *head_ngp_w;
+    const qf_sg_head *head_sg;          /* host, or NULL */
+    float *rgb_c, *sigma_c;
+    /* the image: three arrays or one packed [n_rays,5] (rgb | alpha | depth), as qf_composite_tiles */
+    const float *bkgd;
+    float *out_rgb, *out_alpha, *out_depth, *out_packed;
+} qf_frame_job;
+int qf_frame_render(qf_bvh *bvh, const qf_frame_job *job /* host */, void *stream);
+
 /* The "before" evaluation of a frame in the coherent order (train_finetune.py:696; utils.py:555-572 + the re-sort of
  * mesh_utils.py:389-403): every sample is displaced along its ray by tanh(f) * scaling -- f_c [n] = the deformation
  * field's output at xyz_c (qf_deform_field_forward) -- and each ray's samples are put back in depth order (stable by

@@ -47,6 +47,20 @@ class Camera(Structure):
                 ("width", c_int32), ("height", c_int32)]
 
 
+class FrameJob(Structure):
+    """qf_frame_job (include/qf_hip.h): one render-only camera frame as one host call."""
+    _fields_ = [("camera", c_void_p), ("rays_o", c_void_p), ("rays_d", c_void_p), ("n_rays", c_int64),
+                ("max_hits", c_int32), ("cull_chunks", c_int32), ("min_separation", c_float), ("bg_mode", c_int32),
+                ("delta_const", c_float), ("reserved_", c_int32),
+                ("hit_tri", c_void_p), ("hit_t", c_void_p), ("hit_count", c_void_p), ("final_count", c_void_p),
+                ("tile_base", c_void_p), ("total", c_void_p), ("host_block", c_void_p), ("dropped", c_void_p),
+                ("xyz_c", c_void_p), ("dirs_c", c_void_p), ("depth_c", c_void_p), ("tri_c", c_void_p),
+                ("field", c_void_p), ("table", c_void_p), ("base_w", c_void_p), ("head_ngp_w", c_void_p),
+                ("head_sg", c_void_p), ("rgb_c", c_void_p), ("sigma_c", c_void_p),
+                ("bkgd", c_void_p), ("out_rgb", c_void_p), ("out_alpha", c_void_p), ("out_depth", c_void_p),
+                ("out_packed", c_void_p)]
+
+
 class TextureSet(Structure):
     _fields_ = [("alpha", c_void_p), ("diffuse", c_void_p), ("colors", c_void_p * QF_MAX_LOBES),
                 ("lambda_axis", c_void_p * QF_MAX_LOBES), ("texture_size", c_int32), ("n_lobes", c_int32),
@@ -56,6 +70,7 @@ class TextureSet(Structure):
 _P = c_void_p
 _SIGNATURES = {
     "qf_status_string": (c_char_p, [c_int]),
+    "qf_frame_render": (c_int, [_P, POINTER(FrameJob), _P]),
     "qf_abi_version": (c_int, []),
     "qf_device_cu_count": (c_int, []),
     "qf_grid_desc_init": (c_int, [POINTER(GridDesc), c_uint32, c_uint32, c_uint32, c_double]),

@@ -28,6 +28,7 @@ SOURCES = [
     ("exact.hip", ["-ffp-contract=off"]),
     ("bvh_build.cpp", ["-x", "hip"]),
     ("misc.cpp", ["-x", "hip"]),
+    ("frame.cpp", ["-x", "hip"]),
 ]
 COMMON = os.environ.get("QF_EXTRA_HIPCC_FLAGS", "").split() + ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-I" + os.path.join(ROOT, "include"),
           "-I" + CSRC, "-Wall", "-Wno-unused-function"]

@@ -929,15 +929,27 @@ __global__ __launch_bounds__(kSelectBlock) void select_nearest_kernel(int64_t n_
     float *row_t = hit_t + r * max_hits;
     int32_t *row_i = hit_tri + r * max_hits;
     if (cnt <= max_hits) {
-        for (int i = 0; i < cnt; ++i) {
-            if (kKeys) {
-                const uint64_t k = wide_key[(int64_t)i * n_rays + r];
-                row_t[i] = key_t(k);
-                row_i[i] = key_id(k);
-            } else {
-                row_t[i] = wide_t[(int64_t)i * n_rays + r];
-                row_i[i] = wide_tri[(int64_t)i * n_rays + r];
+        // a plain copy, eight slots per memory round trip (one slot per trip made this path -- most rays of a frame --
+        // the kernel's duration: a wave per 64 rays, few waves per CU next to the selection's LDS columns)
+        constexpr int kCopy = 8;
+        for (int i0 = 0; i0 < cnt; i0 += kCopy) {
+            float tb[kCopy];
+            int ib[kCopy];
+#pragma unroll
+            for (int u = 0; u < kCopy; ++u) {
+                const int i = i0 + u < cnt ? i0 + u : cnt - 1;
+                if (kKeys) {
+                    const uint64_t k = wide_key[(int64_t)i * n_rays + r];
+                    tb[u] = key_t(k);
+                    ib[u] = key_id(k);
+                } else {
+                    tb[u] = wide_t[(int64_t)i * n_rays + r];
+                    ib[u] = wide_tri[(int64_t)i * n_rays + r];
+                }
             }
+#pragma unroll
+            for (int u = 0; u < kCopy; ++u)
+                if (i0 + u < cnt) { row_t[i0 + u] = tb[u]; row_i[i0 + u] = ib[u]; }
         }
         return;
     }

@@ -147,6 +147,8 @@ class RayIntersector:
         self.last_frame = None           # what utils.composite_frame needs of that pack (depths in the coherent order, ...)
         self.last_image_shape = None     # (width, height) of the most recent image-shaped batch (see split_layout)
         self._deferred_policy = None     # (event, pinned block, n_rays, k) of a frame packed without a host wait
+        self._fused_pending = []         # the same records of one-call frames (fused_frame_job), oldest first
+        self._fused_parity = 0           # which of the scratch block's two events the last one-call frame recorded
         self._split_scratch = {}
         self._handle = ctypes.c_void_p()
         tri = np.ascontiguousarray(mesh.vertices.astype(np.float32)[mesh.faces].reshape(-1, 9))
@@ -592,6 +594,19 @@ class RayIntersector:
             ev, host, n_rays, k = pend
             ev.synchronize()
             self._overflow_policy(int(host[1]), n_rays, k)
+        while self._fused_pending:
+            self._settle_fused_policy(0)
+
+    def _settle_fused_policy(self, keep: int = 1) -> None:
+        """One-call frames (``fused_frame_job``) record their event after their LAST launch; waiting for the previous
+        frame's would let the host enqueue a frame only once the GPU has finished the one before -- host and GPU taking
+        turns.  They alternate between the scratch block's two events instead, and a frame settles the policy of the
+        frame BEFORE the previous one (``keep`` = frames left pending), which has long finished.  The pinned block
+        holds the overflow count of the latest frame that got that far: recent enough for a policy."""
+        while len(self._fused_pending) > keep:
+            ev, host, n_rays, k = self._fused_pending.pop(0)
+            ev.synchronize()
+            self._overflow_policy(int(host[1]), n_rays, k)
 
     def pack_hits_device(self, pending):
         """Second half of a RENDER-ONLY frame (``pack_hits_begin(..., lean=True)``) WITHOUT the host wait: the sample
@@ -713,6 +728,73 @@ class RayIntersector:
         self.last_order = None
         return self.pack_hits_device(self.pack_hits_begin(o, d, k, hit_tri, hit_t, hit_count, overflow, int(camera.width),
                                                           lean=True, layout=True, want_tri=want_tri, publish=False))
+
+    def fused_frame_ready(self, camera, max_hits: Optional[int] = None) -> bool:
+        """Does ``sample_frame_device`` reduce to the fixed sequence ``qf_frame_render`` composes -- the plain
+        camera-coherent pass (no wide candidate lists, no back-off to the BVH path) with the re-origin rule left to the
+        tile pack?  No side effects."""
+        k = self.max_hits if max_hits is None else int(max_hits)
+        return (camera is not None and self._raster_backoff <= 0 and int(self.raster_wide) <= k
+                and not (self.min_separation > 0 and self._rule_upfront > 0))
+
+    @_on_device
+    def fused_frame_job(self, origins, vectors, max_hits: Optional[int] = None, camera=None, want_tri: bool = False):
+        """The sampling half of a ``qf_frame_job`` for a camera frame (``fused_frame_ready`` must hold): every buffer
+        ``sample_frame_device`` would allocate, and the frame record it would return -- with nothing enqueued yet.
+        Returns (job, frame, token) -- or None when settling an earlier frame's overflow count has just moved the policy
+        away from the plain pass (take ``sample_frame_device``); the caller adds the field / image pointers, calls
+        ``qf_frame_render`` and hands ``token`` to ``fused_frame_done``."""
+        k = self.max_hits if max_hits is None else int(max_hits)
+        o = _as_device_f32(origins, self.device).reshape(-1, 3)
+        d = _as_device_f32(vectors, self.device).reshape(-1, 3)
+        n = o.shape[0]
+        w, h = int(camera.width), int(camera.height)
+        if n != w * h:
+            raise ValueError("fused_frame_job: origins / vectors must be the camera's full pixel grid")
+        if self._deferred_policy is not None:
+            self._settle_deferred_policy()
+        self._settle_fused_policy(1)
+        if not self.fused_frame_ready(camera, k) or not self.want_raster(camera):      # (the policy may just have moved)
+            return None
+        dev = self.device
+        cap = n * k
+        hit_tri, hit_t, _ = self._alloc_hits(n, k)
+        counts = torch.empty((n + 1,), dtype=torch.int32, device=dev)
+        final_count = torch.empty((n,), dtype=torch.int32, device=dev)
+        tile_base = torch.empty((((w + 7) // 8) * ((h + 7) // 8),), dtype=torch.int64, device=dev)
+        xyz_c = torch.empty((cap, 3), dtype=torch.float32, device=dev)
+        dirs_c = torch.empty((cap, 3), dtype=torch.float32, device=dev)
+        depth_c = torch.empty((cap,), dtype=torch.float32, device=dev)
+        tri_c = torch.empty((cap,), dtype=torch.int32, device=dev) if want_tri else None
+        buf, _temp, host, events, dropped = self._frame_scratch(n)
+        self._fused_parity ^= 1
+        ev, ev_flag = events[self._fused_parity], events[self._fused_parity ^ 1]
+        job = _C.FrameJob()
+        job.camera = ctypes.addressof(camera)
+        job.rays_o, job.rays_d, job.n_rays, job.max_hits = o.data_ptr(), d.data_ptr(), n, k
+        job.cull_chunks = 1 if getattr(camera, "cull", False) else 0
+        job.min_separation = float(self.min_separation)
+        job.hit_tri, job.hit_t, job.hit_count = hit_tri.data_ptr(), hit_t.data_ptr(), counts.data_ptr()
+        job.final_count, job.tile_base = final_count.data_ptr(), tile_base.data_ptr()
+        job.total, job.host_block, job.dropped = buf.data_ptr() + 8 * n, host.data_ptr(), dropped.data_ptr()
+        job.xyz_c, job.dirs_c, job.depth_c = xyz_c.data_ptr(), dirs_c.data_ptr(), depth_c.data_ptr()
+        job.tri_c = tri_c.data_ptr() if want_tri else None
+        frame = SimpleNamespace(depth_c=depth_c, hit_count=final_count, max_hits=k, tile_base=tile_base, width=w, height=h,
+                                total=cap, tri_c=tri_c, total_dev=buf[n:n + 1], samples=None, total_src=(ev, host),
+                                dropped_src=(ev_flag, host), dropped_dev=dropped,
+                                _keep=(hit_tri, hit_t, counts, o, d, camera))
+        return job, frame, (ev, host, n, k, xyz_c, dirs_c)
+
+    def fused_frame_done(self, frame, token) -> None:
+        """After ``qf_frame_render`` was enqueued: the state ``sample_frame_device`` leaves behind."""
+        ev, host, n, k, xyz_c, dirs_c = token
+        ev.record()                           # (total, overflow) are in the pinned block once this event has passed
+        self._rule_pending = None
+        self._fused_pending.append((ev, host, n, k))
+        self.last_order = None
+        self.last_image_shape = (frame.width, frame.height)
+        self.last_layout = (None, xyz_c, dirs_c)
+        self.last_frame = frame
 
     @_on_device
     def coherent_layout(self, hit_count, ray_offset, total: int, width: int, tile_base=None, want_order=True):

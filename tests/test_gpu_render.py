@@ -479,3 +479,44 @@ def test_frame_without_host_wait_equals_the_frame_with_it(device, scaling):
     rgb_a, alpha_a, _, _ = fr.render_async(o + 100.0, d, make_camera(cams[0], focal, w, h), scaling=scaling)
     assert torch.equal(rgb_a, torch.ones_like(rgb_a)) and float(alpha_a.abs().max()) == 0.0
     assert ri.frame_samples() == 0
+
+
+@pytest.mark.parametrize("packed", [False, True])
+def test_one_call_frame_equals_the_separately_bound_launches(device, packed):
+    """qf_frame_render (FrameRenderer.render_async's default route for an NGP field): the frame's six launches behind ONE
+    bound call.  Pixels, per-pixel counts, sample arrays and the sample count equal those of the same launches bound one
+    by one (the route taken when ``fused_frame_ready`` says no), bit for bit -- also for a camera that sees a band of
+    the image (triangle-chunk culling on)."""
+    from quadraturefields_amd import synthetic
+    from quadraturefields_amd.mesh_utils import make_camera
+    from quadraturefields_amd.parallel import band_camera
+    from quadraturefields_amd.render import FrameRenderer
+    mesh, mi, field = _scene(device)
+    fr = FrameRenderer(mi, field)
+    ri = mi.rayintersector
+    w, h = 136, 96
+    focal = synthetic.lego_focal(800) * w / 800.0
+    c2w = synthetic.orbit_cameras(2, seed=5)[1]
+    o, d = synthetic.camera_rays(c2w, focal, w, h, device=device)
+    full = make_camera(c2w, focal, w, h)
+    band = band_camera(c2w, focal, w, h, 24, 72)
+    for cam, sl in ((full, slice(0, w * h)), (band, slice(24 * w, 72 * w))):
+        ob, db = o[sl].contiguous(), d[sl].contiguous()
+        assert ri.fused_frame_ready(cam, mi.num_intersections)
+        one = fr.render_async(ob, db, cam, packed=packed)
+        n_one = ri.frame_samples()
+        f_one = one[3]
+        ready = ri.fused_frame_ready
+        ri.fused_frame_ready = lambda *a, **k: False
+        try:
+            sep = fr.render_async(ob, db, cam, packed=packed)
+        finally:
+            ri.fused_frame_ready = ready
+        n_sep = ri.frame_samples()
+        f_sep = sep[3]
+        assert n_one == n_sep > 500
+        for a, b in zip(one[:3], sep[:3]):
+            assert (a is None and b is None) or torch.equal(a, b)
+        assert torch.equal(f_one.hit_count, f_sep.hit_count) and torch.equal(f_one.tile_base, f_sep.tile_base)
+        total = int(f_one.total_dev.item())
+        assert torch.equal(f_one.depth_c[:total], f_sep.depth_c[:total])

@@ -58,9 +58,26 @@ def main():
                 s._push_profile(frame, w, h, row_samples)
             if i >= 2:
                 per_band.append(times)
+        # the same bands enqueued back to back (no sync in between): what the host needs per band, and what the GPU does
+        import time
+        cuts = sh[0].cuts_for(h)
+        host_us, gpu_ms = [], []
+        for c2w, (o, d) in list(zip(cams, rays))[2:]:
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            a.record()
+            t0 = time.perf_counter()
+            keep = [sh[r].render_band(o, d, c2w, focal, w, h, cuts[r], cuts[r + 1]) for r in range(n)]
+            host_us.append((time.perf_counter() - t0) * 1e6 / n)
+            b.record()
+            torch.cuda.synchronize()
+            gpu_ms.append(a.elapsed_time(b) / n)
+            del keep
         t = np.array(per_band)
         out["ranks"][str(n)] = {"band_ms_mean": t.mean(axis=0).round(4).tolist(), "max_band_ms": float(t.max(axis=1).mean()),
                                 "sum_band_ms": float(t.sum(axis=1).mean()), "last_cuts": cuts,
+                                "back_to_back_ms_per_band": float(np.mean(gpu_ms)),
+                                "host_enqueue_us_per_band": float(np.mean(host_us)),
                                 "speedup_if_gather_free": float(out["ranks"]["1"]["max_band_ms"] / t.max(axis=1).mean())
                                 if "1" in out["ranks"] else None}
     print(json.dumps(out))
