@@ -802,3 +802,22 @@ def test_trimesh_separation_follows_the_mesh_on_refit(device):
     ri.set_min_separation(1e-3)                                         # a fixed distance no longer follows
     ri.update_intersector(v2)
     assert ri.min_separation == 1e-3
+
+
+@pytest.mark.parametrize("k", [12, 16, 28, 32])
+def test_packed_samples_match_oracle_on_every_list_route(device, k):
+    """The packers read a ray's list straight into the sort network's registers (load_sort_row): rows as float4s when K is
+    a multiple of 4, a 16- or a 32-key network by the longest list of the wave.  K = 12 / 16: vector rows, 16 keys, lists
+    truncated to the K nearest; K = 28 / 32: vector rows, 32 keys (up to 20 crossings).  (K = 25, scalar rows, is every
+    other test's case.)  The six sample tensors against the oracle, bit for bit."""
+    from quadraturefields_amd.mesh_utils import MeshIntersection
+    mesh = _scene(subdiv=2, shells=10)
+    mi = MeshIntersection(mesh, simplify_mesh=False, scale=1.0, num_intersections=k)
+    o, d = _rays(3000, seed=k)
+    want = om.to_loader_tensors(om.sampling_raytrace_numpy(om.BruteForceIntersector(mesh.vertices, mesh.faces), d, o, k))
+    got = mi.sampling_raytrace_device(d, o)
+    deepest = int(torch.bincount(want[2]).max())
+    assert deepest == min(k, 20) or deepest > 16
+    for name, g, w in zip(["xyzs", "dirs", "index_ray", "ts", "index_tri", "origins"], got, want):
+        assert g.shape == w.shape, name
+        assert torch.equal(g.cpu(), w), name

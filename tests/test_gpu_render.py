@@ -181,7 +181,7 @@ def test_baked_texture_render_matches_oracle(device):
     assert mi.rayintersector.frame_samples() == n_f and frame.tri_c.dtype == torch.int32
 
 
-@pytest.mark.parametrize("w,h,k", [(40, 24, 64), (9, 1, 25), (1, 13, 25), (8, 8, 1)])
+@pytest.mark.parametrize("w,h,k", [(40, 24, 64), (9, 1, 25), (1, 13, 25), (8, 8, 1), (40, 24, 32), (24, 16, 16)])
 def test_tile_order_frame_equals_the_ray_major_route_at_the_edges(device, w, h, k):
     """The frame driver's tile-order path (qf_pack_tiles / qf_composite_tiles) against the function-by-function route on
     the six ray-major tensors, bit for bit: the largest K the ABI allows (64 hits per ray: the tile kernels' LDS
