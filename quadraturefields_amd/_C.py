@@ -120,9 +120,11 @@ _SIGNATURES = {
     "qf_bvh_copy_tri_ids": (c_int, [_P, _P, c_int64]),
     "qf_bvh_intersect": (c_int, [_P, _P, _P, c_int64, c_int32, c_int32, _P, _P, _P, _P]),
     "qf_bvh_repair_overflow": (c_int, [_P, _P, _P, c_int64, c_int32, c_int32, _P, _P, _P, _P, _P, _P]),
-    "qf_raster_intersect": (c_int, [_P, POINTER(Camera), _P, _P, c_int64, c_int32, _P, _P, _P, _P, c_int32, c_int32, _P]),
-    "qf_raster_intersect_wide": (c_int, [_P, POINTER(Camera), _P, _P, c_int64, c_int32, c_int32, _P, _P, _P, _P, _P, _P, c_int32, _P]),
-    "qf_raster_intersect_slabs": (c_int, [_P, POINTER(Camera), _P, _P, c_int64, c_int32, c_int32, c_int32, _P, _P, _P, _P, _P, _P]),
+    "qf_raster_intersect": (c_int, [_P, POINTER(Camera), _P, _P, c_int64, c_int32, _P, _P, _P, _P, c_int32, c_int32, _P, _P]),
+    "qf_raster_intersect_wide": (c_int, [_P, POINTER(Camera), _P, _P, c_int64, c_int32, c_int32, _P, _P, _P, _P, _P, _P, c_int32, _P,
+                                         _P]),
+    "qf_raster_intersect_slabs": (c_int, [_P, POINTER(Camera), _P, _P, c_int64, c_int32, c_int32, c_int32, _P, _P, _P, _P, _P, _P,
+                                          _P]),
     "qf_grid_march_count": (c_int, [POINTER(c_float), POINTER(c_int32), _P, _P, _P, _P, _P, c_int64, c_float, c_float,
                                     c_float, _P, _P]),
     "qf_grid_march_write": (c_int, [POINTER(c_float), POINTER(c_int32), _P, _P, _P, _P, _P, c_int64, c_float, c_float,
@@ -153,7 +155,7 @@ _SIGNATURES = {
     "qf_texture_shade_points": (c_int, [_P, c_int32, c_int32, c_int32, c_float, _P, _P, _P, _P, _P, c_int64, _P, _P, _P, _P]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
-ABI_VERSION = 3              # QF_ABI_VERSION of include/qf_hip.h
+ABI_VERSION = 4              # QF_ABI_VERSION of include/qf_hip.h
 
 _lib = None
 

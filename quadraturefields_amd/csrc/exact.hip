@@ -559,15 +559,16 @@ struct SlabArgs {
     const int32_t *count_before;     // the pixels' counts when this slab's pass started (NULL for the first slab)
 };
 
-template <int kRasterLanes, bool kWide, bool kSlab = false>
-__device__ __forceinline__ void raster_triangle(const float4 *__restrict__ tris, int64_t tri_i, int sub, const RasterCam &cam,
-                                                const float *__restrict__ rays_o, const float *__restrict__ rays_d,
-                                                int max_hits, int32_t *__restrict__ hit_tri, float *__restrict__ hit_t,
-                                                int32_t *__restrict__ hit_count, int32_t *__restrict__ overflow,
-                                                const SlabArgs slab = SlabArgs())
+// A triangle's screen-space set-up, shared by the passes below: the pixel box it can touch and (when its orientation
+// is reliable) the three guard-banded edge functions.  false: no pixel can be hit.
+struct TriSetup {
+    int x0, x1, y0, y1;
+    bool use_edges;
+    float ea[3], eb[3], ec[3];
+};
+
+__device__ __forceinline__ bool tri_setup(const float4 a, const float4 b, const float4 c, const RasterCam &cam, TriSetup &s)
 {
-    const float4 a = tris[tri_i * 3 + 0], b = tris[tri_i * 3 + 1], c = tris[tri_i * 3 + 2];
-    const int id = __float_as_int(a.w);
     // conservative screen box of the triangle (projection of a convex set is inside the box of its vertices)
     float minx = INFINITY, maxx = -INFINITY, miny = INFINITY, maxy = -INFINITY;
     int behind = 0;
@@ -587,27 +588,25 @@ __device__ __forceinline__ void raster_triangle(const float4 *__restrict__ tris,
         minx = fminf(minx, sx); maxx = fmaxf(maxx, sx);
         miny = fminf(miny, sy); maxy = fmaxf(maxy, sy);
     }
-    if (behind == 3) return;                 // entirely behind the camera: t > 0 is impossible
-    int x0, x1, y0, y1;
+    if (behind == 3) return false;           // entirely behind the camera: t > 0 is impossible
     // Conservative 2-D reject before any memory is touched: a pixel can only be hit if it lies inside the projected
     // triangle grown by the guard band, i.e. on the inner side of every edge line moved outwards by the guard
     // (|edge| is over-estimated by its L1 length).  Skipped for triangles that straddle the camera plane or project
     // (almost) edge-on, where the orientation is not reliable; the exact test below decides in every case.
-    float ea[3], eb[3], ec[3];
-    bool use_edges = false;
+    s.use_edges = false;
     if (behind > 0) {                        // straddles the camera plane: no finite box, test every pixel
-        x0 = 0; y0 = 0; x1 = cam.w - 1; y1 = cam.h - 1;
+        s.x0 = 0; s.y0 = 0; s.x1 = cam.w - 1; s.y1 = cam.h - 1;
     } else {
-        x0 = (int)fmaxf(floorf(minx - kRasterGuard), 0.0f);
-        y0 = (int)fmaxf(floorf(miny - kRasterGuard), 0.0f);
-        x1 = (int)fminf(ceilf(maxx + kRasterGuard), (float)(cam.w - 1));
-        y1 = (int)fminf(ceilf(maxy + kRasterGuard), (float)(cam.h - 1));
+        s.x0 = (int)fmaxf(floorf(minx - kRasterGuard), 0.0f);
+        s.y0 = (int)fmaxf(floorf(miny - kRasterGuard), 0.0f);
+        s.x1 = (int)fminf(ceilf(maxx + kRasterGuard), (float)(cam.w - 1));
+        s.y1 = (int)fminf(ceilf(maxy + kRasterGuard), (float)(cam.h - 1));
         if (!(maxx + kRasterGuard >= 0.0f) || !(maxy + kRasterGuard >= 0.0f) ||
             !(minx - kRasterGuard <= (float)(cam.w - 1)) || !(miny - kRasterGuard <= (float)(cam.h - 1)))
-            return;
+            return false;
         const float area2 = (sxs[1] - sxs[0]) * (sys[2] - sys[0]) - (sys[1] - sys[0]) * (sxs[2] - sxs[0]);
         if (fabsf(area2) > 1e-2f) {
-            use_edges = true;
+            s.use_edges = true;
             const float sgn = area2 > 0.0f ? 1.0f : -1.0f;
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
@@ -615,12 +614,29 @@ __device__ __forceinline__ void raster_triangle(const float4 *__restrict__ tris,
                 const float ex = sxs[k1] - sxs[k], ey = sys[k1] - sys[k];
                 // E(p) = sgn * ((p.y - v.y) * ex - (p.x - v.x) * ey): positive at the opposite vertex.
                 // keep p iff E(p) >= -guard * (|ex| + |ey|) - slack
-                ea[k] = -sgn * ey;
-                eb[k] = sgn * ex;
-                ec[k] = -(ea[k] * sxs[k] + eb[k] * sys[k]) + (kRasterGuard + 0.05f) * (fabsf(ex) + fabsf(ey)) + 1e-3f;
+                s.ea[k] = -sgn * ey;
+                s.eb[k] = sgn * ex;
+                s.ec[k] = -(s.ea[k] * sxs[k] + s.eb[k] * sys[k]) + (kRasterGuard + 0.05f) * (fabsf(ex) + fabsf(ey)) + 1e-3f;
             }
         }
     }
+    return true;
+}
+
+template <int kRasterLanes, bool kWide, bool kSlab = false>
+__device__ __forceinline__ void raster_triangle(const float4 *__restrict__ tris, int64_t tri_i, int sub, const RasterCam &cam,
+                                                const float *__restrict__ rays_o, const float *__restrict__ rays_d,
+                                                int max_hits, int32_t *__restrict__ hit_tri, float *__restrict__ hit_t,
+                                                int32_t *__restrict__ hit_count, int32_t *__restrict__ overflow,
+                                                const bool cam_origin, const SlabArgs slab = SlabArgs())
+{
+    const float4 a = tris[tri_i * 3 + 0], b = tris[tri_i * 3 + 1], c = tris[tri_i * 3 + 2];
+    const int id = __float_as_int(a.w);
+    TriSetup ts;
+    if (!tri_setup(a, b, c, cam, ts)) return;
+    const int x0 = ts.x0, x1 = ts.x1, y0 = ts.y0, y1 = ts.y1;
+    const bool use_edges = ts.use_edges;
+    const float *ea = ts.ea, *eb = ts.eb, *ec = ts.ec;
     const int bw = x1 - x0 + 1;
     const int total = bw * (y1 - y0 + 1);
     int px = x0 + sub % bw, py = y0 + sub / bw;
@@ -638,7 +654,10 @@ __device__ __forceinline__ void raster_triangle(const float4 *__restrict__ tris,
         // the pixel's K nearest are all in nearer slabs.  Decided on the count the pixel had when this pass STARTED: the
         // live count also moves with this slab's own hits, and stopping on it would keep an arbitrary subset of them
         if (kSlab && slab.count_before && slab.count_before[ray] >= slab.stop_at) continue;
-        float ox = rays_o[ray * 3], oy = rays_o[ray * 3 + 1], oz = rays_o[ray * 3 + 2];
+        // the origin: the camera centre when origin_check has verified that every ray's origin IS that value bit for bit
+        // (one scattered 12-byte load less per candidate pixel: 17 % of the pass), the ray's own otherwise
+        float ox = cam.cx, oy = cam.cy, oz = cam.cz;
+        if (!cam_origin) { ox = rays_o[ray * 3]; oy = rays_o[ray * 3 + 1]; oz = rays_o[ray * 3 + 2]; }
         float dx = rays_d[ray * 3], dy = rays_d[ray * 3 + 1], dz = rays_d[ray * 3 + 2];
         // origin and direction arrive together: without the pin the compiler sinks the origin's load behind mt_hit's
         // det != 0 branch, a second memory round trip per pixel (measured: configs[2] intersection 2.90 -> 2.62 ms)
@@ -667,13 +686,35 @@ template <int kRasterLanes, bool kWide>
 __global__ __launch_bounds__(256) void raster_kernel(const float4 *__restrict__ tris, int64_t n_tri, RasterCam cam,
                                                      const float *__restrict__ rays_o, const float *__restrict__ rays_d,
                                                      int max_hits, int32_t *__restrict__ hit_tri, float *__restrict__ hit_t,
-                                                     int32_t *__restrict__ hit_count, int32_t *__restrict__ overflow)
+                                                     int32_t *__restrict__ hit_count, int32_t *__restrict__ overflow,
+                                                     const int32_t *__restrict__ origin_differs)
 {
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t tri_i = gid / kRasterLanes;
     const int sub = (int)(gid % kRasterLanes);
     if (tri_i >= n_tri) return;
-    raster_triangle<kRasterLanes, kWide>(tris, tri_i, sub, cam, rays_o, rays_d, max_hits, hit_tri, hit_t, hit_count, overflow);
+    const bool cam_origin = origin_differs && *origin_differs == 0;
+    raster_triangle<kRasterLanes, kWide>(tris, tri_i, sub, cam, rays_o, rays_d, max_hits, hit_tri, hit_t, hit_count, overflow,
+                                         cam_origin);
+}
+
+// Do all the rays start at the camera centre, bit for bit?  *differs (zeroed by the caller's fill) is raised otherwise;
+// the passes then read every ray's own origin as before.  rays_o as 3 n words against the centre's three.
+__device__ __forceinline__ void origin_check(const uint32_t *__restrict__ o_bits, int64_t n3, const RasterCam &cam,
+                                             int32_t *__restrict__ differs, int64_t first, int64_t stride)
+{
+    const uint32_t c[3] = {__float_as_uint(cam.cx), __float_as_uint(cam.cy), __float_as_uint(cam.cz)};
+    bool bad = false;
+    for (int64_t e = first; e < n3; e += stride) {
+        const int comp = (int)(e % 3);
+        bad |= o_bits[e] != (comp == 0 ? c[0] : (comp == 1 ? c[1] : c[2]));
+    }
+    if (bad) *differs = 1;
+}
+
+__global__ void origin_check_kernel(const uint32_t *__restrict__ o_bits, int64_t n3, RasterCam cam, int32_t *__restrict__ differs)
+{
+    origin_check(o_bits, n3, cam, differs, (int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x);
 }
 
 // ---- triangle culling for cameras that see a PART of the scene (the row bands of parallel.ShardedFrameRenderer: every
@@ -718,10 +759,13 @@ __global__ __launch_bounds__(256) void chunk_boxes_kernel(const float4 *__restri
 // counters[2]: this call appends to counters[parity] and zeroes counters[parity ^ 1] for the next call on the handle
 // (stream order: the previous call's raster kernel, which read it, is done) -- no memset launch per frame.
 __global__ void cull_chunks_kernel(const float4 *__restrict__ boxes, int n_chunks, RasterCam cam, int32_t *__restrict__ visible,
-                                   int32_t *__restrict__ counters, int parity)
+                                   int32_t *__restrict__ counters, int parity, const uint32_t *__restrict__ o_bits, int64_t n3,
+                                   int32_t *__restrict__ origin_differs)
 {
     const int chunk = blockIdx.x * blockDim.x + threadIdx.x;
     if (chunk == 0) counters[parity ^ 1] = 0;
+    // (this launch precedes the pass anyway: it also carries the pass's origin check, see origin_check_kernel)
+    if (origin_differs) origin_check(o_bits, n3, cam, origin_differs, chunk, (int64_t)gridDim.x * blockDim.x);
     if (chunk >= n_chunks) return;
     const float4 lo = boxes[chunk * 2], hi = boxes[chunk * 2 + 1];
     if (!(lo.x <= hi.x)) return;                                  // empty chunk
@@ -752,8 +796,10 @@ __global__ __launch_bounds__(256) void raster_culled_kernel(const float4 *__rest
                                                             const float *__restrict__ rays_o, const float *__restrict__ rays_d,
                                                             int max_hits, int32_t *__restrict__ hit_tri, float *__restrict__ hit_t,
                                                             int32_t *__restrict__ hit_count, int32_t *__restrict__ overflow,
-                                                            const int32_t *__restrict__ visible, const int32_t *__restrict__ n_visible)
+                                                            const int32_t *__restrict__ visible, const int32_t *__restrict__ n_visible,
+                                                            const int32_t *__restrict__ origin_differs)
 {
+    const bool cam_origin = origin_differs && *origin_differs == 0;
     constexpr int kTrisPerBlock = 256 / kRasterLanes;
     constexpr int kBlocksPerChunk = kCullChunk / kTrisPerBlock;       // 1 / 2 / 4 for 4 / 8 / 16 lanes per triangle
     const int n_items = *n_visible * kBlocksPerChunk;
@@ -762,7 +808,8 @@ __global__ __launch_bounds__(256) void raster_culled_kernel(const float4 *__rest
         const int chunk = visible[item / kBlocksPerChunk];
         const int64_t tri_i = (int64_t)chunk * kCullChunk + (item % kBlocksPerChunk) * kTrisPerBlock + threadIdx.x / kRasterLanes;
         if (tri_i < n_tri)
-            raster_triangle<kRasterLanes, kWide>(tris, tri_i, sub, cam, rays_o, rays_d, max_hits, hit_tri, hit_t, hit_count, overflow);
+            raster_triangle<kRasterLanes, kWide>(tris, tri_i, sub, cam, rays_o, rays_d, max_hits, hit_tri, hit_t, hit_count, overflow,
+                                                 cam_origin);
     }
 }
 
@@ -877,8 +924,10 @@ __global__ __launch_bounds__(256) void raster_slab_kernel(const float4 *__restri
                                                           int capacity, uint64_t *__restrict__ keys, int32_t *__restrict__ hit_count,
                                                           int32_t *__restrict__ overflow, const int32_t *__restrict__ list,
                                                           const SlabCtl *__restrict__ ctl, int slab_j, int n_slabs, int stop_at,
-                                                          const int32_t *__restrict__ count_before)
+                                                          const int32_t *__restrict__ count_before,
+                                                          const int32_t *__restrict__ origin_differs)
 {
+    const bool cam_origin = origin_differs && *origin_differs == 0;
     constexpr int kTrisPerBlock = 256 / kRasterLanes;
     constexpr int kBlocksPerChunk = kCullChunk / kTrisPerBlock;
     const int n_items = ctl->slab_count[slab_j] * kBlocksPerChunk;
@@ -893,7 +942,7 @@ __global__ __launch_bounds__(256) void raster_slab_kernel(const float4 *__restri
         const int64_t tri_i = (int64_t)chunk * kCullChunk + (item % kBlocksPerChunk) * kTrisPerBlock + threadIdx.x / kRasterLanes;
         if (tri_i < n_tri)
             raster_triangle<kRasterLanes, true, true>(tris, tri_i, sub, cam, rays_o, rays_d, capacity, nullptr, nullptr,
-                                                      hit_count, overflow, sa);
+                                                      hit_count, overflow, cam_origin, sa);
     }
 }
 
@@ -2336,17 +2385,28 @@ static int ensure_chunk_boxes(qf_bvh *bvh, hipStream_t st)
     return QF_OK;
 }
 
+// zero the counts, the overflow counter and the origin flag: one fill launch when the caller laid them out back to back
+// (hit_count [n_rays] | overflow | origin flag)
+static int raster_zero(int64_t n_rays, int32_t *hit_count, int32_t *overflow, int32_t *origin_flag, hipStream_t st)
+{
+    int64_t words = n_rays;
+    bool ovf_done = false, flag_done = origin_flag == nullptr;
+    if (overflow == hit_count + words) { ++words; ovf_done = true; }
+    if (ovf_done && origin_flag == hit_count + words) { ++words; flag_done = true; }
+    QF_HIP_TRY(hipMemsetAsync(hit_count, 0, (size_t)words * sizeof(int32_t), st));
+    if (!ovf_done) QF_HIP_TRY(hipMemsetAsync(overflow, 0, sizeof(int32_t), st));
+    if (!flag_done) QF_HIP_TRY(hipMemsetAsync(origin_flag, 0, sizeof(int32_t), st));
+    return QF_OK;
+}
+
 static int raster_launch(qf_bvh *bvh, const qf_camera *cam, const float *rays_o, const float *rays_d, int64_t n_rays,
                          int capacity, bool wide, int32_t *hit_tri, float *hit_t, int32_t *hit_count, int32_t *overflow,
-                         bool cull, hipStream_t st)
+                         int32_t *origin_flag, bool cull, hipStream_t st)
 {
-    if (overflow == hit_count + n_rays) {    // the caller put the counter right behind the counts: one fill launch
-        QF_HIP_TRY(hipMemsetAsync(hit_count, 0, (size_t)(n_rays + 1) * sizeof(int32_t), st));
-    } else {
-        QF_HIP_TRY(hipMemsetAsync(hit_count, 0, (size_t)n_rays * sizeof(int32_t), st));
-        QF_HIP_TRY(hipMemsetAsync(overflow, 0, sizeof(int32_t), st));
-    }
+    const int rc_zero = raster_zero(n_rays, hit_count, overflow, origin_flag, st);
+    if (rc_zero != QF_OK) return rc_zero;
     const RasterCam rc = make_raster_cam(cam);
+    const uint32_t *o_bits = reinterpret_cast<const uint32_t *>(rays_o);
     if (bvh->n_tri > 0) {
         // Lanes per triangle: the per-triangle set-up (projection, edge equations) is replicated in every lane, so few
         // lanes win for pixel-sized triangles (measured on the 983 040-triangle 800x800 frame: 1/2/4/8 lanes ->
@@ -2369,14 +2429,14 @@ static int raster_launch(qf_bvh *bvh, const qf_camera *cam, const float *rays_o,
             const int parity = bvh->cull_parity;
             bvh->cull_parity ^= 1;
             hipLaunchKernelGGL(cull_chunks_kernel, dim3((unsigned)qf_div_up(n_chunks, 256)), dim3(256), 0, st, boxes,
-                               (int)n_chunks, rc, visible, counters, parity);
+                               (int)n_chunks, rc, visible, counters, parity, o_bits, n_rays * 3, origin_flag);
             QF_LAUNCH_CHECK();
             const int64_t items = n_chunks * (kCullChunk * lanes / 256);
             const int64_t cap = (int64_t)qf_cu_count_cached() * 8;
             const unsigned grid = (unsigned)(items < cap ? items : cap);
 #define QF_RASTER_CULLED(L, WIDE)                                                                                      \
     hipLaunchKernelGGL((raster_culled_kernel<L, WIDE>), dim3(grid), dim3(256), 0, st, tris4, bvh->n_tri, rc, rays_o,  \
-                       rays_d, capacity, hit_tri, hit_t, hit_count, overflow, visible, counters + parity)
+                       rays_d, capacity, hit_tri, hit_t, hit_count, overflow, visible, counters + parity, origin_flag)
             if (wide) {
                 switch (lanes) {
                 case 16: QF_RASTER_CULLED(16, true); break;
@@ -2394,10 +2454,15 @@ static int raster_launch(qf_bvh *bvh, const qf_camera *cam, const float *rays_o,
             QF_LAUNCH_CHECK();
             return QF_OK;
         }
+        if (origin_flag) {
+            const int64_t n3 = n_rays * 3;
+            hipLaunchKernelGGL(origin_check_kernel, dim3(qf_grid_1d(n3, 256)), dim3(256), 0, st, o_bits, n3, rc, origin_flag);
+            QF_LAUNCH_CHECK();
+        }
 #define QF_RASTER_LAUNCH(L, WIDE)                                                                                     \
     hipLaunchKernelGGL((raster_kernel<L, WIDE>), dim3((unsigned)blocks), dim3(256), 0, st,                           \
                        reinterpret_cast<const float4 *>(bvh->d_tris), bvh->n_tri, rc, rays_o, rays_d, capacity,      \
-                       hit_tri, hit_t, hit_count, overflow)
+                       hit_tri, hit_t, hit_count, overflow, origin_flag)
         if (wide) {
             switch (lanes) {
             case 16: QF_RASTER_LAUNCH(16, true); break;
@@ -2426,13 +2491,14 @@ static bool raster_args_ok(const qf_bvh *bvh, const qf_camera *cam, int64_t n_ra
 
 extern "C" int qf_raster_intersect(qf_bvh *bvh, const qf_camera *cam, const float *rays_o, const float *rays_d,
                                    int64_t n_rays, int32_t max_hits, int32_t *hit_tri, float *hit_t, int32_t *hit_count,
-                                   int32_t *overflow, int32_t sort_lists, int32_t cull_chunks, void *stream)
+                                   int32_t *overflow, int32_t sort_lists, int32_t cull_chunks, int32_t *origin_flag,
+                                   void *stream)
 {
     if (!raster_args_ok(bvh, cam, n_rays, max_hits)) return QF_ERR_INVALID_ARGUMENT;
     if (!rays_o || !rays_d || !hit_tri || !hit_t || !hit_count || !overflow) return QF_ERR_INVALID_ARGUMENT;
     hipStream_t st = qf_stream(stream);
     const int rc = raster_launch(bvh, cam, rays_o, rays_d, n_rays, (int)max_hits, false, hit_tri, hit_t, hit_count, overflow,
-                                 cull_chunks != 0, st);
+                                 origin_flag, cull_chunks != 0, st);
     if (rc != QF_OK) return rc;
     if (sort_lists && n_rays > 0) return filter_launch(n_rays, max_hits, bvh->min_sep, hit_tri, hit_t, hit_count, st);
     return QF_OK;
@@ -2441,7 +2507,7 @@ extern "C" int qf_raster_intersect(qf_bvh *bvh, const qf_camera *cam, const floa
 extern "C" int qf_raster_intersect_wide(qf_bvh *bvh, const qf_camera *cam, const float *rays_o, const float *rays_d,
                                         int64_t n_rays, int32_t max_hits, int32_t wide_hits, int32_t *wide_tri,
                                         float *wide_t, int32_t *hit_tri, float *hit_t, int32_t *hit_count,
-                                        int32_t *overflow, int32_t cull_chunks, void *stream)
+                                        int32_t *overflow, int32_t cull_chunks, int32_t *origin_flag, void *stream)
 {
     if (!raster_args_ok(bvh, cam, n_rays, max_hits)) return QF_ERR_INVALID_ARGUMENT;
     if (wide_hits < max_hits || wide_hits > 4096) return QF_ERR_INVALID_ARGUMENT;
@@ -2449,7 +2515,7 @@ extern "C" int qf_raster_intersect_wide(qf_bvh *bvh, const qf_camera *cam, const
         return QF_ERR_INVALID_ARGUMENT;
     hipStream_t st = qf_stream(stream);
     const int rc = raster_launch(bvh, cam, rays_o, rays_d, n_rays, (int)wide_hits, true, wide_tri, wide_t, hit_count, overflow,
-                                 cull_chunks != 0, st);
+                                 origin_flag, cull_chunks != 0, st);
     if (rc != QF_OK) return rc;
     if (n_rays == 0) return QF_OK;
     const size_t lds = (size_t)select_capacity(max_hits, wide_hits, bvh->min_sep) * kSelectBlock * 2 * sizeof(float);
@@ -2473,7 +2539,7 @@ __global__ void slab_init_kernel(SlabCtl *ctl)
 extern "C" int qf_raster_intersect_slabs(qf_bvh *bvh, const qf_camera *cam, const float *rays_o, const float *rays_d,
                                          int64_t n_rays, int32_t max_hits, int32_t wide_hits, int32_t n_slabs,
                                          uint64_t *wide_keys, int32_t *hit_tri, float *hit_t, int32_t *hit_count,
-                                         int32_t *overflow, void *stream)
+                                         int32_t *overflow, int32_t *origin_flag, void *stream)
 {
     if (!raster_args_ok(bvh, cam, n_rays, max_hits)) return QF_ERR_INVALID_ARGUMENT;
     if (n_slabs < 2 || n_slabs > kMaxSlabs) return QF_ERR_INVALID_ARGUMENT;
@@ -2481,12 +2547,8 @@ extern "C" int qf_raster_intersect_slabs(qf_bvh *bvh, const qf_camera *cam, cons
     if (wide_hits <= sel_cap + 1 || wide_hits > 4096) return QF_ERR_INVALID_ARGUMENT;     // room beyond stop_at for one slab's hits
     if (!rays_o || !rays_d || !wide_keys || !hit_tri || !hit_t || !hit_count || !overflow) return QF_ERR_INVALID_ARGUMENT;
     hipStream_t st = qf_stream(stream);
-    if (overflow == hit_count + n_rays) {
-        QF_HIP_TRY(hipMemsetAsync(hit_count, 0, (size_t)(n_rays + 1) * sizeof(int32_t), st));
-    } else {
-        QF_HIP_TRY(hipMemsetAsync(hit_count, 0, (size_t)n_rays * sizeof(int32_t), st));
-        QF_HIP_TRY(hipMemsetAsync(overflow, 0, sizeof(int32_t), st));
-    }
+    const int rc_zero = raster_zero(n_rays, hit_count, overflow, origin_flag, st);
+    if (rc_zero != QF_OK) return rc_zero;
     if (n_rays == 0 || bvh->n_tri == 0) return QF_OK;
     const int rc_boxes = ensure_chunk_boxes(bvh, st);
     if (rc_boxes != QF_OK) return rc_boxes;
@@ -2502,6 +2564,11 @@ extern "C" int qf_raster_intersect_slabs(qf_bvh *bvh, const qf_camera *cam, cons
     int32_t *visible = bvh->d_visible + 2;
     float2 *range = reinterpret_cast<float2 *>(bvh->d_slab_range);
     SlabCtl *ctl = reinterpret_cast<SlabCtl *>(bvh->d_slab_ctl);
+    if (origin_flag) {
+        const int64_t n3 = n_rays * 3;
+        hipLaunchKernelGGL(origin_check_kernel, dim3(qf_grid_1d(n3, 256)), dim3(256), 0, st,
+                           reinterpret_cast<const uint32_t *>(rays_o), n3, rc, origin_flag);
+    }
     hipLaunchKernelGGL(slab_init_kernel, dim3(1), dim3(1), 0, st, ctl);
     hipLaunchKernelGGL(slab_cull_kernel, dim3((unsigned)qf_div_up(n_chunks, 256)), dim3(256), 0, st, boxes, (int)n_chunks, rc,
                        visible, range, ctl);
@@ -2528,7 +2595,7 @@ extern "C" int qf_raster_intersect_slabs(qf_bvh *bvh, const qf_camera *cam, cons
 #define QF_RASTER_SLAB(L)                                                                                              \
     hipLaunchKernelGGL((raster_slab_kernel<L>), dim3(grid), dim3(256), 0, st, tris4, bvh->n_tri, rc, rays_o, rays_d,    \
                        (int)wide_hits, wide_keys, hit_count, overflow, list, ctl, j, (int)n_slabs, stop_at,               \
-                       j == 0 ? (const int32_t *)nullptr : snapshot)
+                       j == 0 ? (const int32_t *)nullptr : snapshot, origin_flag)
         switch (lanes) {
         case 16: QF_RASTER_SLAB(16); break;
         case 8: QF_RASTER_SLAB(8); break;

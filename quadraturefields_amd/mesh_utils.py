@@ -301,11 +301,14 @@ class RayIntersector:
         """Camera-coherent path; returns the lists plus the device overflow counter (unchecked).
         sort_lists=False leaves the lists in arrival order for qf_pack_samples (which sorts while packing)."""
         n = o.shape[0]
-        hit_tri, hit_t, hit_count = self._alloc_hits(n, k)
-        overflow = torch.empty((1,), dtype=torch.int32, device=self.device)
+        hit_tri, hit_t, _ = self._alloc_hits(n, k)
+        # counts | overflow counter | origin flag, zeroed by one fill (qf_raster_intersect's layout convention)
+        counts = torch.empty((n + 2,), dtype=torch.int32, device=self.device)
+        hit_count, overflow = counts[:n], counts[n:n + 1]
         _C.check(_C.lib().qf_raster_intersect(self._handle, ctypes.byref(camera), _C.ptr(o), _C.ptr(d), n, k,
                                               _C.ptr(hit_tri), _C.ptr(hit_t), _C.ptr(hit_count), _C.ptr(overflow),
-                                              1 if sort_lists else 0, 0, _C.stream()), "qf_raster_intersect")
+                                              1 if sort_lists else 0, 0, _C.ptr(counts[n + 1:]), _C.stream()),
+                 "qf_raster_intersect")
         return hit_tri, hit_t, hit_count, overflow
 
     @_on_device
@@ -371,8 +374,9 @@ class RayIntersector:
         hit_tri, hit_t, _ = self._alloc_hits(n, k)
         # the overflow counter rides right behind the counts (qf_raster_intersect then zeroes both with one fill); the
         # offsets scan copies it to the frame's pinned block together with the sample total (one readback)
-        counts = torch.empty((n + 1,), dtype=torch.int32, device=self.device)
-        hit_count, overflow = counts[:n], counts[n:]
+        # (... and the origin flag behind that: qf_raster_intersect's layout convention)
+        counts = torch.empty((n + 2,), dtype=torch.int32, device=self.device)
+        hit_count, overflow, origin_flag = counts[:n], counts[n:n + 1], counts[n + 1:]
         wide = max(int(self.raster_wide), 0)
         # a camera that sees part of the scene (parallel.band_camera sets .cull): cull the triangles in chunks first
         cull = 1 if getattr(camera, "cull", False) else 0
@@ -386,7 +390,7 @@ class RayIntersector:
                 keys = self._wide_scratch[key] = torch.empty((wide_s, n), dtype=torch.int64, device=self.device)
             _C.check(_C.lib().qf_raster_intersect_slabs(self._handle, ctypes.byref(camera), _C.ptr(o), _C.ptr(d), n, k, wide_s,
                                                         int(self.raster_slabs), _C.ptr(keys), _C.ptr(hit_tri), _C.ptr(hit_t),
-                                                        _C.ptr(hit_count), _C.ptr(overflow), _C.stream()),
+                                                        _C.ptr(hit_count), _C.ptr(overflow), _C.ptr(origin_flag), _C.stream()),
                      "qf_raster_intersect_slabs")
         elif wide > k:
             key = (n, wide, _C.raw_stream())
@@ -397,12 +401,13 @@ class RayIntersector:
                                                    torch.empty((wide, n), dtype=torch.float32, device=self.device))
             _C.check(_C.lib().qf_raster_intersect_wide(self._handle, ctypes.byref(camera), _C.ptr(o), _C.ptr(d), n, k, wide,
                                                        _C.ptr(lists[0]), _C.ptr(lists[1]), _C.ptr(hit_tri), _C.ptr(hit_t),
-                                                       _C.ptr(hit_count), _C.ptr(overflow), cull, _C.stream()),
+                                                       _C.ptr(hit_count), _C.ptr(overflow), cull, _C.ptr(origin_flag),
+                                                       _C.stream()),
                      "qf_raster_intersect_wide")
         else:
             _C.check(_C.lib().qf_raster_intersect(self._handle, ctypes.byref(camera), _C.ptr(o), _C.ptr(d), n, k,
                                                   _C.ptr(hit_tri), _C.ptr(hit_t), _C.ptr(hit_count), _C.ptr(overflow),
-                                                  0, cull, _C.stream()), "qf_raster_intersect")
+                                                  0, cull, _C.ptr(origin_flag), _C.stream()), "qf_raster_intersect")
         # pixels that collected more than K candidates: exact K nearest through the BVH, those rays only, no host
         # round trip (afterwards every count is <= K).  With the reference's re-origin rule on, the same launch decides
         # it for every other ray as a keep-mask over its sorted list (the lists are not rewritten); the mask rides on
@@ -759,7 +764,7 @@ class RayIntersector:
         dev = self.device
         cap = n * k
         hit_tri, hit_t, _ = self._alloc_hits(n, k)
-        counts = torch.empty((n + 1,), dtype=torch.int32, device=dev)
+        counts = torch.empty((n + 2,), dtype=torch.int32, device=dev)         # counts | overflow | origin flag
         final_count = torch.empty((n,), dtype=torch.int32, device=dev)
         tile_base = torch.empty((((w + 7) // 8) * ((h + 7) // 8),), dtype=torch.int64, device=dev)
         xyz_c = torch.empty((cap, 3), dtype=torch.float32, device=dev)

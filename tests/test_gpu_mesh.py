@@ -821,3 +821,29 @@ def test_packed_samples_match_oracle_on_every_list_route(device, k):
     for name, g, w in zip(["xyzs", "dirs", "index_ray", "ts", "index_tri", "origins"], got, want):
         assert g.shape == w.shape, name
         assert torch.equal(g.cpu(), w), name
+
+
+def test_origin_flag_camera_centre_or_the_rays_own_origins(device):
+    """qf_raster_intersect's origin_flag: while every ray starts at the camera centre bit for bit the pass takes the
+    origin from the camera struct (flag stays 0); one origin that differs in a single bit (-0.0 for 0.0) raises it and
+    every ray's own origin is loaded again.  Either way the hits are those of the BVH traversal."""
+    from quadraturefields_amd import synthetic
+    from quadraturefields_amd.mesh_utils import RayIntersector, make_camera
+    mesh = _scene(subdiv=3, shells=3)
+    ri = RayIntersector(mesh, max_hits=25)
+    w, h = 96, 64
+    c2w = synthetic.orbit_cameras(1, seed=2)[0].clone()
+    c2w[0, 3] = 0.0                                       # a centre with a zero coordinate: -0.0 == 0.0 but not bitwise
+    focal = synthetic.lego_focal(800) * w / 800.0
+    o, d = synthetic.camera_rays(c2w, focal, w, h, device=device)
+    cam = make_camera(c2w, focal, w, h)
+    n = w * h
+    want = ri._hits_bvh(o.contiguous(), d.contiguous(), 25, w)
+    for flip, flag_want in ((False, 0), (True, 1)):
+        o2 = o.clone()
+        if flip:
+            o2[n // 2 + 7, 0] = -0.0
+        tri, t, cnt, ovf = ri._hits_raster(o2.contiguous(), d.contiguous(), 25, cam, sort_lists=True)
+        assert int(cnt._base[n + 1]) == flag_want and int(ovf.item()) == 0
+        assert torch.equal(cnt, want[2]) and torch.equal(tri, want[0]) and torch.equal(t, want[1])
+    assert int(want[2].sum()) > 2000
