@@ -370,7 +370,7 @@ int qf_filter_hits(const qf_bvh *bvh, int64_t n_rays, int32_t max_hits, int32_t 
  * ray's list full: when it is non-zero the lists are NOT guaranteed to hold the K nearest hits and the caller must
  * fall back to qf_bvh_intersect.  (hit_count and *overflow are zeroed by the call; with overflow == hit_count + n_rays
  * -- the counter stored right behind the counts -- that is one fill launch.)  The camera is only used to bound the
- * search, never for arithmetic.
+ * search, never for arithmetic (but see origin_flag below).
  * sort_lists != 0: lists come out ascending in (t, tri) and padded like qf_bvh_intersect; 0: left in arrival
  * order with raw counts, for qf_pack_samples (which sorts while it packs).                                      */
 typedef struct qf_camera {

@@ -75,8 +75,9 @@ def band_cuts(height: int, world_size: int, row_cost: Optional[Sequence[float]] 
 def band_camera(c2w, focal: float, width: int, height: int, y0: int, y1: int):
     """The pinhole camera whose full pixel grid is rows ``[y0, y1)`` of the ``width x height`` frame of
     ``mesh_utils.make_camera(c2w, focal, width, height)``: same pose and focal length, principal point moved up by
-    ``y0`` rows.  The camera only bounds the intersector's search (it never enters the hit arithmetic), so the band's
-    hits are those of the frame's rays."""
+    ``y0`` rows.  The camera only bounds the intersector's search (of its values only the centre enters the hit
+    arithmetic, and only once the pass has verified that it IS every ray's origin), so the band's hits are those of the
+    frame's rays."""
     from .mesh_utils import make_camera
     cam = make_camera(c2w, focal, width, height)
     cam.cy = height / 2.0 - float(y0)
