@@ -371,8 +371,11 @@ int qf_filter_hits(const qf_bvh *bvh, int64_t n_rays, int32_t max_hits, int32_t 
  * fall back to qf_bvh_intersect.  (hit_count and *overflow are zeroed by the call; with overflow == hit_count + n_rays
  * -- the counter stored right behind the counts -- that is one fill launch.)  The camera is only used to bound the
  * search, never for arithmetic (but see origin_flag below).
- * sort_lists != 0: lists come out ascending in (t, tri) and padded like qf_bvh_intersect; 0: left in arrival
- * order with raw counts, for qf_pack_samples (which sorts while it packs).                                      */
+ * sort_lists = 1: lists come out ascending in (t, tri) and padded like qf_bvh_intersect; 0: left in arrival
+ * order with raw counts, for qf_pack_samples (which sorts while it packs); 2: as 0, and the pass does not write
+ * hit_tri at all (one scattered store less per hit) -- for a render-only frame whose tile pack (qf_pack_tiles with
+ * tri_c = NULL) never reads the ids; hit_tri must still be valid memory: qf_bvh_repair_overflow writes the lists of
+ * the rays it re-traverses.                                                                                     */
 typedef struct qf_camera {
     float c2w[12];      /* row-major 3x4 camera-to-world (OpenGL axes: right, up, back | centre) */
     float fx, fy;       /* focal lengths in pixels */

@@ -675,7 +675,7 @@ __device__ __forceinline__ void raster_triangle(const float4 *__restrict__ tris,
         if (slot < max_hits) {
             const int64_t at = kWide ? (int64_t)slot * ((int64_t)cam.w * cam.h) + ray : ray * max_hits + slot;
             hit_t[at] = t;
-            hit_tri[at] = id;
+            if (hit_tri) hit_tri[at] = id;      // (NULL: a render-only frame's tile pack never reads the ids)
         } else {
             atomicAdd(overflow, 1);      // more than max_hits candidates: the caller re-runs the exact K-nearest BVH path
         }
@@ -2401,8 +2401,9 @@ static int raster_zero(int64_t n_rays, int32_t *hit_count, int32_t *overflow, in
 
 static int raster_launch(qf_bvh *bvh, const qf_camera *cam, const float *rays_o, const float *rays_d, int64_t n_rays,
                          int capacity, bool wide, int32_t *hit_tri, float *hit_t, int32_t *hit_count, int32_t *overflow,
-                         int32_t *origin_flag, bool cull, hipStream_t st)
+                         int32_t *origin_flag, bool cull, hipStream_t st, bool skip_ids = false)
 {
+    if (skip_ids) hit_tri = nullptr;         // the pass leaves the id lists alone (qf_raster_intersect sort_lists = 2)
     const int rc_zero = raster_zero(n_rays, hit_count, overflow, origin_flag, st);
     if (rc_zero != QF_OK) return rc_zero;
     const RasterCam rc = make_raster_cam(cam);
@@ -2496,11 +2497,12 @@ extern "C" int qf_raster_intersect(qf_bvh *bvh, const qf_camera *cam, const floa
 {
     if (!raster_args_ok(bvh, cam, n_rays, max_hits)) return QF_ERR_INVALID_ARGUMENT;
     if (!rays_o || !rays_d || !hit_tri || !hit_t || !hit_count || !overflow) return QF_ERR_INVALID_ARGUMENT;
+    if (sort_lists < 0 || sort_lists > 2) return QF_ERR_INVALID_ARGUMENT;
     hipStream_t st = qf_stream(stream);
     const int rc = raster_launch(bvh, cam, rays_o, rays_d, n_rays, (int)max_hits, false, hit_tri, hit_t, hit_count, overflow,
-                                 origin_flag, cull_chunks != 0, st);
+                                 origin_flag, cull_chunks != 0, st, sort_lists == 2);
     if (rc != QF_OK) return rc;
-    if (sort_lists && n_rays > 0) return filter_launch(n_rays, max_hits, bvh->min_sep, hit_tri, hit_t, hit_count, st);
+    if (sort_lists == 1 && n_rays > 0) return filter_launch(n_rays, max_hits, bvh->min_sep, hit_tri, hit_t, hit_count, st);
     return QF_OK;
 }
 

@@ -16,7 +16,8 @@ extern "C" int qf_frame_render(qf_bvh *bvh, const qf_frame_job *job, void *strea
     int32_t *overflow = j.hit_count + j.n_rays;
     // 1. camera-coherent intersection (lists in arrival order), 2. exact K nearest for the pixels that overflowed
     int rc = qf_raster_intersect(bvh, j.camera, j.rays_o, j.rays_d, j.n_rays, j.max_hits, j.hit_tri, j.hit_t, j.hit_count,
-                                 overflow, 0, j.cull_chunks, overflow + 1, stream);
+                                 overflow, j.tri_c ? 0 : 2 /* no ids wanted: the pass skips their stores */, j.cull_chunks,
+                                 overflow + 1, stream);
     if (rc != QF_OK) return rc;
     rc = qf_bvh_repair_overflow(bvh, j.rays_o, j.rays_d, j.n_rays, j.max_hits, w, j.hit_tri, j.hit_t, j.hit_count, nullptr,
                                 nullptr, stream);
