@@ -15,11 +15,11 @@ cp -r $R/quadraturefields_amd/csrc/*.hip $R/quadraturefields_amd/csrc/*.cpp $R/q
 (cd $W/src && patch -p3 < $R/tools/experiments/cell_record_sim.patch) || { echo "patch failed"; exit 1; }
 build() {   # $1 = 1|2
   mkdir -p $W/obj$1
-  for f in field_eval field_eval_bf16 grid_backward mlp_train scan composite; do
+  for f in field_eval field_eval_bf16 grid_backward mlp_train scan composite optim; do
     /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -I$R/include -I$W/src -DQF_REC_SIM=$1 -c $W/src/$f.hip -o $W/obj$1/$f.o || return 1
   done
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -I$R/include -I$W/src -ffp-contract=off -c $W/src/exact.hip -o $W/obj$1/exact.o || return 1
-  for f in bvh_build misc; do
+  for f in bvh_build misc frame; do
     /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -I$R/include -I$W/src -DQF_ABI_VERSION_OFFSET=1000 -x hip -c $W/src/$f.cpp -o $W/obj$1/$f.o || return 1
   done
   /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o $W/libqf_sim$1.so $W/obj$1/*.o
