@@ -520,3 +520,19 @@ def test_one_call_frame_equals_the_separately_bound_launches(device, packed):
         assert torch.equal(f_one.hit_count, f_sep.hit_count) and torch.equal(f_one.tile_base, f_sep.tile_base)
         total = int(f_one.total_dev.item())
         assert torch.equal(f_one.depth_c[:total], f_sep.depth_c[:total])
+    # a caller-supplied background colour and the black one go through the job's bg_mode / bkgd fields
+    bk = torch.tensor([0.2, 0.5, 0.7], device=device)
+    for colour, bkgd in (("custom", bk), ("black", None)):
+        fr2 = FrameRenderer(mi, field, bg_color=colour)
+        one = fr2.render_async(o, d, full, render_bkgd=bkgd, packed=packed)
+        ready = ri.fused_frame_ready
+        ri.fused_frame_ready = lambda *a, **k: False
+        try:
+            sep = fr2.render_async(o, d, full, render_bkgd=bkgd, packed=packed)
+        finally:
+            ri.fused_frame_ready = ready
+        for a, b in zip(one[:3], sep[:3]):
+            assert (a is None and b is None) or torch.equal(a, b)
+        # rays without samples keep the reference's buffer initialisation: white unless the mode is black (utils.py:863-898)
+        img = one[0][:, :3]
+        assert bool((img[one[3].hit_count == 0] == (1.0 if bkgd is not None else 0.0)).all())
