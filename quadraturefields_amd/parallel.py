@@ -124,13 +124,16 @@ def gather_bands(local: torch.Tensor, cuts: Sequence[int], width: int, rank: int
     if mode == "exact":
         # chunk of rank r = its band followed by ceil(rows_r / C) entries of per-row numbers (only with meta)
         sizes = [rows[r] * width + (_meta_slots(rows[r], c) if meta is not None else 0) for r in range(world_size)]
-        mine = torch.zeros((sizes[rank], c), dtype=local.dtype, device=local.device)
-        mine[:local.shape[0]] = local
+        # the same chunk to every rank: the band (and its per-row numbers) written straight into the world_size copies
+        # all_to_all_single wants -- two broadcast copies (13 MB at 800x800); the slots behind the numbers are never read
+        send3 = torch.empty((world_size, sizes[rank], c), dtype=local.dtype, device=local.device)
+        send3[:, :local.shape[0]] = local
         if meta is not None:
-            mine[local.shape[0]:].view(-1)[:rows[rank]] = meta.to(device=local.device, dtype=local.dtype).reshape(-1)
+            send3[:, local.shape[0]:].reshape(world_size, -1)[:, :rows[rank]] = \
+                meta.to(device=local.device, dtype=local.dtype).reshape(-1)
+        send = send3.view(world_size * sizes[rank], c)
         if staged:
-            mine = mine.cpu()
-        send = mine.repeat(world_size, 1)                       # the same chunk to every rank (a 13 MB copy at 800x800)
+            send = send.cpu()
         buf = torch.empty((sum(sizes), c), dtype=send.dtype, device=send.device)
         work = dist.all_to_all_single(buf, send, output_split_sizes=sizes, input_split_sizes=[sizes[rank]] * world_size,
                                       async_op=async_op)
