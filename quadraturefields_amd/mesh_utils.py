@@ -869,10 +869,27 @@ class RayIntersector:
         return order
 
     @torch.no_grad()
+    def _warn_if_not_unit(self, vectors) -> None:
+        """The re-origin rule compares the ray parameter t with a WORLD distance (``min_separation``), i.e. it assumes unit
+        directions -- what every caller of the reference passes (nerf_synthetic.py:341-358 normalises its rays) and what
+        trimesh enforces itself (it unitises the directions it is given).  Host arrays are cheap to check: warn once."""
+        if self.min_separation <= 0 or getattr(self, "_warned_unit", False) or not isinstance(vectors, np.ndarray):
+            return
+        if vectors.size == 0:
+            return
+        nrm = np.linalg.norm(np.asarray(vectors, dtype=np.float64).reshape(-1, 3), axis=1)
+        if float(np.abs(nrm - 1.0).max()) > 1e-3:
+            import warnings
+            self._warned_unit = True
+            warnings.warn("RayIntersector: ray directions are not unit vectors; the multi-hit rule's separation "
+                          f"({self.min_separation:.3g}) is applied to the ray parameter t, i.e. scaled by 1/|d| -- normalise "
+                          "the directions (as trimesh does) or set min_separation for your parametrisation", stacklevel=3)
+
     def intersects_id(self, origins, vectors, multiple_hits=True, return_locations=True, max_hits=10):
         """numpy (index_tri[S], index_ray[S], locations[S,3]) like trimesh / mesh_utils.py:86-109.  Rows come
         grouped by ray, front to back (a valid ordering: the reference's callers sort anyway)."""
         k = int(max_hits) if multiple_hits else 1
+        self._warn_if_not_unit(vectors)
         out = self.sample_device(origins, vectors, k)
         if out is None:
             return np.zeros(0, np.int64), np.zeros(0, np.int64), np.zeros((0, 3), np.float64)
@@ -962,6 +979,7 @@ class MeshIntersection:
         """numpy 7-tuple (points, dirs, index_ray, depth, index_tri, 0, origins) sorted by (ray, depth), or None
         when nothing is hit -- mesh_utils.py:343-387.  (The reference returns float64 arrays that the loader
         casts to float32, nerf_synthetic.py:256-257; these are the float32 values directly.)"""
+        self.rayintersector._warn_if_not_unit(vectors)
         out = self.sampling_raytrace_device(vectors, origins)
         if out is None:
             return None

@@ -137,3 +137,24 @@ def test_bench_refuses_a_world_it_was_not_launched_with():
     proc = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "0"],
                           env=env, capture_output=True, text=True, timeout=300, cwd=ROOT)
     assert proc.returncode != 0 and '"metric"' not in proc.stdout
+
+
+def test_non_unit_directions_on_the_host_are_called_out():
+    """The multi-hit rule is stated for unit directions: host arrays are checked, once per intersector."""
+    import warnings
+    import numpy as np
+    from quadraturefields_amd.mesh_utils import RayIntersector
+    ri = RayIntersector.__new__(RayIntersector)          # no device needed: only the check itself
+    ri.min_separation = 1e-3
+    d = np.tile(np.array([[0.0, 0.0, 2.0]], np.float32), (4, 1))
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        ri._warn_if_not_unit(d)
+        ri._warn_if_not_unit(d)                          # once
+        assert len(w) == 1 and "unit" in str(w[0].message)
+    ri2 = RayIntersector.__new__(RayIntersector)
+    ri2.min_separation = 1e-3
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        ri2._warn_if_not_unit(d / 2.0)
+        assert len(w) == 0
