@@ -97,3 +97,34 @@ def test_forked_worker_is_refused():
     msg = q.get(timeout=60)
     p.join(timeout=30)
     assert "forked child" in msg and "num_workers=0" in msg
+
+
+def test_struct_layouts_match_the_header(tmp_path):
+    """The ctypes mirrors of the header's structs (``_C.Camera``, ``GridDesc``, ``FieldDesc``, ``SGHead``, ``TextureSet``,
+    ``FrameJob``) have the C compiler's sizes and field offsets: a C translation unit that includes ``include/qf_hip.h``
+    (which must compile as plain C -- it is the FFI boundary) prints them."""
+    import shutil
+    import subprocess
+    from quadraturefields_amd import _C
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    pairs = {"qf_camera": _C.Camera, "qf_grid_desc": _C.GridDesc, "qf_field_desc": _C.FieldDesc, "qf_sg_head": _C.SGHead,
+             "qf_texture_set": _C.TextureSet, "qf_frame_job": _C.FrameJob}
+    lines = ["#include <stdio.h>", "#include <stddef.h>", '#include "qf_hip.h"', "int main(void) {"]
+    for cname, cls in pairs.items():
+        lines.append(f'printf("{cname} size %zu\\n", sizeof({cname}));')
+        for fname, _ in cls._fields_:
+            lines.append(f'printf("{cname} {fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ["return 0;", "}"]
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    inc = os.path.join(ROOT, "include")
+    subprocess.run([gcc, "-std=c99", "-Wall", "-I", inc, str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split("\n")
+    got = {tuple(l.split()[:2]): int(l.split()[2]) for l in out if l.strip()}
+    for cname, cls in pairs.items():
+        assert got[(cname, "size")] == ctypes.sizeof(cls), cname
+        for fname, _ in cls._fields_:
+            assert got[(cname, fname)] == getattr(cls, fname).offset, (cname, fname)
