@@ -14,7 +14,7 @@ import torch
 from . import _C, utils
 from .datasets.utils import Rays
 from .field import Field as _Field
-from .radiance_fields.ngp import NGPRadianceField
+from .radiance_fields.ngp import NGPRadianceField, NGPRadianceFieldSGNew
 
 
 class FrameRenderer:
@@ -135,8 +135,8 @@ class FrameRenderer:
             return rgb, alpha, depth, ri.last_frame
         k = self.mesh_intersect.num_intersections
         deform = self.field_net is not None and scaling != 0
-        if (not deform and type(self.radiance_field) is NGPRadianceField and self.radiance_field.compute_dtype == "fp32"
-                and ri.fused_frame_ready(camera, k)):
+        if (not deform and type(self.radiance_field) in (NGPRadianceField, NGPRadianceFieldSGNew)
+                and self.radiance_field.compute_dtype == "fp32" and ri.fused_frame_ready(camera, k)):
             return self._render_async_one_call(origins, viewdirs, camera, k, render_bkgd, packed)
         frame = ri.sample_frame_device(origins, viewdirs, k, camera)
         _, xyz_c, dirs_c = ri.last_layout
@@ -155,7 +155,7 @@ class FrameRenderer:
 
     def _render_async_one_call(self, origins, viewdirs, camera, k, render_bkgd, packed):
         """``render_async`` when the whole frame is the library's fixed sequence (``qf_frame_render``: intersection,
-        repair, tile offsets, tile pack, NGP field, tile compositor): the buffers are allocated here, the launches are
+        repair, tile offsets, tile pack, the field -- NGP or spherical-Gaussian head --, tile compositor): the buffers are allocated here, the launches are
         enqueued by ONE bound call instead of six -- the host cost of a frame drops from ~0.28 ms to what the
         allocations take, which is what a 0.3 ms row band of a frame sharded over 8 GPUs needs.  Same kernels, same
         arguments, same pixels."""
@@ -172,9 +172,15 @@ class FrameRenderer:
         n, cap = frame.width * frame.height, frame.total
         rgbs = torch.empty((cap, 3), dtype=torch.float32, device=dev)
         sigmas = torch.empty((cap,), dtype=torch.float32, device=dev)
-        desc = rf._field_desc(_C.HEAD_NGP, 0)
         table, base_w = rf.mlp_base.grid_params(), rf.mlp_base.network_params()
-        head_w = rf.mlp_head.params.detach()
+        head_w = sg = sg_params = None
+        if type(rf) is NGPRadianceFieldSGNew:         # spherical-Gaussian head: six parameter tensors behind a host struct
+            desc = rf._field_desc(_C.HEAD_SG, rf.num_g_lobes)
+            sg_params = rf._sg_params()
+            sg = _C.SGHead(*[_C.ptr(t) for t in sg_params])
+        else:
+            desc = rf._field_desc(_C.HEAD_NGP, 0)
+            head_w = rf.mlp_head.params.detach()
         mode = utils._BG.get(self.bg_color, _C.BG_CUSTOM)
         bk = _C.f32c(render_bkgd.detach().reshape(3).to(dev)) if mode == _C.BG_CUSTOM else None
         rgb = alpha = depth = out5 = None
@@ -187,13 +193,15 @@ class FrameRenderer:
             depth = torch.empty((n, 1), dtype=torch.float32, device=dev)
             job.out_rgb, job.out_alpha, job.out_depth = rgb.data_ptr(), alpha.data_ptr(), depth.data_ptr()
         job.field = ctypes.addressof(desc)
-        job.table, job.base_w, job.head_ngp_w = _C.ptr(table).value, _C.ptr(base_w).value, _C.ptr(head_w).value
+        job.table, job.base_w = _C.ptr(table).value, _C.ptr(base_w).value
+        job.head_ngp_w = _C.ptr(head_w).value if head_w is not None else None
+        job.head_sg = ctypes.addressof(sg) if sg is not None else None
         job.rgb_c, job.sigma_c = rgbs.data_ptr(), sigmas.data_ptr()
         job.delta_const, job.bg_mode = float(self.render_step_size), mode
         job.bkgd = bk.data_ptr() if bk is not None else None
         _C.check(_C.lib().qf_frame_render(ri._handle, ctypes.byref(job), _C.stream()), "qf_frame_render")
         ri.fused_frame_done(frame, token)
-        frame._keep = frame._keep + (rgbs, sigmas, table, base_w, head_w, bk)   # referenced until their readers ran
+        frame._keep = frame._keep + (rgbs, sigmas, table, base_w, head_w, sg_params, bk)   # referenced until their readers ran
         return (out5, None, None, frame) if packed else (rgb, alpha, depth, frame)
 
     @torch.no_grad()

@@ -520,6 +520,22 @@ def test_one_call_frame_equals_the_separately_bound_launches(device, packed):
         assert torch.equal(f_one.hit_count, f_sep.hit_count) and torch.equal(f_one.tile_base, f_sep.tile_base)
         total = int(f_one.total_dev.item())
         assert torch.equal(f_one.depth_c[:total], f_sep.depth_c[:total])
+    # the spherical-Gaussian field takes the same call (head_sg)
+    _, mi_sg, field_sg = _scene(device, lobes=6)
+    fr_sg = FrameRenderer(mi_sg, field_sg)
+    ri_sg = mi_sg.rayintersector
+    one = fr_sg.render_async(o, d, full, packed=packed)
+    ready = ri_sg.fused_frame_ready
+    ri_sg.fused_frame_ready = lambda *a, **k: False
+    try:
+        sep = fr_sg.render_async(o, d, full, packed=packed)
+    finally:
+        ri_sg.fused_frame_ready = ready
+    for a, b in zip(one[:3], sep[:3]):
+        assert (a is None and b is None) or torch.equal(a, b)
+    ref = fr_sg.render(o, d, camera=full)
+    if not packed:
+        assert torch.equal(one[0], ref[0]) and torch.equal(one[2], ref[2])
     # a caller-supplied background colour and the black one go through the job's bg_mode / bkgd fields
     bk = torch.tensor([0.2, 0.5, 0.7], device=device)
     for colour, bkgd in (("custom", bk), ("black", None)):
