@@ -54,6 +54,13 @@ __device__ __forceinline__ float safe_inv(float d)
 // (t, tri) lexicographic "a sorts before b"
 __device__ __forceinline__ bool hit_less(float ta, int ia, float tb, int ib) { return ta < tb || (ta == tb && ia < ib); }
 
+// Four consecutive list entries as ONE memory request.  A ray's list starts at ray * K entries, 4-byte aligned only
+// (K = 25 is the default everywhere), and gfx9+ global memory takes dwordx4 accesses at dword alignment: these types
+// make the compiler emit them.  The kernels that walk [ray][K] lists lane = ray are bound by the number of scattered
+// per-lane requests (measured: ~4.75 us per million), so a row costs K / 4 of them instead of K.
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef int i32x4u __attribute__((ext_vector_type(4), aligned(4)));
+
 // A hit as one 64-bit key: t > 0, so its bit pattern orders like its value, and the triangle id breaks ties --
 // key order IS the (t, tri) order of the contract.
 __device__ __forceinline__ uint64_t hit_key(float t, int id) { return ((uint64_t)__float_as_uint(t) << 32) | (uint32_t)id; }
@@ -958,6 +965,29 @@ __host__ __device__ inline int select_capacity(int max_hits, int wide, float min
     const int cap = min_sep > 0.0f ? max_hits + kSelectHeadroom : max_hits;
     return cap < wide ? cap : wide;
 }
+// the first `count` keys of a lane's LDS column -> its [K] row of the hit lists, four entries per memory request
+__device__ __forceinline__ void write_row_from_keys(const uint64_t *lk, int count, float *row_t, int32_t *row_i)
+{
+    int i = 0;
+    for (; i + 4 <= count; i += 4) {
+        f32x4u t4;
+        i32x4u i4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const uint64_t k = lk[(i + e) * kSelectBlock];
+            t4[e] = key_t(k);
+            i4[e] = key_id(k);
+        }
+        *reinterpret_cast<f32x4u *>(row_t + i) = t4;
+        *reinterpret_cast<i32x4u *>(row_i + i) = i4;
+    }
+    for (; i < count; ++i) {
+        const uint64_t k = lk[i * kSelectBlock];
+        row_t[i] = key_t(k);
+        row_i[i] = key_id(k);
+    }
+}
+
 // kKeys: the candidates are 8-byte keys (t bits << 32 | tri) in wide_key [wide][n_rays] (the depth-slab pass).
 template <bool kKeys>
 __global__ __launch_bounds__(kSelectBlock) void select_nearest_kernel(int64_t n_rays, int wide, int max_hits, float min_sep,
@@ -967,10 +997,12 @@ __global__ __launch_bounds__(kSelectBlock) void select_nearest_kernel(int64_t n_
                                                                       int32_t *__restrict__ hit_tri, float *__restrict__ hit_t,
                                                                       int32_t *__restrict__ hit_count)
 {
-    extern __shared__ float select_lds[];
+    // the lane's column: [cap][block] 8-byte keys (t bits << 32 | tri) -- key order IS the (t, tri) order, so the
+    // insertion below is one LDS read, one 64-bit compare and one LDS write per shifted entry (it was two of each on
+    // separate t / tri columns: selection 0.42 -> 0.3 ms on configs[2])
+    extern __shared__ __attribute__((aligned(8))) unsigned char select_lds[];
     const int cap = select_capacity(max_hits, wide, min_sep);
-    float *lt = select_lds + threadIdx.x;                                                  // [cap][block]
-    int *li = reinterpret_cast<int *>(select_lds + (size_t)cap * kSelectBlock) + threadIdx.x;
+    uint64_t *lk = reinterpret_cast<uint64_t *>(select_lds) + threadIdx.x;
     const int64_t r = (int64_t)blockIdx.x * kSelectBlock + threadIdx.x;
     if (r >= n_rays) return;
     const int cnt = hit_count[r];
@@ -997,64 +1029,59 @@ __global__ __launch_bounds__(kSelectBlock) void select_nearest_kernel(int64_t n_
                 }
             }
 #pragma unroll
-            for (int u = 0; u < kCopy; ++u)
-                if (i0 + u < cnt) { row_t[i0 + u] = tb[u]; row_i[i0 + u] = ib[u]; }
+            for (int q = 0; q < kCopy / 4; ++q) {
+                if (i0 + 4 * q + 4 <= cnt) {                    // a whole quartet: one request per array
+                    *reinterpret_cast<f32x4u *>(row_t + i0 + 4 * q) = (f32x4u){tb[4 * q], tb[4 * q + 1], tb[4 * q + 2], tb[4 * q + 3]};
+                    *reinterpret_cast<i32x4u *>(row_i + i0 + 4 * q) = (i32x4u){ib[4 * q], ib[4 * q + 1], ib[4 * q + 2], ib[4 * q + 3]};
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (i0 + 4 * q + e < cnt) { row_t[i0 + 4 * q + e] = tb[4 * q + e]; row_i[i0 + 4 * q + e] = ib[4 * q + e]; }
+                }
+            }
         }
         return;
     }
     // the `held` nearest candidates under (t, tri) (all of them when cnt <= cap), kept SORTED in the column as they
     // arrive: an insertion shifts half the column on average, about what re-finding the maximum after a replacement
-    // cost, and there is no sort left to do afterwards.  The candidates are read eight slots at a time: one slot per
-    // pass is a dependent global load per pass, eight independent loads in flight cost the same latency once.
+    // cost, and there is no sort left to do afterwards.  The candidates are read sixteen slots at a time: one slot per
+    // pass is a dependent global load per pass, sixteen independent loads in flight cost the same latency once.
     const int held = cnt < cap ? cnt : cap;
-    constexpr int kBatch = 8;
+    constexpr int kBatch = 16;
     int n = 0;
-    float max_t = -INFINITY;                 // the column's last (largest) entry, in registers for the common reject
-    int max_i = -1;
+    uint64_t max_key = 0;                    // the column's last (largest) entry, in registers for the common reject
     for (int i0 = 0; i0 < cnt; i0 += kBatch) {
-        float tb[kBatch];
-        int ib[kBatch];
+        uint64_t kb[kBatch];
 #pragma unroll
         for (int u = 0; u < kBatch; ++u) {
             const int i = i0 + u < cnt ? i0 + u : cnt - 1;
-            if (kKeys) {
-                const uint64_t k = wide_key[(int64_t)i * n_rays + r];
-                tb[u] = key_t(k);
-                ib[u] = key_id(k);
-            } else {
-                tb[u] = wide_t[(int64_t)i * n_rays + r];
-                ib[u] = wide_tri[(int64_t)i * n_rays + r];
-            }
+            if (kKeys) kb[u] = wide_key[(int64_t)i * n_rays + r];
+            else kb[u] = hit_key(wide_t[(int64_t)i * n_rays + r], wide_tri[(int64_t)i * n_rays + r]);
         }
 #pragma unroll
         for (int u = 0; u < kBatch; ++u) {
             if (i0 + u >= cnt) break;
-            const float t = tb[u];
-            const int id = ib[u];
+            const uint64_t key = kb[u];
             int j;
             if (n < held) {
                 j = n - 1;
                 ++n;
             } else {
-                if (!hit_less(t, id, max_t, max_i)) continue;
+                if (!(key < max_key)) continue;
                 j = n - 2;                   // the last entry falls out
             }
-            while (j >= 0 && hit_less(t, id, lt[j * kSelectBlock], li[j * kSelectBlock])) {
-                lt[(j + 1) * kSelectBlock] = lt[j * kSelectBlock];
-                li[(j + 1) * kSelectBlock] = li[j * kSelectBlock];
+            while (j >= 0) {
+                const uint64_t other = lk[j * kSelectBlock];
+                if (!(key < other)) break;
+                lk[(j + 1) * kSelectBlock] = other;
                 --j;
             }
-            lt[(j + 1) * kSelectBlock] = t;
-            li[(j + 1) * kSelectBlock] = id;
-            max_t = lt[(n - 1) * kSelectBlock];
-            max_i = li[(n - 1) * kSelectBlock];
+            lk[(j + 1) * kSelectBlock] = key;
+            max_key = lk[(n - 1) * kSelectBlock];
         }
     }
     if (min_sep <= 0.0f) {                   // held == K: any order will do, qf_pack_samples sorts (this one is sorted)
-        for (int i = 0; i < max_hits; ++i) {
-            row_t[i] = lt[i * kSelectBlock];
-            row_i[i] = li[i * kSelectBlock];
-        }
+        write_row_from_keys(lk, max_hits, row_t, row_i);
         hit_count[r] = max_hits;
         return;
     }
@@ -1062,21 +1089,18 @@ __global__ __launch_bounds__(kSelectBlock) void select_nearest_kernel(int64_t n_
     // not decide it: every hit the chain drops lets a farther one in.  Run the chain over the held prefix of the
     // ray's hits.  K kept hits are the answer whatever lies behind; fewer are the answer only if the prefix was the
     // whole list.  Otherwise the ray goes to the paged BVH traversal (count > K marks it for qf_bvh_repair_overflow).
-    float last_t = lt[0];
+    float last_t = key_t(lk[0]);
     int kept = 1;                            // compacted in place: slot `kept` never runs ahead of slot i
     for (int i = 1; i < held && kept < max_hits; ++i) {
-        const float t = lt[i * kSelectBlock];
+        const uint64_t k = lk[i * kSelectBlock];
+        const float t = key_t(k);
         if (!(t > last_t + min_sep)) continue;
         last_t = t;
-        lt[kept * kSelectBlock] = t;
-        li[kept * kSelectBlock] = li[i * kSelectBlock];
+        lk[kept * kSelectBlock] = k;
         ++kept;
     }
     if (kept < max_hits && cnt > held) return;      // hit_count[r] stays > K
-    for (int i = 0; i < kept; ++i) {
-        row_t[i] = lt[i * kSelectBlock];
-        row_i[i] = li[i * kSelectBlock];
-    }
+    write_row_from_keys(lk, kept, row_t, row_i);
     hit_count[r] = kept;
 }
 
@@ -1140,39 +1164,36 @@ __global__ __launch_bounds__(kFilterRays) void filter_hits_kernel(int64_t n_rays
 }
 
 // The same sort fed straight from global memory (the tile kernel): lane = ray reads ITS OWN list -- rows of K entries,
-// as float4s when the rows are 16-byte aligned -- into the network's registers, sorts, and leaves the sorted list in
+// four entries per request (f32x4u) -- into the network's registers, sorts, and leaves the sorted list in
 // its LDS row for the loops that index it by rank.  Every load of the list is independent of the others, so the wave
 // waits for memory once; the staged variant (coalesced loop -> LDS -> registers) waited once per loop iteration, which
 // is what a tile wave's time was made of (one wave per tile, nothing to overlap with).  kN = 16 or 32: network size,
 // picked per tile from its longest list.  `deepest` (wave-uniform) bounds what is read.
 template <int kN, bool kTri>
 __device__ __forceinline__ void load_sort_row(const float *__restrict__ g_t, const int32_t *__restrict__ g_i, int K,
-                                              bool vec4, int cnt, int deepest, float *row_t, int32_t *row_i)
+                                              int cnt, int deepest, float *row_t, int32_t *row_i)
 {
     float t[kN];
     int32_t id[kN];
-    if (vec4) {
 #pragma unroll
-        for (int j = 0; j < kN / 4; ++j) {
-            float4 v = make_float4(INFINITY, INFINITY, INFINITY, INFINITY);
-            int4 w = make_int4(-1, -1, -1, -1);
-            if (4 * j < deepest) {                              // wave-uniform; K % 4 == 0 here, so 4j+3 < K
-                v = reinterpret_cast<const float4 *>(g_t)[j];
-                if (kTri) w = reinterpret_cast<const int4 *>(g_i)[j];
-            }
-            t[4 * j] = v.x; t[4 * j + 1] = v.y; t[4 * j + 2] = v.z; t[4 * j + 3] = v.w;
-            id[4 * j] = w.x; id[4 * j + 1] = w.y; id[4 * j + 2] = w.z; id[4 * j + 3] = w.w;
-        }
-    } else {
+    for (int j = 0; j < kN / 4; ++j) {
+        f32x4u v = {INFINITY, INFINITY, INFINITY, INFINITY};
+        i32x4u w = {-1, -1, -1, -1};
+        if (4 * j < deepest) {                                  // wave-uniform; deepest <= K
+            if (4 * j + 3 < K) {                                // the whole quartet lies inside the row: one request
+                v = *reinterpret_cast<const f32x4u *>(g_t + 4 * j);
+                if (kTri) w = *reinterpret_cast<const i32x4u *>(g_i + 4 * j);
+            } else {                                            // the row's last 1..3 entries
 #pragma unroll
-        for (int k = 0; k < kN; ++k) {
-            t[k] = INFINITY;
-            id[k] = -1;
-            if (k < deepest) {                                  // wave-uniform; deepest <= K
-                t[k] = g_t[k];
-                if (kTri) id[k] = g_i[k];
+                for (int e = 0; e < 3; ++e)
+                    if (4 * j + e < K) {
+                        v[e] = g_t[4 * j + e];
+                        if (kTri) w[e] = g_i[4 * j + e];
+                    }
             }
         }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { t[4 * j + e] = v[e]; id[4 * j + e] = w[e]; }
     }
     if (kTri) {
         uint64_t key[kN];
@@ -1275,9 +1296,8 @@ __global__ __launch_bounds__(kPackRays) void pack_samples_kernel(
             deepest = other > deepest ? other : deepest;
         }
         const int64_t own = tid < nr ? ray0 + tid : ray0;
-        const bool vec4 = (K & 3) == 0 && ((reinterpret_cast<uintptr_t>(hit_t) | reinterpret_cast<uintptr_t>(hit_tri)) & 15) == 0;
-        if (deepest > 16) load_sort_row<32, true>(hit_t + own * K, hit_tri + own * K, K, vec4, cnt, deepest, s_t + tid * Kp, s_tri + tid * Kp);
-        else if (deepest > 0) load_sort_row<16, true>(hit_t + own * K, hit_tri + own * K, K, vec4, cnt, deepest, s_t + tid * Kp, s_tri + tid * Kp);
+        if (deepest > 16) load_sort_row<32, true>(hit_t + own * K, hit_tri + own * K, K, cnt, deepest, s_t + tid * Kp, s_tri + tid * Kp);
+        else if (deepest > 0) load_sort_row<16, true>(hit_t + own * K, hit_tri + own * K, K, cnt, deepest, s_t + tid * Kp, s_tri + tid * Kp);
     } else {
         for (int i = tid; i < nr * K; i += kPackRays) {
             const int r = i / K, k = i - r * K;
@@ -1442,9 +1462,8 @@ __global__ __launch_bounds__(64) void pack_tiles_kernel(
     if (K <= 32) {
         // lists of up to 32 hits: global memory -> registers -> sorted -> the lane's own LDS row (load_sort_row); no lane
         // reads another lane's row below, so no barrier
-        const bool vec4 = (K & 3) == 0 && ((reinterpret_cast<uintptr_t>(hit_t) | reinterpret_cast<uintptr_t>(hit_tri)) & 15) == 0;
-        if (deepest <= 16) load_sort_row<16, kTri>(hit_t + ray * K, hit_tri + ray * K, K, vec4, cnt, deepest, row_t, row_i);
-        else load_sort_row<32, kTri>(hit_t + ray * K, hit_tri + ray * K, K, vec4, cnt, deepest, row_t, row_i);
+        if (deepest <= 16) load_sort_row<16, kTri>(hit_t + ray * K, hit_tri + ray * K, K, cnt, deepest, row_t, row_i);
+        else load_sort_row<32, kTri>(hit_t + ray * K, hit_tri + ray * K, K, cnt, deepest, row_t, row_i);
     } else {
         // stage: the lists of a tile row's pixels lie K apart
         for (int yy = 0; yy < rows; ++yy) {
