@@ -44,7 +44,7 @@ struct qf_bvh {
     float *d_slab_range = nullptr;
     int32_t *d_slab_lists = nullptr;
     void *d_slab_ctl = nullptr;
-    int32_t *d_slab_snapshot = nullptr;   // the pixels' counts at the start of a slab pass
+    int32_t *d_slab_snapshot = nullptr;   // [rays] 16-byte records (direction | the pixel's count at the start of a slab pass)
     int64_t slab_snapshot_rays = 0;
     int64_t n_tri = 0;
     int64_t n_nodes = 0;             // binary build tree

@@ -563,7 +563,7 @@ struct SlabArgs {
     float t_lo, t_hi;
     int stop_at;
     uint64_t *keys;
-    const int32_t *count_before;     // the pixels' counts when this slab's pass started (NULL for the first slab)
+    const float4 *ray_rec;           // per ray (d.xyz, count when this slab's pass started as int bits); NULL for the first slab
 };
 
 // A triangle's screen-space set-up, shared by the passes below: the pixel box it can touch and (when its orientation
@@ -660,12 +660,20 @@ __device__ __forceinline__ void raster_triangle(const float4 *__restrict__ tris,
         const int64_t ray = (int64_t)cy_ * cam.w + cx_;
         // the pixel's K nearest are all in nearer slabs.  Decided on the count the pixel had when this pass STARTED: the
         // live count also moves with this slab's own hits, and stopping on it would keep an arbitrary subset of them
-        if (kSlab && slab.count_before && slab.count_before[ray] >= slab.stop_at) continue;
+        // (the count rides in one 16-byte record with the ray's direction: one request and one round trip for both; read
+        // separately they were two of each per candidate pixel of the later passes)
+        float dx, dy, dz;
+        if (kSlab && slab.ray_rec) {
+            const float4 rr = slab.ray_rec[ray];
+            if (__float_as_int(rr.w) >= slab.stop_at) continue;
+            dx = rr.x; dy = rr.y; dz = rr.z;
+        } else {
+            dx = rays_d[ray * 3]; dy = rays_d[ray * 3 + 1]; dz = rays_d[ray * 3 + 2];
+        }
         // the origin: the camera centre when origin_check has verified that every ray's origin IS that value bit for bit
         // (one scattered 12-byte load less per candidate pixel: 17 % of the pass), the ray's own otherwise
         float ox = cam.cx, oy = cam.cy, oz = cam.cz;
         if (!cam_origin) { ox = rays_o[ray * 3]; oy = rays_o[ray * 3 + 1]; oz = rays_o[ray * 3 + 2]; }
-        float dx = rays_d[ray * 3], dy = rays_d[ray * 3 + 1], dz = rays_d[ray * 3 + 2];
         // origin and direction arrive together: without the pin the compiler sinks the origin's load behind mt_hit's
         // det != 0 branch, a second memory round trip per pixel (measured: configs[2] intersection 2.90 -> 2.62 ms)
         asm volatile("" : "+v"(ox), "+v"(oy), "+v"(oz), "+v"(dx), "+v"(dy), "+v"(dz));
@@ -925,13 +933,22 @@ __global__ __launch_bounds__(256) void slab_assign_kernel(const int32_t *__restr
     for (int j = j0; j <= j1; ++j) lists[(int64_t)j * n_chunks + atomicAdd(&s_base[j], 1)] = chunk;
 }
 
+// Between two slab passes: every ray's direction and the count its pixel holds now, as one 16-byte record (the stop rule
+// of the next pass is decided on THIS count, see raster_triangle).
+__global__ void slab_ray_records_kernel(const float *__restrict__ rays_d, const int32_t *__restrict__ hit_count, int64_t n,
+                                        float4 *__restrict__ rec)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        rec[i] = make_float4(rays_d[i * 3], rays_d[i * 3 + 1], rays_d[i * 3 + 2], __int_as_float(hit_count[i]));
+}
+
 template <int kRasterLanes>
 __global__ __launch_bounds__(256) void raster_slab_kernel(const float4 *__restrict__ tris, int64_t n_tri, RasterCam cam,
                                                           const float *__restrict__ rays_o, const float *__restrict__ rays_d,
                                                           int capacity, uint64_t *__restrict__ keys, int32_t *__restrict__ hit_count,
                                                           int32_t *__restrict__ overflow, const int32_t *__restrict__ list,
                                                           const SlabCtl *__restrict__ ctl, int slab_j, int n_slabs, int stop_at,
-                                                          const int32_t *__restrict__ count_before,
+                                                          const float4 *__restrict__ ray_rec,
                                                           const int32_t *__restrict__ origin_differs)
 {
     const bool cam_origin = origin_differs && *origin_differs == 0;
@@ -942,7 +959,7 @@ __global__ __launch_bounds__(256) void raster_slab_kernel(const float4 *__restri
     slab_edges(ctl, n_slabs, slab_j, &sa.t_lo, &sa.t_hi);
     sa.stop_at = stop_at;
     sa.keys = keys;
-    sa.count_before = count_before;
+    sa.ray_rec = ray_rec;
     const int sub = threadIdx.x % kRasterLanes;
     for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
         const int chunk = list[item / kBlocksPerChunk];
@@ -2602,21 +2619,25 @@ extern "C" int qf_raster_intersect_slabs(qf_bvh *bvh, const qf_camera *cam, cons
     const int64_t cap = (int64_t)qf_cu_count_cached() * 8;
     const unsigned grid = (unsigned)(items < cap ? items : cap);
     const int stop_at = sel_cap + 1;
-    // the counts at the start of each pass: one device-to-device copy between the passes (4 B per ray)
+    // the counts at the start of each later pass, in one record with the ray's direction: rewritten between the passes
     if (bvh->slab_snapshot_rays < n_rays) {
         if (bvh->d_slab_snapshot) (void)hipFree(bvh->d_slab_snapshot);
         bvh->d_slab_snapshot = nullptr;
-        QF_HIP_TRY(hipMalloc((void **)&bvh->d_slab_snapshot, (size_t)n_rays * sizeof(int32_t)));
+        QF_HIP_TRY(hipMalloc((void **)&bvh->d_slab_snapshot, (size_t)n_rays * sizeof(float4)));
         bvh->slab_snapshot_rays = n_rays;
     }
-    int32_t *snapshot = bvh->d_slab_snapshot;
+    float4 *snapshot = reinterpret_cast<float4 *>(bvh->d_slab_snapshot);
     for (int j = 0; j < n_slabs; ++j) {
-        if (j > 0) QF_HIP_TRY(hipMemcpyAsync(snapshot, hit_count, (size_t)n_rays * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+        if (j > 0) {
+            hipLaunchKernelGGL(slab_ray_records_kernel, dim3(qf_grid_1d(n_rays, 256)), dim3(256), 0, st, rays_d, hit_count,
+                               n_rays, snapshot);
+            QF_LAUNCH_CHECK();
+        }
         const int32_t *list = bvh->d_slab_lists + (int64_t)j * n_chunks;
 #define QF_RASTER_SLAB(L)                                                                                              \
     hipLaunchKernelGGL((raster_slab_kernel<L>), dim3(grid), dim3(256), 0, st, tris4, bvh->n_tri, rc, rays_o, rays_d,    \
                        (int)wide_hits, wide_keys, hit_count, overflow, list, ctl, j, (int)n_slabs, stop_at,               \
-                       j == 0 ? (const int32_t *)nullptr : snapshot, origin_flag)
+                       j == 0 ? (const float4 *)nullptr : snapshot, origin_flag)
         switch (lanes) {
         case 16: QF_RASTER_SLAB(16); break;
         case 8: QF_RASTER_SLAB(8); break;
