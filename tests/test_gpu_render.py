@@ -552,3 +552,44 @@ def test_one_call_frame_equals_the_separately_bound_launches(device, packed):
         # rays without samples keep the reference's buffer initialisation: white unless the mode is black (utils.py:863-898)
         img = one[0][:, :3]
         assert bool((img[one[3].hit_count == 0] == (1.0 if bkgd is not None else 0.0)).all())
+
+
+def test_frame_job_is_validated(device):
+    """qf_frame_render refuses a job whose ray count is not the camera's pixel grid, whose lists are missing, or that asks
+    for a field without output arrays -- status -1 (ValueError through _C.check), nothing launched."""
+    import ctypes
+    from quadraturefields_amd import _C, synthetic
+    from quadraturefields_amd.mesh_utils import make_camera
+    mesh, mi, field = _scene(device)
+    ri = mi.rayintersector
+    w, h = 40, 24
+    c2w = synthetic.orbit_cameras(1, seed=3)[0]
+    focal = synthetic.lego_focal(800) * w / 800.0
+    o, d = synthetic.camera_rays(c2w, focal, w, h, device=device)
+    cam = make_camera(c2w, focal, w, h)
+
+    def fresh():
+        ri._raster_backoff = 0
+        job, frame, token = ri.fused_frame_job(o, d, 25, cam)
+        return job, frame
+
+    job, frame = fresh()
+    job.n_rays = w * h - 1
+    with pytest.raises(ValueError):
+        _C.check(_C.lib().qf_frame_render(ri._handle, ctypes.byref(job), _C.stream()), "qf_frame_render")
+    job, frame = fresh()
+    job.hit_t = None
+    with pytest.raises(ValueError):
+        _C.check(_C.lib().qf_frame_render(ri._handle, ctypes.byref(job), _C.stream()), "qf_frame_render")
+    job, frame = fresh()
+    desc = field._field_desc(_C.HEAD_NGP, 0)
+    job.field = ctypes.addressof(desc)           # a field, but no rgb_c / sigma_c
+    job.table, job.base_w = _C.ptr(field.mlp_base.grid_params()).value, _C.ptr(field.mlp_base.network_params()).value
+    job.head_ngp_w = _C.ptr(field.mlp_head.params.detach()).value
+    with pytest.raises(ValueError):
+        _C.check(_C.lib().qf_frame_render(ri._handle, ctypes.byref(job), _C.stream()), "qf_frame_render")
+    torch.cuda.synchronize()
+    # sampling only (field = NULL) is a valid job: the tile pack's slot count arrives in total[0]
+    job, frame = fresh()
+    _C.check(_C.lib().qf_frame_render(ri._handle, ctypes.byref(job), _C.stream()), "qf_frame_render")
+    assert int(frame.total_dev.item()) > 100
