@@ -12,6 +12,7 @@ extern "C" int qf_frame_render(qf_bvh *bvh, const qf_frame_job *job, void *strea
     if (!j.rays_o || !j.rays_d || !j.hit_tri || !j.hit_t || !j.hit_count || !j.final_count || !j.tile_base || !j.total ||
         !j.dropped || !j.xyz_c || !j.dirs_c || !j.depth_c)
         return QF_ERR_INVALID_ARGUMENT;
+    if (j.field && (!j.rgb_c || !j.sigma_c || !j.table || !j.base_w)) return QF_ERR_INVALID_ARGUMENT;   // before any launch
     const int64_t cap = j.n_rays * (int64_t)j.max_hits;
     int32_t *overflow = j.hit_count + j.n_rays;
     // 1. camera-coherent intersection (lists in arrival order), 2. exact K nearest for the pixels that overflowed
@@ -31,7 +32,6 @@ extern "C" int qf_frame_render(qf_bvh *bvh, const qf_frame_job *job, void *strea
     if (rc != QF_OK) return rc;
     if (!j.field) return QF_OK;                 // sampling only
     // 5. the field over min(*total, cap) points, 6. the tile compositor
-    if (!j.rgb_c || !j.sigma_c) return QF_ERR_INVALID_ARGUMENT;
     rc = qf_field_forward(j.field, j.table, j.base_w, j.head_ngp_w, j.head_sg, j.xyz_c, j.dirs_c, cap, j.total, nullptr,
                           j.rgb_c, j.sigma_c, nullptr, nullptr, nullptr, stream);
     if (rc != QF_OK) return rc;
