@@ -1079,21 +1079,34 @@ __global__ __launch_bounds__(kSelectBlock) void select_nearest_kernel(int64_t n_
         for (int u = 0; u < kBatch; ++u) {
             if (i0 + u >= cnt) break;
             const uint64_t key = kb[u];
-            int j;
+            int m;                           // entries of the column that stay: [0, m)
             if (n < held) {
-                j = n - 1;
+                m = n;
                 ++n;
             } else {
                 if (!(key < max_key)) continue;
-                j = n - 2;                   // the last entry falls out
+                m = n - 1;                   // the last entry falls out
             }
-            while (j >= 0) {
-                const uint64_t other = lk[j * kSelectBlock];
-                if (!(key < other)) break;
-                lk[(j + 1) * kSelectBlock] = other;
-                --j;
+            // position by bisection (log2 dependent LDS reads instead of one per shifted entry), then the move with its
+            // reads issued four at a time ahead of the writes (independent of each other; LDS executes a wave's
+            // operations in order)
+            int lo = 0, hi = m;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (lk[mid * kSelectBlock] < key) lo = mid + 1;
+                else hi = mid;
             }
-            lk[(j + 1) * kSelectBlock] = key;
+            int j = m - 1;
+            for (; j - 3 >= lo; j -= 4) {
+                const uint64_t a0 = lk[j * kSelectBlock], a1 = lk[(j - 1) * kSelectBlock], a2 = lk[(j - 2) * kSelectBlock],
+                               a3 = lk[(j - 3) * kSelectBlock];
+                lk[(j + 1) * kSelectBlock] = a0;
+                lk[j * kSelectBlock] = a1;
+                lk[(j - 1) * kSelectBlock] = a2;
+                lk[(j - 2) * kSelectBlock] = a3;
+            }
+            for (; j >= lo; --j) lk[(j + 1) * kSelectBlock] = lk[j * kSelectBlock];
+            lk[lo * kSelectBlock] = key;
             max_key = lk[(n - 1) * kSelectBlock];
         }
     }
