@@ -1061,10 +1061,10 @@ __global__ __launch_bounds__(kSelectBlock) void select_nearest_kernel(int64_t n_
     }
     // the `held` nearest candidates under (t, tri) (all of them when cnt <= cap), kept SORTED in the column as they
     // arrive: an insertion shifts half the column on average, about what re-finding the maximum after a replacement
-    // cost, and there is no sort left to do afterwards.  The candidates are read sixteen slots at a time: one slot per
-    // pass is a dependent global load per pass, sixteen independent loads in flight cost the same latency once.
+    // cost, and there is no sort left to do afterwards.  The candidates are read eight slots at a time: one slot per
+    // pass is a dependent global load per pass, eight independent loads in flight cost the same latency once.
     const int held = cnt < cap ? cnt : cap;
-    constexpr int kBatch = 16;
+    constexpr int kBatch = 8;
     int n = 0;
     uint64_t max_key = 0;                    // the column's last (largest) entry, in registers for the common reject
     for (int i0 = 0; i0 < cnt; i0 += kBatch) {
