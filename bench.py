@@ -7,12 +7,18 @@ ray/mesh intersection (camera-coherent pass, exact BVH traversal as its fallback
 evaluation (fp32 hash grid + MLPs) -> per-ray compositing.  N > 1 (launched by torch.distributed.run, one rank per
 GPU, RCCL):
 
+* before anything is timed, every data-path collective runs once on ~1 KB of known data on device tensors
+  (``parallel.selftest_collectives``): the modes that deliver the right bytes on every rank are the ones used, the run
+  exits non-zero with the backend's error text when none does, and the JSON line carries the evidence
+  (``distributed``: backend, world size, the device of every rank, the chosen modes);
 * ``value`` (weak scaling): the frames of an evaluation run are dealt to the ranks, one frame per rank per step, and
-  every finished frame is exchanged with one all_gather_into_tensor (every rank ends up with every frame);
+  every finished frame goes to rank 0 -- the rank that scores an evaluation run -- with one ``dist.gather``
+  (``--frame-gather all``: all_gather_into_tensor to every rank, the default of rounds 1-3; ``none``: no collective);
 * ``sharded_frame`` (BASELINE configs[3]): ONE frame at a time, cut into cost-balanced row bands over the N ranks
-  (quadraturefields_amd/parallel.py), each band rendered through the same HIP kernels and the bands gathered with one
-  all_gather_into_tensor per frame; looped over eight seeded scenes.  Reported as latency (host waits for every frame)
-  and as pipelined throughput, next to the same loop's 1-rank figure when N = 1.
+  (quadraturefields_amd/parallel.py), each band rendered through the same HIP kernels and the bands exchanged with one
+  collective per frame (``all_to_all_single`` with split sizes; padded all_gather / per-rank broadcasts as fallbacks);
+  looped over eight seeded scenes.  Reported as latency (host waits for every frame) and as pipelined throughput,
+  next to the same loop's 1-rank figure when N = 1.
 
 At N = 1 rank 0 also appends ``configs``: BASELINE configs[2] (1080p, bf16, T = 2^21, dense shells) and configs[4]
 (baked SG textures 4096^2, L = 6), each with the roofline of its own dominant kernel measured with HIP events, and
@@ -38,7 +44,7 @@ N_SHELLS, SUBDIV = 12, 6           # 12 x 81,920 = 983,040 triangles
 STEP = 5e-3
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 ALG_BYTES_PER_POINT = 16 * 8 * 2 * 4   # 16 levels x 8 corners x 2 features x 4 B
-PROFILE_ROUND = "r3"
+PROFILE_ROUNDS = ("r4", "r3", "r2", "r1")      # the newest committed PMC reduction wins
 
 
 def log(msg):
@@ -103,7 +109,7 @@ class Stages:
         packed.record()                   # a back-half stream waits for this before it reads the samples
         return pending, overflow is not None, record, o.shape[0], (o, d, cam), packed
 
-    def finish(self, begun):
+    def finish(self, begun, _retry=False):
         """Second half, on the stream ``begin`` ran on: wait for the sample count, field, compositing."""
         from quadraturefields_amd import utils
         pending, rastered, record, n_rays, frame_in, packed = begun
@@ -135,8 +141,13 @@ class Stages:
             rgb, alpha, _, depth, _ = self._timed("composite", lambda: utils.derive_properties(
                 rgbs, sigmas.reshape(-1), ts, STEP, None, index_ray, bg_color="white", N=n_rays), record)
         if ri.rule_violated():          # some ray had hits closer than the re-origin distance: this frame again, exactly
+            # ONE retry, as the product's FrameRenderer._again (render.py): the intersector has switched to the keep
+            # masks by now, so a second violation means the rule's bookkeeping is broken -- stop, do not loop
+            if _retry:
+                raise RuntimeError("bench: the re-origin rule was violated again on the exact retry of a frame")
             self.rule_redone = getattr(self, "rule_redone", 0) + 1
-            return self.frame(*frame_in, record)
+            o, d, cam = frame_in
+            return self.finish(self.begin(o, d, cam, record), _retry=True)
         return rgb, alpha, depth, ri.frame_samples() if layout is not None else index_ray.shape[0]
 
     def frame_nowait(self, o, d, cam, record=False):
@@ -258,7 +269,7 @@ def timed_field_events(stages, frames, warm):
 def _committed_traffic(name: str):
     """(bytes per point, source) of a dominant kernel from the committed PMC reduction profiles/<round>/<name>, or
     (None, None): bench.py cannot sample PMC counters itself (separate rocprofv3 --pmc passes, tools/config_traffic.sh)."""
-    for rnd in (PROFILE_ROUND, "r2", "r1"):
+    for rnd in PROFILE_ROUNDS:
         path = os.path.join(ROOT, "profiles", rnd, name)
         if os.path.exists(path):
             tj = json.load(open(path))
@@ -616,8 +627,15 @@ def main():
     ap.add_argument("--host-wait", action="store_true",
                     help="round-2 frame: the host waits for every frame's sample count before it launches the field kernel "
                          "(default since round 3: the count stays on the device, no wait -- 1.650 -> 1.628 ms per frame)")
-    ap.add_argument("--no-gather", action="store_true",
-                    help="N > 1: do not all_gather the finished frames of the frame-parallel loop")
+    ap.add_argument("--frame-gather", default=None, choices=["rank0", "all", "none"],
+                    help="N > 1, frame-parallel loop: where the finished frames go.  rank0 (default): dist.gather to rank 0, "
+                         "the rank that scores / stores an evaluation run; all: all_gather_into_tensor to every rank (the "
+                         "default of rounds 1-3); none: no data-path collective")
+    ap.add_argument("--no-gather", action="store_true", help="same as --frame-gather none")
+    ap.add_argument("--repeats", type=int, default=9,
+                    help="after the timed region: this many more untimed-for-value repetitions of the same K-step loop; their "
+                         "median / min / max ms_per_step ride along in the JSON line (`repeat`), so that a 2 %% change is "
+                         "distinguishable from run-to-run noise (0 = skip)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for N > 1 (nccl = RCCL).  gloo + --single-device rehearses the multi-rank "
                          "control flow on a one-GPU box (all ranks on cuda:0)")
@@ -637,6 +655,28 @@ def main():
     assert world == args.gpus, (world, args.gpus)      # launch_guard
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    if args.no_gather:
+        args.frame_gather = "none"
+    if args.frame_gather is not None:
+        parallel.FRAME_GATHER_MODE = args.frame_gather
+    # N > 1: before anything is built or timed, every data-path collective runs once on ~1 KB of known data on device
+    # tensors; the modes that deliver the right bytes on EVERY rank are selected (parallel.GATHER_MODE /
+    # FRAME_GATHER_MODE), and the run stops with the backend's error text when none does
+    dist_info = None
+    if world > 1:
+        try:
+            dist_info = parallel.selftest_collectives(rank, world, device)
+            dist_info["devices"] = parallel.device_report(rank, world, device)
+        except parallel.CollectiveSelfTestError as e:
+            print(f"bench.py: rank {rank}: collective self-test failed: {e}", file=sys.stderr, flush=True)
+            raise SystemExit(3)
+        log(f"collectives ok: {dist_info['backend']}, {dist_info['world_size']} ranks on "
+            f"{dist_info['devices']['distinct_devices']} distinct device(s); bands by {dist_info['band_gather_mode']!r}, "
+            f"frames by {dist_info['frame_gather_mode']!r}; {dist_info['tested']}")
+        if dist_info["devices"]["distinct_devices"] != world and not args.single_device:
+            print(f"bench.py: {world} ranks share {dist_info['devices']['distinct_devices']} device(s): "
+                  f"{dist_info['devices']['ranks']}", file=sys.stderr, flush=True)
+            raise SystemExit(3)
 
     log("building scene (mesh, BVH, field)")
     t_build = time.perf_counter()
@@ -650,10 +690,12 @@ def main():
     rays = [synthetic.camera_rays(cams[i * world + rank], focal, W, H, device=device) for i in range(n_frames)]
     cameras = [None if args.intersector == "bvh" else make_camera(cams[i * world + rank], focal, W, H) for i in range(n_frames)]
     stages = Stages(mi, field)
-    gather = world > 1 and not args.no_gather
+    frame_mode = parallel.FRAME_GATHER_MODE if world > 1 else "none"
+    gather = frame_mode != "none"
     staged = gather and args.backend == "gloo"          # rehearsal: gloo moves host memory
+    receives = gather and (frame_mode == "all" or rank == 0)
     gather_bufs = [torch.empty((world * W * H, 5), dtype=torch.float32, device="cpu" if staged else device)
-                   for _ in range(2)] if gather else None
+                   for _ in range(2)] if receives else [None, None]
 
     # --pipeline 2 (measured, not the default -- see its help text): two frames in flight as a FRONT / BACK pipeline:
     # frame i+1's intersection, offsets, ordering and pack (~0.45 ms) on one stream while frame i's field kernel and
@@ -663,31 +705,31 @@ def main():
     nowait = not args.host_wait and args.intersector == "raster" and args.pipeline == 1
 
     def run(first, last, record):
-        """Frames [first, last); returns (last rgb, total points).  N > 1: every finished frame is all-gathered to
-        every rank; the collective of frame i (RCCL's own stream) overlaps the render of frame i+1 and is waited for
-        before frame i+1's gather starts (two receive buffers alternate)."""
+        """Frames [first, last); returns (last rgb, total points).  N > 1: every finished frame goes to rank 0 with one
+        ``dist.gather`` (``--frame-gather all``: to every rank with one all_gather_into_tensor); the collective of frame
+        i (RCCL's own stream) overlaps the render of frame i+1 and is waited for before frame i+1's exchange starts (two
+        receive buffers alternate)."""
         pts, rgb, pending, prev = 0, None, None, None
 
+        def exchange(rgb, alpha, depth, i):
+            nonlocal pending
+            mine = torch.cat([rgb, alpha, depth], dim=1)
+            if pending is not None:
+                pending()                   # frame i-1's exchange has landed before frame i's starts
+            pending = parallel.gather_frames(mine, rank, world, mode=frame_mode, out=gather_bufs[i & 1], async_op=True)
+
         def complete(begun, i):
-            nonlocal pts, rgb, pending
+            nonlocal pts, rgb
             rgb, alpha, depth, n_pts = stages.finish(begun)
             if gather:
-                mine = torch.cat([rgb, alpha, depth], dim=1)
-                mine = mine.cpu() if staged else mine
-                if pending is not None:
-                    pending[0].wait()
-                pending = (torch.distributed.all_gather_into_tensor(gather_bufs[i & 1], mine, async_op=True), mine)
+                exchange(rgb, alpha, depth, i)
             pts += n_pts
 
         if args.pipeline == 1 and nowait:
             for i in range(first, last):
                 rgb, alpha, depth, _ = stages.frame_nowait(rays[i][0], rays[i][1], cameras[i], record)
                 if gather:
-                    mine = torch.cat([rgb, alpha, depth], dim=1)
-                    mine = mine.cpu() if staged else mine
-                    if pending is not None:
-                        pending[0].wait()
-                    pending = (torch.distributed.all_gather_into_tensor(gather_bufs[i & 1], mine, async_op=True), mine)
+                    exchange(rgb, alpha, depth, i)
         elif args.pipeline == 1:
             for i in range(first, last):
                 complete(stages.begin(rays[i][0], rays[i][1], cameras[i], record), i)
@@ -705,7 +747,7 @@ def main():
                     complete(*prev)
             ri0.scratch_slot = 0
         if pending is not None:
-            pending[0].wait()
+            pending()
         return rgb, pts
 
     # Device spin-up (untimed, before the W warm-up steps): the scene build leaves the GPU idle for seconds and its
@@ -733,14 +775,42 @@ def main():
         pts = sum(stages.frame(rays[i][0], rays[i][1], cameras[i])[3] for i in range(args.warmup, n_frames))
         torch.cuda.synchronize()
     t = torch.tensor([elapsed, float(pts)], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
+    rank_ms = [elapsed / args.steps * 1e3] * 2          # (min, max) of the ranks' own ms_per_step
     if world > 1:
-        tmax = t.clone()
+        tmax, tmin, tsum = t.clone(), t.clone(), t.clone()
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
-        tsum = t.clone()
+        torch.distributed.all_reduce(tmin, op=torch.distributed.ReduceOp.MIN)
         torch.distributed.all_reduce(tsum, op=torch.distributed.ReduceOp.SUM)
+        rank_ms = [float(tmin[0]) / args.steps * 1e3, float(tmax[0]) / args.steps * 1e3]
         elapsed, pts_total = float(tmax[0]), float(tsum[1])
     else:
         pts_total = float(pts)
+
+    # The timed region is K = 20 steps of ~1.6 ms: 32 ms.  `value` comes from it alone (the contract), but one such
+    # sample cannot tell a 2 % change from noise -- so the same K-step loop runs `--repeats` more times, each bracketed
+    # exactly like the timed region, and the spread rides along.
+    repeat = None
+    if args.repeats > 0:
+        samples = []
+        for _ in range(args.repeats):
+            if world > 1:
+                torch.distributed.barrier()
+            torch.cuda.synchronize()
+            r0 = time.perf_counter()
+            run(args.warmup, n_frames, False)
+            if world > 1:
+                torch.distributed.barrier()
+            torch.cuda.synchronize()
+            samples.append(time.perf_counter() - r0)
+        rt = torch.tensor(samples, dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
+        if world > 1:
+            torch.distributed.all_reduce(rt, op=torch.distributed.ReduceOp.MAX)
+        per_step = (rt.cpu().numpy() / args.steps * 1e3).tolist()
+        repeat = {"what": f"{args.repeats} more repetitions of the timed region's {args.steps}-step loop (same frames, same "
+                          "barriers, max over ranks each; no HIP events inside); `value` does not use them",
+                  "ms_per_step_median": float(np.median(per_step)), "ms_per_step_min": float(np.min(per_step)),
+                  "ms_per_step_max": float(np.max(per_step)),
+                  "value_at_median": W * H * world / (float(np.median(per_step)) * 1e-3)}
 
     sharded = None
     if args.scenes > 0:             # every rank takes part
@@ -771,7 +841,7 @@ def main():
     # command, see profiles/<round>/README.md); bench.py cannot sample them itself, so the committed measurement is
     # scaled to this run's points per launch.
     traffic = traffic_src = None
-    for rnd in (PROFILE_ROUND, "r2", "r1"):
+    for rnd in PROFILE_ROUNDS:
         tpath = os.path.join(ROOT, "profiles", rnd, "field_traffic.json")
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
@@ -810,8 +880,11 @@ def main():
             "frames_in_flight": args.pipeline,
             "host_wait_per_frame": not nowait,
             "parallelism": f"{world} rank(s), the frames dealt round-robin to the ranks, one frame per rank per step"
-                           + (", all_gather_into_tensor of the finished frames" if gather else ", no data-path collective"),
+                           + {"rank0": ", dist.gather of every finished frame to rank 0 (20 B/ray)",
+                              "all": ", all_gather_into_tensor of every finished frame to every rank",
+                              "none": ", no data-path collective"}[frame_mode],
         },
+        "ms_per_step_ranks": {"min": rank_ms[0], "max": rank_ms[1]},
         "quadrature_points_per_frame": pts_per_launch,
         "field_evals_per_s": pts_total / elapsed,
         "field_evals_per_s_in_kernel": pts_per_launch / field_s if field_s > 0 else None,
@@ -827,6 +900,11 @@ def main():
             "avg_launch_ms": ms["field"],
         },
     }
+    if repeat is not None:
+        result["repeat"] = repeat
+    result["distributed"] = dist_info if dist_info is not None else {
+        "backend": None, "world_size": 1, "note": "one rank: no process group, no collective",
+        "devices": parallel.device_report(0, 1, device)}
     if sharded is not None:
         result["sharded_frame"] = sharded
     if world == 1 and not args.no_reference_route and args.up_sample == 1:

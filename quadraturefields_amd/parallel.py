@@ -93,6 +93,8 @@ def band_camera(c2w, focal: float, width: int, height: int, y0: int, y1: int):
 #: frame: the bytes on the wire are the frame's own 20 B/ray, nothing is padded, nothing is concatenated afterwards.
 #: "padded": one ``all_gather_into_tensor`` of the bands padded to the tallest (round 2; with cost-balanced cuts of an
 #: 800-row frame over 8 ranks -- [224, 72, 56, 48, 48, 56, 72, 224] rows -- that moved 28.7 MB for a 12.8 MB frame).
+#: "broadcast": one ``dist.broadcast`` per rank straight into place in the frame (the plainest primitive; the last
+#: resort of ``selftest_collectives``, which picks the first of the three that delivers the right bytes on every rank).
 GATHER_MODE = "exact"
 
 
@@ -102,20 +104,23 @@ def _meta_slots(rows: int, c: int) -> int:
 
 
 def gather_bands(local: torch.Tensor, cuts: Sequence[int], width: int, rank: int, world_size: int,
-                 async_op: bool = False, meta: Optional[torch.Tensor] = None, mode: Optional[str] = None):
+                 async_op: bool = False, meta: Optional[torch.Tensor] = None, mode: Optional[str] = None,
+                 force_collective: bool = False):
     """local [rows_r * width, C] (this rank's band, row-major) -> the full frame [H * width, C] on every rank with ONE
     collective (see ``GATHER_MODE``).  ``async_op``: returns a zero-argument callable instead; the collective runs on
     the backend's own stream (RCCL) beside whatever is launched next, and calling the callable makes the current stream
     wait for it and hands out the frame.
     ``meta`` (every rank or none): float32 [rows_r], one number per row of the band (the band's per-row sample counts);
     it rides behind the band in the same collective and comes back as [H]: the result is then
-    ``(frame, meta_of_every_row)``."""
+    ``(frame, meta_of_every_row)``.
+    ``force_collective``: issue the collective even in a one-rank group (``selftest_collectives``: a 1-rank RCCL group
+    on a one-GPU box still runs the backend's real entry points)."""
     rows = [cuts[r + 1] - cuts[r] for r in range(world_size)]
     if local.shape[0] != rows[rank] * width:
         raise ValueError(f"rank {rank}: band has {local.shape[0]} rays, expected {rows[rank] * width}")
     if meta is not None and meta.numel() != rows[rank]:
         raise ValueError(f"rank {rank}: meta has {meta.numel()} entries, expected {rows[rank]}")
-    if world_size == 1:
+    if world_size == 1 and not force_collective:
         result = local if meta is None else (local, meta.to(torch.float32).reshape(-1))
         return (lambda: result) if async_op else result
     mode = GATHER_MODE if mode is None else mode
@@ -151,6 +156,31 @@ def gather_bands(local: torch.Tensor, cuts: Sequence[int], width: int, rank: int
             return (frame.to(local.device), m.to(local.device)) if staged else (frame, m)
 
         return finish_exact if async_op else finish_exact()
+    if mode == "broadcast":
+        # the plainest primitive: rank r broadcasts its chunk into its place of the frame buffer, one call per rank
+        sizes = [rows[r] * width + (_meta_slots(rows[r], c) if meta is not None else 0) for r in range(world_size)]
+        starts = [sum(sizes[:r]) for r in range(world_size)]
+        host = torch.device("cpu") if staged else local.device
+        buf = torch.empty((sum(sizes), c), dtype=local.dtype, device=host)
+        mine = buf[starts[rank]:starts[rank] + sizes[rank]]
+        mine[:local.shape[0]] = local
+        if meta is not None:
+            mine[local.shape[0]:].reshape(-1)[:rows[rank]] = meta.to(device=host, dtype=local.dtype).reshape(-1)
+        works = [dist.broadcast(buf[starts[r]:starts[r] + sizes[r]], src=r, async_op=async_op)
+                 for r in range(world_size) if sizes[r] > 0]
+
+        def finish_broadcast():
+            for w in works:
+                if w is not None:
+                    w.wait()
+            if meta is None:
+                return buf.to(local.device) if staged else buf      # the bands lie back to back: this IS the frame
+            frame = torch.cat([buf[starts[r]:starts[r] + rows[r] * width] for r in range(world_size)], dim=0)
+            m = torch.cat([buf[starts[r] + rows[r] * width:starts[r] + sizes[r]].reshape(-1)[:rows[r]]
+                           for r in range(world_size)], dim=0)
+            return (frame.to(local.device), m.to(local.device)) if staged else (frame, m)
+
+        return finish_broadcast if async_op else finish_broadcast()
     if mode != "padded":
         raise ValueError(f"gather mode {mode!r}")
     band_cap = max(rows) * width
@@ -336,6 +366,201 @@ def gather_frame(local: torch.Tensor, width: int, height: int, rank: int, world_
 
 
 # ----------------------------------------------------------------------------------------------------------
+# whole frames dealt to the ranks (weak scaling: one frame per rank per step)
+
+#: where the finished frames of a frame-parallel run go.  "rank0" (default): ``dist.gather`` to rank 0, the only rank
+#: that scores or stores an evaluation run's images (train_finetune.py:575-629 runs on one device) -- the other ranks
+#: receive nothing.  "all": ``all_gather_into_tensor``, every rank ends up with every frame (rounds 1-3; 7 x 12.8 MB
+#: inbound per rank per 1.6 ms step at 8 ranks, beside a fabric-bound field kernel).  "none": no data-path collective.
+FRAME_GATHER_MODE = "rank0"
+FRAME_GATHER_MODES = ("rank0", "all", "none")
+BAND_GATHER_MODES = ("exact", "padded", "broadcast")
+
+
+def gather_frames(mine: torch.Tensor, rank: int, world_size: int, mode: Optional[str] = None,
+                  out: Optional[torch.Tensor] = None, async_op: bool = False, force_collective: bool = False):
+    """mine [n, C] (this rank's finished frame; the same shape on every rank) -> ``[world, n, C]`` on rank 0 ("rank0")
+    or on every rank ("all"); ``None`` on the ranks that receive nothing.  ``out``: the receive buffer to use
+    ([world * n, C], on the ranks that receive).  ``async_op``: returns a zero-argument callable that waits for the
+    collective (current stream) and returns the result.  The gloo rehearsal on one GPU stages through host memory."""
+    mode = FRAME_GATHER_MODE if mode is None else mode
+    if mode not in FRAME_GATHER_MODES:
+        raise ValueError(f"frame gather mode {mode!r}")
+    n, c = mine.shape
+    if mode == "none" or (world_size == 1 and not force_collective):
+        result = None if mode == "none" else mine.view(1, n, c)
+        return (lambda: result) if async_op else result
+    staged = mine.is_cuda and dist.get_backend() == "gloo"
+    send = (mine.cpu() if staged else mine).contiguous()
+    receives = mode == "all" or rank == 0
+    buf = None
+    if receives:
+        buf = out if out is not None else torch.empty((world_size * n, c), dtype=send.dtype, device=send.device)
+        if buf.shape != (world_size * n, c) or buf.device != send.device:
+            raise ValueError("gather_frames: out must be [world * n, C] on the collective's device")
+    if mode == "all":
+        work = dist.all_gather_into_tensor(buf, send, async_op=async_op)
+    else:
+        parts = list(buf.view(world_size, n, c).unbind(0)) if rank == 0 else None
+        work = dist.gather(send, gather_list=parts, dst=0, async_op=async_op)
+
+    def finish():
+        if work is not None:
+            work.wait()                    # send / buf stay referenced by this closure until then
+        if buf is None:
+            return None
+        res = buf.view(world_size, n, c)
+        return res.to(mine.device) if staged else res
+
+    return finish if async_op else finish()
+
+
+# ----------------------------------------------------------------------------------------------------------
+# the first thing an N > 1 run does: prove the collectives before anything is timed
+
+class CollectiveSelfTestError(RuntimeError):
+    """No usable collective for a data-path exchange (or the ranks' plain all_reduce failed): the run must stop."""
+
+
+def _selftest_band(r: int, rows: int, width: int, c: int) -> torch.Tensor:
+    """The analytically known band of rank r: value = 1000 r + 10 (row-major ray index) + channel (exact in fp32)."""
+    ray = torch.arange(rows * width, dtype=torch.float32)[:, None]
+    return 1000.0 * r + 10.0 * ray + torch.arange(c, dtype=torch.float32)[None, :]
+
+
+def device_report(rank: int, world_size: int, device: Optional[torch.device] = None) -> dict:
+    """Which device every rank computes on, gathered with the group's plain all_reduce (int64 SUM of a one-hot table):
+    ``torch.cuda.current_device()``, PCI domain / bus / device and a 62-bit digest of the device UUID per rank, and the
+    number of DISTINCT physical devices among them (must equal the world size on a real N-GPU run; 1 in the one-GPU
+    rehearsal)."""
+    row = [-1, -1, -1, -1, 0]
+    if device is not None and device.type == "cuda":
+        import hashlib
+        idx = torch.cuda.current_device()
+        props = torch.cuda.get_device_properties(idx)
+        uuid = str(getattr(props, "uuid", ""))
+        row = [idx, int(getattr(props, "pci_domain_id", -1)), int(getattr(props, "pci_bus_id", -1)),
+               int(getattr(props, "pci_device_id", -1)),
+               int.from_bytes(hashlib.sha256(uuid.encode()).digest()[:8], "little") >> 2 if uuid else 0]
+    on = device if (device is not None and dist.is_initialized() and dist.get_backend() == "nccl") else torch.device("cpu")
+    table = torch.zeros((world_size, len(row)), dtype=torch.int64, device=on)
+    table[rank] = torch.tensor(row, dtype=torch.int64, device=on)
+    if world_size > 1 or (dist.is_available() and dist.is_initialized()):
+        dist.all_reduce(table, op=dist.ReduceOp.SUM)
+    rows = table.cpu().tolist()
+    ranks = [{"rank": r, "cuda_device": v[0], "pci": (f"{v[1]:04x}:{v[2]:02x}:{v[3]:02x}" if v[2] >= 0 else None),
+              "uuid_digest": f"{v[4]:016x}" if v[4] else None} for r, v in enumerate(rows)]
+    # physical identity: PCI address when the runtime reports one, else the UUID digest, else the device ordinal
+    ident = [(v[1], v[2], v[3]) if v[2] >= 0 else (("uuid", v[4]) if v[4] else ("ordinal", v[0])) for v in rows]
+    return {"ranks": ranks, "distinct_devices": len(set(ident))}
+
+
+def selftest_collectives(rank: int, world_size: int, device: Optional[torch.device] = None,
+                         band_modes: Sequence[str] = BAND_GATHER_MODES,
+                         frame_modes: Sequence[str] = ("rank0", "all"), select: bool = True) -> dict:
+    """Runs every data-path collective of this module once on ~1 KB of analytically known data -- on ``device``
+    tensors (RCCL) or host tensors (gloo) -- BEFORE anything is timed, and picks the modes to use:
+
+    * band exchange (``gather_bands``): uneven bands with their per-row numbers riding along, blocking and async, for
+      every mode of ``band_modes`` in order of preference (all_to_all_single with split sizes, the padded
+      all_gather_into_tensor, per-rank broadcasts);
+    * frame exchange (``gather_frames``): ``dist.gather`` to rank 0, then ``all_gather_into_tensor``;
+    * the float64 MAX / SUM all_reduce the benchmark takes its max-over-ranks time with.
+
+    A mode counts only if EVERY rank got the right bytes (the ranks agree through an int32 MIN all_reduce).  With
+    ``select`` the first good mode of each kind becomes ``GATHER_MODE`` / ``FRAME_GATHER_MODE``.  Raises
+    ``CollectiveSelfTestError`` carrying the backend's error text when the plain all_reduce fails or no mode of a kind
+    works -- a wrong frame must never be timed.  The returned dict goes into bench.py's JSON line."""
+    global GATHER_MODE, FRAME_GATHER_MODE
+    if not (dist.is_available() and dist.is_initialized()):
+        return {"backend": None, "world_size": world_size, "band_gather_mode": GATHER_MODE,
+                "frame_gather_mode": FRAME_GATHER_MODE, "tested": {}, "note": "no process group (one rank)"}
+    backend = dist.get_backend()
+    on = device if (backend == "nccl" and device is not None) else torch.device("cpu")
+    data_dev = device if device is not None else torch.device("cpu")     # where a rank's results live
+    if dist.get_world_size() != world_size or dist.get_rank() != rank:
+        raise CollectiveSelfTestError(f"process group says rank {dist.get_rank()} of {dist.get_world_size()}, the "
+                                      f"environment rank {rank} of {world_size}")
+    tested = {}
+    # (0) the plain reductions everything else leans on
+    try:
+        t = torch.tensor([float(rank + 1), 1.0], dtype=torch.float64, device=on)
+        tmax, tsum = t.clone(), t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        want_max, want_sum = [float(world_size), 1.0], [world_size * (world_size + 1) / 2.0, float(world_size)]
+        if tmax.cpu().tolist() != want_max or tsum.cpu().tolist() != want_sum:
+            raise CollectiveSelfTestError(f"all_reduce gave MAX {tmax.cpu().tolist()} SUM {tsum.cpu().tolist()}, "
+                                          f"expected {want_max} / {want_sum}")
+        tested["all_reduce_f64"] = "ok"
+    except CollectiveSelfTestError:
+        raise
+    except Exception as e:                                              # noqa: BLE001 -- the backend's own error text
+        raise CollectiveSelfTestError(f"{backend} all_reduce failed on rank {rank}: {type(e).__name__}: {e}") from e
+
+    def agree(flags):
+        f = torch.tensor(flags, dtype=torch.int32, device=on)
+        dist.all_reduce(f, op=dist.ReduceOp.MIN)
+        return [bool(v) for v in f.cpu().tolist()]
+
+    # (1) band exchange: rank r owns (r % 3) + 1 rows of a 3-wide frame, 5 channels; per-row numbers = global row index
+    width, c = 3, 5
+    rows = [(r % 3) + 1 for r in range(world_size)]
+    cuts = [sum(rows[:r]) for r in range(world_size + 1)]
+    want_frame = torch.cat([_selftest_band(r, rows[r], width, c) for r in range(world_size)], dim=0)
+    want_meta = torch.arange(cuts[-1], dtype=torch.float32)
+    local = _selftest_band(rank, rows[rank], width, c).to(data_dev)
+    meta = torch.arange(cuts[rank], cuts[rank + 1], dtype=torch.float32, device=data_dev)
+    errors, flags = {}, []
+    for mode in band_modes:
+        try:
+            frame, m = gather_bands(local, cuts, width, rank, world_size, meta=meta, mode=mode, force_collective=True)
+            frame2 = gather_bands(local, cuts, width, rank, world_size, mode=mode, async_op=True, force_collective=True)()
+            ok = (torch.equal(frame.cpu(), want_frame) and torch.equal(m.cpu(), want_meta)
+                  and torch.equal(frame2.cpu(), want_frame))
+            errors[mode] = None if ok else "wrong bytes"
+        except Exception as e:                                          # noqa: BLE001
+            ok, errors[mode] = False, f"{type(e).__name__}: {e}"
+        flags.append(int(ok))
+    good = agree(flags)
+    for mode, g in zip(band_modes, good):
+        tested[f"band:{mode}"] = "ok" if g else (errors[mode] or "failed on another rank")
+    band_choice = next((m for m, g in zip(band_modes, good) if g), None)
+
+    # (2) frame exchange: every rank sends 6 x 5 numbers
+    mine = _selftest_band(rank, 2, width, c).to(data_dev)
+    want_all = torch.stack([_selftest_band(r, 2, width, c) for r in range(world_size)])
+    errors, flags = {}, []
+    for mode in frame_modes:
+        try:
+            got = gather_frames(mine, rank, world_size, mode=mode, force_collective=True)
+            got2 = gather_frames(mine, rank, world_size, mode=mode, async_op=True, force_collective=True)()
+            if mode == "rank0" and rank != 0:
+                ok = got is None and got2 is None
+            else:
+                ok = torch.equal(got.cpu(), want_all) and torch.equal(got2.cpu(), want_all)
+            errors[mode] = None if ok else "wrong bytes"
+        except Exception as e:                                          # noqa: BLE001
+            ok, errors[mode] = False, f"{type(e).__name__}: {e}"
+        flags.append(int(ok))
+    good = agree(flags)
+    for mode, g in zip(frame_modes, good):
+        tested[f"frame:{mode}"] = "ok" if g else (errors[mode] or "failed on another rank")
+    frame_choice = next((m for m, g in zip(frame_modes, good) if g), None)
+
+    if band_choice is None or frame_choice is None:
+        raise CollectiveSelfTestError(f"{backend}, {world_size} ranks: no working collective for the "
+                                      f"{'band' if band_choice is None else 'frame'} exchange: {tested}")
+    if select:
+        if GATHER_MODE not in band_modes or tested.get(f"band:{GATHER_MODE}") != "ok":
+            GATHER_MODE = band_choice
+        if FRAME_GATHER_MODE != "none" and tested.get(f"frame:{FRAME_GATHER_MODE}") != "ok":
+            FRAME_GATHER_MODE = frame_choice
+    return {"backend": backend, "world_size": dist.get_world_size(), "band_gather_mode": GATHER_MODE,
+            "frame_gather_mode": FRAME_GATHER_MODE, "tested": tested}
+
+
+# ----------------------------------------------------------------------------------------------------------
 
 def init_from_env(backend: str = "nccl"):
     """(rank, local_rank, world_size) from the torchrun environment; initialises the process group if needed."""
@@ -349,8 +574,11 @@ def init_from_env(backend: str = "nccl"):
         if backend == "nccl" and torch.cuda.is_available():
             # bind the rank to its GPU before RCCL comes up, and tell the process group which device it owns
             torch.cuda.set_device(local_rank)
-            dist.init_process_group(backend=backend, rank=rank, world_size=world,
-                                    device_id=torch.device("cuda", local_rank))
+            try:
+                dist.init_process_group(backend=backend, rank=rank, world_size=world,
+                                        device_id=torch.device("cuda", local_rank))
+            except TypeError:               # a torch without the device_id keyword: lazy communicator, same binding
+                dist.init_process_group(backend=backend, rank=rank, world_size=world)
         else:
             dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local_rank, world

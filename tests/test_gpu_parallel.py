@@ -45,6 +45,9 @@ def _worker(rank, world, port, q):
     torch.set_grad_enabled(False)
     parallel.init_from_env("gloo")
     device = torch.device("cuda:0")
+    info = parallel.selftest_collectives(rank, world, device)          # device tensors, host-staged by gloo
+    assert info["band_gather_mode"] == "exact" and info["frame_gather_mode"] == "rank0", info
+    assert parallel.device_report(rank, world, device)["distinct_devices"] == 1      # the rehearsal shares cuda:0
     fr, cams, focal = _build(device)
     sharded = parallel.ShardedFrameRenderer(fr, rank, world)
     ok, cuts = [], []
@@ -150,3 +153,53 @@ def test_band_triangle_culling_keeps_every_hit(device):
         if a is not None:
             assert all(torch.equal(x, y) for x, y in zip(a, b))
     assert a is not None or b is not None or True
+
+
+def _rccl_one_rank_worker(port, q):
+    """A ONE-rank RCCL group on the box's GPU: torch's ProcessGroupNCCL and RCCL's own entry points (all_to_all_single
+    with split sizes, all_gather_into_tensor, gather, broadcast, fp64 / int64 all_reduce on device tensors) all run for
+    real -- what a one-GPU box can prove about the N > 1 path besides the gloo rehearsal."""
+    import torch.distributed as dist
+    from quadraturefields_amd import parallel
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1",
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    try:
+        torch.cuda.set_device(0)
+        device = torch.device("cuda", 0)
+        dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=device)
+        info = parallel.selftest_collectives(0, 1, device)
+        info["devices"] = parallel.device_report(0, 1, device)
+        # and a band / a frame at the bench's real sizes through the selected modes, forced through the collective
+        band = torch.rand((800 * 800, 5), device=device)
+        counts = torch.arange(800, dtype=torch.float32, device=device)
+        frame, m = parallel.gather_bands(band, [0, 800], 800, 0, 1, meta=counts, async_op=True, force_collective=True)()
+        frames = parallel.gather_frames(band, 0, 1, async_op=True, force_collective=True)()
+        torch.cuda.synchronize()
+        info["full_size_ok"] = bool(torch.equal(frame, band) and torch.equal(m, counts) and torch.equal(frames[0], band))
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put(info)
+    except Exception as e:                                              # noqa: BLE001
+        q.put({"error": f"{type(e).__name__}: {e}"})
+
+
+def test_rccl_one_rank_group_runs_every_collective():
+    import json
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_one_rank_worker, args=(_free_port(), q))
+    p.start()
+    info = q.get(timeout=600)
+    p.join(timeout=120)
+    assert "error" not in info, info
+    assert info["backend"] == "nccl" and info["world_size"] == 1
+    assert all(v == "ok" for v in info["tested"].values()), info["tested"]
+    assert set(info["tested"]) == {"all_reduce_f64", "band:exact", "band:padded", "band:broadcast", "frame:rank0", "frame:all"}
+    assert info["band_gather_mode"] == "exact" and info["frame_gather_mode"] == "rank0"
+    assert info["full_size_ok"]
+    assert info["devices"]["distinct_devices"] == 1 and info["devices"]["ranks"][0]["cuda_device"] == 0
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "rccl_selftest_1rank.json"), "w") as f:
+        json.dump(info, f, indent=1)

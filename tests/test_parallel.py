@@ -185,3 +185,92 @@ def test_gather_bands_single_rank_and_shape_check():
     assert parallel.gather_bands(x, [0, 2], 4, 0, 1) is x
     with pytest.raises(ValueError):
         parallel.gather_bands(x, [0, 3], 4, 0, 1)
+
+
+# ----------------------------------------------------------------------------------------------------------
+# the collective self-test an N > 1 run starts with: mode selection, fallbacks, hard failure
+
+def _raiser(name):
+    def fail(*a, **k):
+        raise RuntimeError(f"injected {name} failure")
+    return fail
+
+
+def _selftest_worker(rank, world, port, broken, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank),
+                      WORLD_SIZE=str(world))
+    parallel.init_from_env("gloo")
+    for name in broken:                       # the collective every rank finds broken (what an RCCL build that
+        setattr(dist, name, _raiser(name))    # rejects a call would look like: a synchronous error on every rank)
+    try:
+        info = parallel.selftest_collectives(rank, world)
+        report = parallel.device_report(rank, world)
+        # the selected modes are the ones the module now uses by default: a real exchange through them
+        cuts = [0, 8, 24] if world == 2 else [0, 8, 8, 24]
+        w = 4
+        local = torch.full(((cuts[rank + 1] - cuts[rank]) * w, 5), float(rank))
+        frame = parallel.gather_bands(local, cuts, w, rank, world)
+        ok = all(bool((frame[cuts[r] * w:cuts[r + 1] * w] == r).all()) for r in range(world))
+        frames = parallel.gather_frames(torch.full((6, 5), float(rank)), rank, world)
+        if parallel.FRAME_GATHER_MODE == "rank0" and rank != 0:
+            ok = ok and frames is None
+        else:
+            ok = ok and all(bool((frames[r] == r).all()) for r in range(world))
+        q.put((rank, "ok" if ok else "wrong", info, report))
+    except parallel.CollectiveSelfTestError as e:
+        q.put((rank, "error", str(e), None))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run_selftest(world, broken):
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_selftest_worker, args=(r, world, port, broken, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted(q.get(timeout=90) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return results
+
+
+@pytest.mark.parametrize("world,broken,band,frame", [
+    (2, (), "exact", "rank0"),
+    (3, (), "exact", "rank0"),
+    (2, ("all_to_all_single",), "padded", "rank0"),
+    (3, ("all_to_all_single",), "padded", "rank0"),
+    (2, ("all_to_all_single", "all_gather_into_tensor"), "broadcast", "rank0"),
+    (3, ("gather",), "exact", "all"),
+])
+def test_collective_selftest_picks_a_working_mode(world, broken, band, frame):
+    results = _run_selftest(world, broken)
+    for rank, status, info, report in results:
+        assert status == "ok", (rank, status, info)
+        assert info["backend"] == "gloo" and info["world_size"] == world
+        assert info["band_gather_mode"] == band and info["frame_gather_mode"] == frame
+        assert info["tested"]["all_reduce_f64"] == "ok"
+        for name in broken:                   # the injected error text is in the record
+            hit = [v for v in info["tested"].values() if f"injected {name} failure" in v]
+            assert hit, info["tested"]
+        assert len(report["ranks"]) == world and [r["rank"] for r in report["ranks"]] == list(range(world))
+    assert all(r[2] == results[0][2] for r in results)                     # every rank chose the same modes
+
+
+def test_collective_selftest_fails_loudly_when_nothing_works():
+    results = _run_selftest(2, ("all_to_all_single", "all_gather_into_tensor", "broadcast"))
+    for rank, status, text, _ in results:
+        assert status == "error"
+        assert "no working collective for the band exchange" in text and "injected broadcast failure" in text
+
+
+def test_selftest_without_a_process_group_is_a_no_op():
+    info = parallel.selftest_collectives(0, 1)
+    assert info["backend"] is None and info["band_gather_mode"] == parallel.GATHER_MODE
+    x = torch.arange(30.0).reshape(6, 5)
+    assert parallel.gather_frames(x, 0, 1).shape == (1, 6, 5)
+    assert parallel.gather_frames(x, 0, 1, mode="none") is None
+    with pytest.raises(ValueError):
+        parallel.gather_frames(x, 0, 1, mode="ring")
