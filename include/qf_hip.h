@@ -28,7 +28,7 @@ extern "C" {
 #define QF_ERR_UNSUPPORTED (-3)
 #define QF_ERR_NO_DEVICE (-4)
 
-#define QF_ABI_VERSION 4
+#define QF_ABI_VERSION 5
 #define QF_MAX_LEVELS 16
 #define QF_MAX_LOBES 8
 
@@ -370,7 +370,7 @@ int qf_filter_hits(const qf_bvh *bvh, int64_t n_rays, int32_t max_hits, int32_t 
  * ray's list full: when it is non-zero the lists are NOT guaranteed to hold the K nearest hits and the caller must
  * fall back to qf_bvh_intersect.  (hit_count and *overflow are zeroed by the call; with overflow == hit_count + n_rays
  * -- the counter stored right behind the counts -- that is one fill launch.)  The camera is only used to bound the
- * search, never for arithmetic (but see origin_flag below).
+ * search, never for arithmetic (but see ray_flag below).
  * sort_lists = 1: lists come out ascending in (t, tri) and padded like qf_bvh_intersect; 0: left in arrival
  * order with raw counts, for qf_pack_samples (which sorts while it packs); 2: as 0, and the pass does not write
  * hit_tri at all (one scattered store less per hit) -- for a render-only frame whose tile pack (qf_pack_tiles with
@@ -387,17 +387,27 @@ typedef struct qf_camera {
  * against the camera's image with the triangle pass's own conservative screen-box test, and only the surviving
  * chunks are projected (two small extra launches; the per-frame set-up then shrinks with the band).  Same hits.
  * Culled calls on one handle must be issued on one stream (the handle owns the visible-chunk list).          */
-/* origin_flag (or NULL; also on the two variants below): a device int32 the call zeroes (in the same fill as the counts
- * when it lies right behind the overflow counter: hit_count [n_rays] | overflow | origin_flag) and then raises iff some
- * ray's origin differs BITWISE from the camera centre c2w[:,3].  While it stays zero the pass takes the origin from
- * the camera struct instead of loading it for every candidate pixel -- the same value by construction, one scattered
- * 12-byte load less per candidate (17 % of the pass).  NULL, or a raised flag: every ray's own origin is loaded, as
- * the arithmetic contract above says.  (The check is one small launch before the pass; with cull_chunks it rides in
- * the culling launch.)                                                                                          */
+/* ray_flag (or NULL; also on the two variants below) -- the route's precondition, VERIFIED: a device int32 the call
+ * zeroes (in the same fill as the counts when it lies right behind the overflow counter: hit_count [n_rays] | overflow
+ * | ray_flag) and then raises iff the rays are NOT this camera's pixel grid, i.e. iff for some ray i
+ *   - the origin differs BITWISE from the camera centre c2w[:,3], or
+ *   - the direction, projected with the pass's own projection, lies more than 0.02 px from the centre of pixel
+ *     (i % width, i / width) or behind the camera (the guard band around a projected triangle is 0.25 px; a consistent
+ *     fp32 ray reprojects to within 3e-3 px), or
+ *   - | |d|^2 - 1 | > 1e-4 (qf_raster_intersect_slabs bins by distance, the re-origin rule compares t with a world
+ *     distance).
+ * That is what a consistent ray set is (nerf_synthetic.py:341-366); add_ray_direction_noise (:335-340), a stale or wrong
+ * camera, another up_sample, another ray order all raise it.  While the flag is down the pass takes the origin from the
+ * camera struct (the same value: one scattered 12-byte load less per candidate pixel, 17 % of the pass).  When it is
+ * RAISED the pass returns without writing a hit (all counts stay 0) and qf_bvh_repair_overflow(traverse_all_flag =
+ * ray_flag) traverses every ray through the BVH -- exact for any rays, no host round trip.  A caller that does not run
+ * that repair must read the flag and call qf_bvh_intersect itself.  NULL: NO check -- the caller vouches for the rays,
+ * and every ray's own origin is loaded.  (The check is one small launch before the pass, 24 B/ray streamed; with
+ * cull_chunks it rides in the culling launch.)                                                                   */
 int qf_raster_intersect(qf_bvh *bvh, const qf_camera *cam /* host */, const float *rays_o,
                         const float *rays_d, int64_t n_rays, int32_t max_hits, int32_t *hit_tri, float *hit_t,
                         int32_t *hit_count, int32_t *overflow, int32_t sort_lists, int32_t cull_chunks,
-                        int32_t *origin_flag, void *stream);
+                        int32_t *ray_flag, void *stream);
 /* The same pass for dense scenes, where most rays meet more than K = max_hits triangles (thin concentric shells):
  * up to wide_hits >= max_hits candidates per ray are collected in the scratch lists wide_tri / wide_t
  * ([wide_hits, n_rays], slot-major), then every ray's K nearest under (t, tri) -- the rule of qf_bvh_intersect -- go
@@ -407,7 +417,7 @@ int qf_raster_intersect(qf_bvh *bvh, const qf_camera *cam /* host */, const floa
 int qf_raster_intersect_wide(qf_bvh *bvh, const qf_camera *cam /* host */, const float *rays_o,
                              const float *rays_d, int64_t n_rays, int32_t max_hits, int32_t wide_hits,
                              int32_t *wide_tri, float *wide_t, int32_t *hit_tri, float *hit_t, int32_t *hit_count,
-                             int32_t *overflow, int32_t cull_chunks, int32_t *origin_flag, void *stream);
+                             int32_t *overflow, int32_t cull_chunks, int32_t *ray_flag, void *stream);
 /* qf_raster_intersect_wide without collecting every crossing: the triangle chunks are binned by distance from the camera
  * into n_slabs (2..16) slabs of equal thickness and rasterised nearest slab first, one launch per slab; a hit is
  * accepted by the pass of the slab its t falls into, and a pixel that already holds (selection capacity + 1)
@@ -415,11 +425,13 @@ int qf_raster_intersect_wide(qf_bvh *bvh, const qf_camera *cam /* host */, const
  * candidate lists are 8-byte keys (t bits << 32 | tri), wide_keys [wide_hits, n_rays] slot-major; wide_hits only has to
  * exceed the selection capacity by one slab's worth of crossings (not 4K).  Same result as qf_raster_intersect_wide:
  * hit_tri / hit_t [n_rays, max_hits] hold each ray's K nearest under (t, tri) in arrival order, rays that lost
- * candidates keep hit_count > max_hits for qf_bvh_repair_overflow.  For unit-length camera rays (qf_generate_rays).
+ * candidates keep hit_count > max_hits for qf_bvh_repair_overflow.  Exact for unit-length rays from the camera centre
+ * only (t = distance): pass ray_flag, which verifies exactly that, and run the repair with it.
  * One stream per handle, as with cull_chunks.                                                          */
 int qf_raster_intersect_slabs(qf_bvh *bvh, const qf_camera *cam /* host */, const float *rays_o, const float *rays_d,
                               int64_t n_rays, int32_t max_hits, int32_t wide_hits, int32_t n_slabs, uint64_t *wide_keys,
-                              int32_t *hit_tri, float *hit_t, int32_t *hit_count, int32_t *overflow, int32_t *origin_flag, void *stream);
+                              int32_t *hit_tri, float *hit_t, int32_t *hit_count, int32_t *overflow, int32_t *ray_flag,
+                              void *stream);
 /* The fall-back, per ray: after qf_raster_intersect with sort_lists = 0 (raw counts), re-traverses exactly the rays
  * with hit_count > max_hits through the BVH (exact K nearest under the handle's min_separation rule; their lists and
  * counts are overwritten, in the layout of qf_bvh_intersect) and leaves every other ray's list alone.  No host round
@@ -427,10 +439,14 @@ int qf_raster_intersect_slabs(qf_bvh *bvh, const qf_camera *cam /* host */, cons
  * keep_mask [n_rays] uint64 / raw_count [n_rays] (both or neither, NULL to skip): when the handle's rule is on, the
  * same launch also decides it for every other ray WITHOUT rewriting its list (the lists of a frame are 128 MB; the
  * masks 8): bit i of keep_mask[r] = the i-th hit of ray r in (t, tri) order is kept, raw_count[r] = length of the
- * stored list, hit_count[r] = number kept.  qf_pack_samples takes the two arrays.  Ignored while the rule is off. */
+ * stored list, hit_count[r] = number kept.  qf_pack_samples takes the two arrays.  Ignored while the rule is off.
+ * traverse_all_flag (or NULL): the ray_flag of the camera-coherent pass before it.  Raised (non-zero on the device when
+ * this launch runs): EVERY ray is traversed -- the pass found that the rays are not its camera's pixel grid and wrote
+ * nothing -- so the lists are those of qf_bvh_intersect whatever the rays were.                                  */
 int qf_bvh_repair_overflow(const qf_bvh *bvh, const float *rays_o, const float *rays_d, int64_t n_rays,
                            int32_t max_hits, int32_t image_width, int32_t *hit_tri, float *hit_t,
-                           int32_t *hit_count, uint64_t *keep_mask, int32_t *raw_count, void *stream);
+                           int32_t *hit_count, uint64_t *keep_mask, int32_t *raw_count,
+                           const int32_t *traverse_all_flag, void *stream);
 
 /* Occupancy-grid ray marching: nerfacc 0.5.3 OccGridEstimator.sampling -> traverse_grids for one grid level and
  * cone_angle = 0 (examples/utils.py:137-147,266-285).  Samples are [t0 + k*step, t0 + (k+1)*step],
@@ -467,18 +483,21 @@ int qf_sample_offsets(const int32_t *hit_count, int64_t n_rays, int32_t max_hits
  * tile_base is not NULL (rays = a row-major width x height image) -- tile_base [ceil(w/8)*ceil(h/8)] = the exclusive
  * scan of the 8x8-tile sample totals that qf_coherent_layout takes (round 1: qf_tile_totals + a host-side cumsum).
  * temp: qf_frame_offsets_temp_bytes(n_rays) bytes of device scratch.
- * host_out (or NULL): device-accessible PINNED HOST memory, int64[2]; the scan writes (total, *overflow_in) there
- * itself, so the frame's readback needs no copy kernel -- the host waits for an event recorded after this call.
- * overflow_in (or NULL): the device counter of qf_raster_intersect.                                */
+ * host_out (or NULL): device-accessible PINNED HOST memory, int64[4]; the scan writes [0] = total, [1] = *overflow_in,
+ * [3] = *ray_flag_in there itself ([2] is the pack's), so the frame's readback needs no copy kernel -- the host waits
+ * for an event recorded after this call.
+ * overflow_in / ray_flag_in (or NULL -> 0): the device counter and the ray flag of qf_raster_intersect (policy only:
+ * the repair launch has already acted on both).                                                    */
 int64_t qf_frame_offsets_temp_bytes(int64_t n_rays);
 int qf_frame_offsets(const int32_t *hit_count, int64_t n_rays, int32_t max_hits, int32_t width, int32_t height,
                      int64_t *ray_offset /* [n_rays+1] */, int64_t *tile_base /* or NULL */, void *temp,
-                     int64_t temp_bytes, const int32_t *overflow_in, int64_t *host_out, void *stream);
+                     int64_t temp_bytes, const int32_t *overflow_in, const int32_t *ray_flag_in, int64_t *host_out,
+                     void *stream);
 
 /* The same for a frame that is only rendered: tile_base (as above) and *total (device int64) alone -- what
  * qf_pack_tiles and qf_composite_tiles take -- in two launches, without the per-ray offsets.              */
 int qf_tile_offsets(const int32_t *hit_count, int32_t max_hits, int32_t width, int32_t height, int64_t *tile_base,
-                    int64_t *total, const int32_t *overflow_in, int64_t *host_out,
+                    int64_t *total, const int32_t *overflow_in, const int32_t *ray_flag_in, int64_t *host_out,
                     int32_t *zero_word /* or NULL: a device int32 the scan launch zeroes on the way -- the dropped-hit
                                           counter of the qf_pack_tiles that follows (dropped_is_zero) */, void *stream);
 
@@ -595,7 +614,7 @@ typedef struct qf_frame_job {
     /* scratch */
     int32_t *hit_tri;                   /* [n_rays, K] */
     float *hit_t;                       /* [n_rays, K] */
-    int32_t *hit_count;                 /* [n_rays + 2]: counts | raster overflow counter | origin flag */
+    int32_t *hit_count;                 /* [n_rays + 2]: counts | raster overflow counter | ray flag */
     int32_t *final_count;               /* [n_rays]: counts after the rule (what the compositor walks) */
     int64_t *tile_base;                 /* [ceil(w/8) * ceil(h/8)] */
     int64_t *total;                     /* [3] device: slots | overflow | - */

@@ -119,7 +119,7 @@ _SIGNATURES = {
     "qf_bvh_copy_nodes": (c_int, [_P, _P, c_int64]),
     "qf_bvh_copy_tri_ids": (c_int, [_P, _P, c_int64]),
     "qf_bvh_intersect": (c_int, [_P, _P, _P, c_int64, c_int32, c_int32, _P, _P, _P, _P]),
-    "qf_bvh_repair_overflow": (c_int, [_P, _P, _P, c_int64, c_int32, c_int32, _P, _P, _P, _P, _P, _P]),
+    "qf_bvh_repair_overflow": (c_int, [_P, _P, _P, c_int64, c_int32, c_int32, _P, _P, _P, _P, _P, _P, _P]),
     "qf_raster_intersect": (c_int, [_P, POINTER(Camera), _P, _P, c_int64, c_int32, _P, _P, _P, _P, c_int32, c_int32, _P, _P]),
     "qf_raster_intersect_wide": (c_int, [_P, POINTER(Camera), _P, _P, c_int64, c_int32, c_int32, _P, _P, _P, _P, _P, _P, c_int32, _P,
                                          _P]),
@@ -134,8 +134,8 @@ _SIGNATURES = {
     "qf_sample_offsets_temp_bytes": (c_int64, [c_int64]),
     "qf_sample_offsets": (c_int, [_P, c_int64, c_int32, _P, _P, c_int64, _P]),
     "qf_frame_offsets_temp_bytes": (c_int64, [c_int64]),
-    "qf_frame_offsets": (c_int, [_P, c_int64, c_int32, c_int32, c_int32, _P, _P, _P, c_int64, _P, _P, _P]),
-    "qf_tile_offsets": (c_int, [_P, c_int32, c_int32, c_int32, _P, _P, _P, _P, _P, _P]),
+    "qf_frame_offsets": (c_int, [_P, c_int64, c_int32, c_int32, c_int32, _P, _P, _P, c_int64, _P, _P, _P, _P]),
+    "qf_tile_offsets": (c_int, [_P, c_int32, c_int32, c_int32, _P, _P, _P, _P, _P, _P, _P]),
     "qf_pack_tiles": (c_int, [_P, _P, c_int32, c_int32, c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_float, _P, _P, _P, c_int32, _P]),
     "qf_pack_samples": (c_int, [_P, _P, c_int64, c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_float, _P, _P]),
     "qf_tile_totals": (c_int, [_P, c_int32, c_int32, _P, _P]),
@@ -155,7 +155,7 @@ _SIGNATURES = {
     "qf_texture_shade_points": (c_int, [_P, c_int32, c_int32, c_int32, c_float, _P, _P, _P, _P, _P, c_int64, _P, _P, _P, _P]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
-ABI_VERSION = 4              # QF_ABI_VERSION of include/qf_hip.h
+ABI_VERSION = 5              # QF_ABI_VERSION of include/qf_hip.h
 
 _lib = None
 
@@ -241,6 +241,17 @@ def stream():
             f"in the process that imported the package (pid {_OWNER_PID}).  Use num_workers=0 for the device path, or a "
             "'spawn' multiprocessing context.")
     return c_void_p(raw_stream())
+
+
+def resolve_device(device) -> torch.device:
+    """``torch.device(device)`` WITH an index: "cuda" means the current device at construction time.  The package
+    compares ``device.index`` with the raw current-device ordinal (``mesh_utils._on_device``, the renderers' fast
+    paths); an index-less device never compared equal -- ``FrameRenderer.render_async`` then called itself until
+    RecursionError."""
+    dev = torch.device(device)
+    if dev.type == "cuda" and dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    return dev
 
 
 def f32c(t: torch.Tensor) -> torch.Tensor:

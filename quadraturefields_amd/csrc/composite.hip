@@ -905,7 +905,8 @@ extern "C" int qf_split_layout(const int64_t *index_ray, int64_t n, int32_t widt
                        hit_count, ray_offset, invalid);
     QF_LAUNCH_CHECK();
     // tile bases: exclusive scan of the 8x8-tile totals (the grand total lands in ray_offset[n_rays], where it already is)
-    int rc = qf_tile_offsets(hit_count, 0x7fffffff, width, height, tile_base, ray_offset + n_rays, nullptr, nullptr, nullptr, stream);
+    int rc = qf_tile_offsets(hit_count, 0x7fffffff, width, height, tile_base, ray_offset + n_rays, nullptr, nullptr, nullptr,
+                             nullptr, stream);
     if (rc != QF_OK) return rc;
     const int tiles_x = (width + 7) / 8, tiles_y = (height + 7) / 8;
     hipLaunchKernelGGL(split_order_kernel, dim3(tiles_x * tiles_y), dim3(64), 0, st, hit_count, ray_offset, tile_base,

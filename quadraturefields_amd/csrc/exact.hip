@@ -228,6 +228,7 @@ struct TravArgs {
     uint64_t *keep_mask;         // repair launch only (see bvh8_repair_kernel)
     int32_t *raw_count;
     int tcol_offset;             // repair launch: float offset of the [K][256] distance columns in the LDS
+    const int32_t *all_flag;     // repair launch, or NULL: *all_flag != 0 -> EVERY ray is traversed (camera_rays_check)
 };
 
 // LDS of a workgroup: [kOctRays][K] keys | [kOctRays][K] sorted (only when min_sep > 0) | [kOctRays][stack_cap] stack
@@ -485,7 +486,9 @@ __global__ __launch_bounds__(kTravThreads) void bvh8_repair_kernel(TravArgs a)
         if (ray < a.n_rays) {
             const int c = a.hit_count[ray];
             int need = 0;
-            if (c > K) need = 2;
+            // all_flag raised: the rays were not the camera's pixel grid, the camera-coherent passes returned at once and
+            // the lists are empty -- this launch IS the intersection then, exact for any rays
+            if (c > K || (a.all_flag && *a.all_flag)) need = 2;
             else if (a.keep_mask) {
                 // The rule can only drop a hit if two of the ray's hits lie within min_sep of each other.  One lane
                 // tests that on the distances alone -- no sort: with no such pair every hit is kept whatever the order
@@ -670,7 +673,7 @@ __device__ __forceinline__ void raster_triangle(const float4 *__restrict__ tris,
         } else {
             dx = rays_d[ray * 3]; dy = rays_d[ray * 3 + 1]; dz = rays_d[ray * 3 + 2];
         }
-        // the origin: the camera centre when origin_check has verified that every ray's origin IS that value bit for bit
+        // the origin: the camera centre when camera_rays_check has verified that every ray's origin IS that value bit for bit
         // (one scattered 12-byte load less per candidate pixel: 17 % of the pass), the ray's own otherwise
         float ox = cam.cx, oy = cam.cy, oz = cam.cz;
         if (!cam_origin) { ox = rays_o[ray * 3]; oy = rays_o[ray * 3 + 1]; oz = rays_o[ray * 3 + 2]; }
@@ -702,34 +705,62 @@ __global__ __launch_bounds__(256) void raster_kernel(const float4 *__restrict__ 
                                                      const float *__restrict__ rays_o, const float *__restrict__ rays_d,
                                                      int max_hits, int32_t *__restrict__ hit_tri, float *__restrict__ hit_t,
                                                      int32_t *__restrict__ hit_count, int32_t *__restrict__ overflow,
-                                                     const int32_t *__restrict__ origin_differs)
+                                                     const int32_t *__restrict__ ray_flag)
 {
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t tri_i = gid / kRasterLanes;
     const int sub = (int)(gid % kRasterLanes);
     if (tri_i >= n_tri) return;
-    const bool cam_origin = origin_differs && *origin_differs == 0;
+    if (ray_flag && *ray_flag) return;           // not this camera's pixel grid (camera_rays_check): the BVH answers
+    const bool cam_origin = ray_flag != nullptr; // verified: every origin IS the camera centre
     raster_triangle<kRasterLanes, kWide>(tris, tri_i, sub, cam, rays_o, rays_d, max_hits, hit_tri, hit_t, hit_count, overflow,
                                          cam_origin);
 }
 
-// Do all the rays start at the camera centre, bit for bit?  *differs (zeroed by the caller's fill) is raised otherwise;
-// the passes then read every ray's own origin as before.  rays_o as 3 n words against the centre's three.
-__device__ __forceinline__ void origin_check(const uint32_t *__restrict__ o_bits, int64_t n3, const RasterCam &cam,
-                                             int32_t *__restrict__ differs, int64_t first, int64_t stride)
+// The precondition of the whole camera-coherent route, VERIFIED (round 4): ray i of the batch must be pixel
+// (i % w, i / w) of this camera -- the reference's consistent ray set (nerf_synthetic.py:341-366: every ray starts at
+// c2w[:3,3], its direction is the normalised pixel-centre direction).  Per ray:
+//   * the origin equals the camera centre BIT FOR BIT (the passes then take it from the camera struct; the test uses
+//     -0.0 for 0.0);
+//   * the direction, projected with the very projection the triangle set-up uses, lands within kRayPixelTol of its own
+//     pixel centre -- an order of magnitude inside the 0.25 px guard band, two above the rounding of a consistent ray
+//     (3e-4 px at f = 1111, 3e-3 px at f = 8900) -- and in front of the camera;
+//   * the direction has unit length (| |d|^2 - 1 | <= kRayUnitTol): the depth-slab passes bin by DISTANCE and accept by
+//     t (0.1 % margin), the re-origin rule compares t with a world distance.
+// Any violation (jittered directions of add_ray_direction_noise, nerf_synthetic.py:335-340; a stale or wrong camera;
+// another up_sample; rays in another order; off-centre origins) raises *flag (zeroed by the caller's fill).  A raised
+// flag makes every camera-coherent pass return at once and qf_bvh_repair_overflow traverse EVERY ray through the BVH
+// -- exact for any rays -- instead of the guard-band reject silently dropping hits.  15.4 MB streamed per 800x800 frame.
+constexpr float kRayPixelTol = 0.02f;
+constexpr float kRayUnitTol = 1e-4f;
+
+__device__ __forceinline__ void camera_rays_check(const uint32_t *__restrict__ o_bits, const float *__restrict__ rays_d,
+                                                  int64_t n_rays, const RasterCam &cam, int32_t *__restrict__ flag,
+                                                  int64_t first, int64_t stride)
 {
-    const uint32_t c[3] = {__float_as_uint(cam.cx), __float_as_uint(cam.cy), __float_as_uint(cam.cz)};
+    const uint32_t c0 = __float_as_uint(cam.cx), c1 = __float_as_uint(cam.cy), c2 = __float_as_uint(cam.cz);
     bool bad = false;
-    for (int64_t e = first; e < n3; e += stride) {
-        const int comp = (int)(e % 3);
-        bad |= o_bits[e] != (comp == 0 ? c[0] : (comp == 1 ? c[1] : c[2]));
+    for (int64_t r = first; r < n_rays; r += stride) {
+        const uint32_t o0 = o_bits[r * 3], o1 = o_bits[r * 3 + 1], o2 = o_bits[r * 3 + 2];
+        const float dx = rays_d[r * 3], dy = rays_d[r * 3 + 1], dz = rays_d[r * 3 + 2];
+        bad |= (o0 != c0) | (o1 != c1) | (o2 != c2);
+        const float xc = cam.r00 * dx + cam.r10 * dy + cam.r20 * dz;    // R^T d, as tri_setup projects R^T (v - c)
+        const float yc = cam.r01 * dx + cam.r11 * dy + cam.r21 * dz;
+        const float zv = -(cam.r02 * dx + cam.r12 * dy + cam.r22 * dz);
+        const float sx = cam.fx * (xc / zv) + cam.px0, sy = -cam.fy * (yc / zv) + cam.py0;
+        const float px = (float)(int)(r % cam.w), py = (float)(int)(r / cam.w);
+        // (negated comparisons: a NaN anywhere counts as a violation)
+        bad |= !(zv > 0.0f) | !(fabsf(sx - px) <= kRayPixelTol) | !(fabsf(sy - py) <= kRayPixelTol);
+        bad |= !(fabsf(dx * dx + dy * dy + dz * dz - 1.0f) <= kRayUnitTol);
     }
-    if (bad) *differs = 1;
+    if (bad) *flag = 1;
 }
 
-__global__ void origin_check_kernel(const uint32_t *__restrict__ o_bits, int64_t n3, RasterCam cam, int32_t *__restrict__ differs)
+__global__ void camera_rays_check_kernel(const uint32_t *__restrict__ o_bits, const float *__restrict__ rays_d, int64_t n_rays,
+                                         RasterCam cam, int32_t *__restrict__ flag)
 {
-    origin_check(o_bits, n3, cam, differs, (int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x);
+    camera_rays_check(o_bits, rays_d, n_rays, cam, flag, (int64_t)blockIdx.x * blockDim.x + threadIdx.x,
+                      (int64_t)gridDim.x * blockDim.x);
 }
 
 // ---- triangle culling for cameras that see a PART of the scene (the row bands of parallel.ShardedFrameRenderer: every
@@ -774,13 +805,13 @@ __global__ __launch_bounds__(256) void chunk_boxes_kernel(const float4 *__restri
 // counters[2]: this call appends to counters[parity] and zeroes counters[parity ^ 1] for the next call on the handle
 // (stream order: the previous call's raster kernel, which read it, is done) -- no memset launch per frame.
 __global__ void cull_chunks_kernel(const float4 *__restrict__ boxes, int n_chunks, RasterCam cam, int32_t *__restrict__ visible,
-                                   int32_t *__restrict__ counters, int parity, const uint32_t *__restrict__ o_bits, int64_t n3,
-                                   int32_t *__restrict__ origin_differs)
+                                   int32_t *__restrict__ counters, int parity, const uint32_t *__restrict__ o_bits,
+                                   const float *__restrict__ rays_d, int64_t n_rays, int32_t *__restrict__ ray_flag)
 {
     const int chunk = blockIdx.x * blockDim.x + threadIdx.x;
     if (chunk == 0) counters[parity ^ 1] = 0;
-    // (this launch precedes the pass anyway: it also carries the pass's origin check, see origin_check_kernel)
-    if (origin_differs) origin_check(o_bits, n3, cam, origin_differs, chunk, (int64_t)gridDim.x * blockDim.x);
+    // (this launch precedes the pass anyway: it also carries the pass's ray check, see camera_rays_check_kernel)
+    if (ray_flag) camera_rays_check(o_bits, rays_d, n_rays, cam, ray_flag, chunk, (int64_t)gridDim.x * blockDim.x);
     if (chunk >= n_chunks) return;
     const float4 lo = boxes[chunk * 2], hi = boxes[chunk * 2 + 1];
     if (!(lo.x <= hi.x)) return;                                  // empty chunk
@@ -812,9 +843,10 @@ __global__ __launch_bounds__(256) void raster_culled_kernel(const float4 *__rest
                                                             int max_hits, int32_t *__restrict__ hit_tri, float *__restrict__ hit_t,
                                                             int32_t *__restrict__ hit_count, int32_t *__restrict__ overflow,
                                                             const int32_t *__restrict__ visible, const int32_t *__restrict__ n_visible,
-                                                            const int32_t *__restrict__ origin_differs)
+                                                            const int32_t *__restrict__ ray_flag)
 {
-    const bool cam_origin = origin_differs && *origin_differs == 0;
+    if (ray_flag && *ray_flag) return;           // see raster_kernel
+    const bool cam_origin = ray_flag != nullptr;
     constexpr int kTrisPerBlock = 256 / kRasterLanes;
     constexpr int kBlocksPerChunk = kCullChunk / kTrisPerBlock;       // 1 / 2 / 4 for 4 / 8 / 16 lanes per triangle
     const int n_items = *n_visible * kBlocksPerChunk;
@@ -949,9 +981,10 @@ __global__ __launch_bounds__(256) void raster_slab_kernel(const float4 *__restri
                                                           int32_t *__restrict__ overflow, const int32_t *__restrict__ list,
                                                           const SlabCtl *__restrict__ ctl, int slab_j, int n_slabs, int stop_at,
                                                           const float4 *__restrict__ ray_rec,
-                                                          const int32_t *__restrict__ origin_differs)
+                                                          const int32_t *__restrict__ ray_flag)
 {
-    const bool cam_origin = origin_differs && *origin_differs == 0;
+    if (ray_flag && *ray_flag) return;           // see raster_kernel
+    const bool cam_origin = ray_flag != nullptr;
     constexpr int kTrisPerBlock = 256 / kRasterLanes;
     constexpr int kBlocksPerChunk = kCullChunk / kTrisPerBlock;
     const int n_items = ctl->slab_count[slab_j] * kBlocksPerChunk;
@@ -2106,7 +2139,7 @@ int fill_tex_args(const qf_texture_set *tex, TexArgs *t)
 
 static int bvh_launch(const qf_bvh *bvh, const float *rays_o, const float *rays_d, int64_t n_rays, int32_t max_hits,
                       int32_t image_width, int32_t *hit_tri, float *hit_t, int32_t *hit_count, int only_overflowed,
-                      uint64_t *keep_mask, int32_t *raw_count, void *stream)
+                      uint64_t *keep_mask, int32_t *raw_count, void *stream, const int32_t *all_flag = nullptr)
 {
     if (!bvh || n_rays < 0 || max_hits < 1 || max_hits > kMaxHits || image_width < 0) return QF_ERR_INVALID_ARGUMENT;
     if (bvh->n_tri >= (1 << 28)) return QF_ERR_UNSUPPORTED;      // leaf tokens of the traversal pack (first, count)
@@ -2140,6 +2173,7 @@ static int bvh_launch(const qf_bvh *bvh, const float *rays_o, const float *rays_
     a.keep_mask = (only_overflowed && sep) ? keep_mask : nullptr;
     a.raw_count = a.keep_mask ? raw_count : nullptr;
     a.tcol_offset = (int)tcol_offset;
+    a.all_flag = only_overflowed ? all_flag : nullptr;
     if (only_overflowed) n_blocks = qf_div_up(n_rays, kTravThreads);        // 256 consecutive rays per workgroup
     int64_t per_xcd = qf_div_up(n_blocks, 8);
     a.stripe_blocks = 0;
@@ -2200,11 +2234,12 @@ extern "C" int qf_bvh_intersect(const qf_bvh *bvh, const float *rays_o, const fl
 
 extern "C" int qf_bvh_repair_overflow(const qf_bvh *bvh, const float *rays_o, const float *rays_d, int64_t n_rays,
                                       int32_t max_hits, int32_t image_width, int32_t *hit_tri, float *hit_t,
-                                      int32_t *hit_count, uint64_t *keep_mask, int32_t *raw_count, void *stream)
+                                      int32_t *hit_count, uint64_t *keep_mask, int32_t *raw_count,
+                                      const int32_t *traverse_all_flag, void *stream)
 {
     if ((keep_mask == nullptr) != (raw_count == nullptr)) return QF_ERR_INVALID_ARGUMENT;
     return bvh_launch(bvh, rays_o, rays_d, n_rays, max_hits, image_width, hit_tri, hit_t, hit_count, 1, keep_mask, raw_count,
-                      stream);
+                      stream, traverse_all_flag);
 }
 
 extern "C" int qf_pack_samples(const float *rays_o, const float *rays_d, int64_t n_rays, int32_t max_hits,
@@ -2479,7 +2514,7 @@ static int raster_launch(qf_bvh *bvh, const qf_camera *cam, const float *rays_o,
             const int parity = bvh->cull_parity;
             bvh->cull_parity ^= 1;
             hipLaunchKernelGGL(cull_chunks_kernel, dim3((unsigned)qf_div_up(n_chunks, 256)), dim3(256), 0, st, boxes,
-                               (int)n_chunks, rc, visible, counters, parity, o_bits, n_rays * 3, origin_flag);
+                               (int)n_chunks, rc, visible, counters, parity, o_bits, rays_d, n_rays, origin_flag);
             QF_LAUNCH_CHECK();
             const int64_t items = n_chunks * (kCullChunk * lanes / 256);
             const int64_t cap = (int64_t)qf_cu_count_cached() * 8;
@@ -2505,8 +2540,8 @@ static int raster_launch(qf_bvh *bvh, const qf_camera *cam, const float *rays_o,
             return QF_OK;
         }
         if (origin_flag) {
-            const int64_t n3 = n_rays * 3;
-            hipLaunchKernelGGL(origin_check_kernel, dim3(qf_grid_1d(n3, 256)), dim3(256), 0, st, o_bits, n3, rc, origin_flag);
+            hipLaunchKernelGGL(camera_rays_check_kernel, dim3(qf_grid_1d(n_rays, 256)), dim3(256), 0, st, o_bits, rays_d, n_rays,
+                               rc, origin_flag);
             QF_LAUNCH_CHECK();
         }
 #define QF_RASTER_LAUNCH(L, WIDE)                                                                                     \
@@ -2616,9 +2651,8 @@ extern "C" int qf_raster_intersect_slabs(qf_bvh *bvh, const qf_camera *cam, cons
     float2 *range = reinterpret_cast<float2 *>(bvh->d_slab_range);
     SlabCtl *ctl = reinterpret_cast<SlabCtl *>(bvh->d_slab_ctl);
     if (origin_flag) {
-        const int64_t n3 = n_rays * 3;
-        hipLaunchKernelGGL(origin_check_kernel, dim3(qf_grid_1d(n3, 256)), dim3(256), 0, st,
-                           reinterpret_cast<const uint32_t *>(rays_o), n3, rc, origin_flag);
+        hipLaunchKernelGGL(camera_rays_check_kernel, dim3(qf_grid_1d(n_rays, 256)), dim3(256), 0, st,
+                           reinterpret_cast<const uint32_t *>(rays_o), rays_d, n_rays, rc, origin_flag);
     }
     hipLaunchKernelGGL(slab_init_kernel, dim3(1), dim3(1), 0, st, ctl);
     hipLaunchKernelGGL(slab_cull_kernel, dim3((unsigned)qf_div_up(n_chunks, 256)), dim3(256), 0, st, boxes, (int)n_chunks, rc,

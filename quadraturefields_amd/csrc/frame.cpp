@@ -20,11 +20,14 @@ extern "C" int qf_frame_render(qf_bvh *bvh, const qf_frame_job *job, void *strea
                                  overflow, j.tri_c ? 0 : 2 /* no ids wanted: the pass skips their stores */, j.cull_chunks,
                                  overflow + 1, stream);
     if (rc != QF_OK) return rc;
+    // (... and for EVERY pixel when the pass's ray check found that the rays are not this camera's pixel grid: the pass
+    // wrote nothing then, and this launch is the intersection)
     rc = qf_bvh_repair_overflow(bvh, j.rays_o, j.rays_d, j.n_rays, j.max_hits, w, j.hit_tri, j.hit_t, j.hit_count, nullptr,
-                                nullptr, stream);
+                                nullptr, overflow + 1, stream);
     if (rc != QF_OK) return rc;
     // 3. tile bases + slot total (device; a copy on its way to the pinned block), 4. the tile pack with the re-origin rule
-    rc = qf_tile_offsets(j.hit_count, j.max_hits, w, h, j.tile_base, j.total, overflow, j.host_block, j.dropped, stream);
+    rc = qf_tile_offsets(j.hit_count, j.max_hits, w, h, j.tile_base, j.total, overflow, overflow + 1, j.host_block, j.dropped,
+                         stream);
     if (rc != QF_OK) return rc;
     rc = qf_pack_tiles(j.rays_o, j.rays_d, w, h, j.max_hits, j.hit_tri, j.hit_t, j.hit_count, j.tile_base, j.total, j.xyz_c,
                        j.dirs_c, j.depth_c, j.tri_c, nullptr, nullptr, j.min_separation, j.final_count, j.dropped, nullptr, 1,

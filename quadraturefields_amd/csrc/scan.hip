@@ -80,7 +80,7 @@ __global__ __launch_bounds__(kFoThreads) void frame_partials_kernel(const int32_
 // one workgroup; every thread owns a CONTIGUOUS run of each array, so an array is scanned with one block scan
 __device__ __forceinline__ void frame_scan_body(int64_t *partial, int n_blocks, int64_t *tile_total, int n_tiles,
                                                 int64_t *grand_total, const int32_t *overflow_in, int64_t *host_out,
-                                                int64_t *s_wave)
+                                                int64_t *s_wave, const int32_t *ray_flag_in)
 {
     for (int pass = 0; pass < 2; ++pass) {
         int64_t *a = pass == 0 ? partial : tile_total;
@@ -105,6 +105,8 @@ __device__ __forceinline__ void frame_scan_body(int64_t *partial, int n_blocks, 
             if (host_out) {                 // pinned host memory: the frame's 16-byte readback without a copy kernel
                 host_out[0] = total;
                 host_out[1] = overflow_in ? (int64_t)*overflow_in : 0;
+                // the camera-coherent route's verdict on the rays (camera_rays_check): policy only, like the overflow count
+                host_out[3] = ray_flag_in ? (int64_t)*ray_flag_in : 0;
             }
         }
     }
@@ -117,11 +119,12 @@ __device__ __forceinline__ void frame_scan_body(int64_t *partial, int n_blocks, 
 // for the 12 500 workgroups of an 800x800 frame.)
 __global__ __launch_bounds__(kFoThreads) void frame_scan_kernel(int64_t *partial, int n_blocks, int64_t *tile_total, int n_tiles,
                                                                 int64_t *grand_total, const int32_t *overflow_in,
-                                                                int64_t *host_out, int32_t *zero_word)
+                                                                int64_t *host_out, int32_t *zero_word,
+                                                                const int32_t *ray_flag_in)
 {
     __shared__ int64_t s_wave[kFoThreads / 64];
     if (zero_word && threadIdx.x == 0) *zero_word = 0;
-    frame_scan_body(partial, n_blocks, tile_total, n_tiles, grand_total, overflow_in, host_out, s_wave);
+    frame_scan_body(partial, n_blocks, tile_total, n_tiles, grand_total, overflow_in, host_out, s_wave, ray_flag_in);
 }
 
 __global__ __launch_bounds__(kFoThreads) void frame_ray_offsets_kernel(const int32_t *__restrict__ hit_count, int64_t n_rays,
@@ -152,7 +155,7 @@ extern "C" int64_t qf_frame_offsets_temp_bytes(int64_t n_rays)
 
 extern "C" int qf_frame_offsets(const int32_t *hit_count, int64_t n_rays, int32_t max_hits, int32_t width, int32_t height,
                                 int64_t *ray_offset, int64_t *tile_base, void *temp, int64_t temp_bytes,
-                                const int32_t *overflow_in, int64_t *host_out, void *stream)
+                                const int32_t *overflow_in, const int32_t *ray_flag_in, int64_t *host_out, void *stream)
 {
     if (n_rays < 0 || n_rays >= 0x7fffffff || max_hits < 1 || width < 0 || height < 0) return QF_ERR_INVALID_ARGUMENT;
     if (!ray_offset || !temp || (n_rays > 0 && !hit_count)) return QF_ERR_INVALID_ARGUMENT;
@@ -171,7 +174,7 @@ extern "C" int qf_frame_offsets(const int32_t *hit_count, int64_t n_rays, int32_
         QF_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(frame_scan_kernel, dim3(1), dim3(kFoThreads), 0, st, partial, n_blocks, tile_base, n_tiles,
-                       ray_offset + n_rays, overflow_in, host_out, (int32_t *)nullptr);
+                       ray_offset + n_rays, overflow_in, host_out, (int32_t *)nullptr, ray_flag_in);
     QF_LAUNCH_CHECK();
     if (n_blocks > 0) {
         hipLaunchKernelGGL(frame_ray_offsets_kernel, dim3((unsigned)n_blocks), dim3(kFoThreads), 0, st, hit_count, n_rays,
@@ -184,8 +187,8 @@ extern "C" int qf_frame_offsets(const int32_t *hit_count, int64_t n_rays, int32_
 // The render-only frame's version: only the tile bases and the total (what qf_pack_tiles and qf_composite_tiles take),
 // no per-ray offsets -- the tile part of step 1 and a scan over the tile totals alone.
 extern "C" int qf_tile_offsets(const int32_t *hit_count, int32_t max_hits, int32_t width, int32_t height,
-                               int64_t *tile_base, int64_t *total, const int32_t *overflow_in, int64_t *host_out,
-                               int32_t *zero_word, void *stream)
+                               int64_t *tile_base, int64_t *total, const int32_t *overflow_in, const int32_t *ray_flag_in,
+                               int64_t *host_out, int32_t *zero_word, void *stream)
 {
     if (max_hits < 1 || width < 1 || height < 1 || !hit_count || !tile_base || !total) return QF_ERR_INVALID_ARGUMENT;
     const int64_t n_rays = (int64_t)width * height;
@@ -197,7 +200,7 @@ extern "C" int qf_tile_offsets(const int32_t *hit_count, int32_t max_hits, int32
     hipLaunchKernelGGL(frame_partials_kernel, dim3((unsigned)tile_blocks), dim3(kFoThreads), 0, st, hit_count, n_rays, max_hits,
                        0, (int)width, (int)height, tiles_x, n_tiles, (int64_t *)nullptr, tile_base);
     hipLaunchKernelGGL(frame_scan_kernel, dim3(1), dim3(kFoThreads), 0, st, (int64_t *)nullptr, 0, tile_base, n_tiles, total,
-                       overflow_in, host_out, zero_word);
+                       overflow_in, host_out, zero_word, ray_flag_in);
     QF_LAUNCH_CHECK();
     return QF_OK;
 }
@@ -214,5 +217,5 @@ extern "C" int qf_sample_offsets(const int32_t *hit_count, int64_t n_rays, int32
 {
     if (temp_bytes < qf_sample_offsets_temp_bytes(n_rays)) return QF_ERR_INVALID_ARGUMENT;
     return qf_frame_offsets(hit_count, n_rays, max_hits, 0, 0, ray_offset, nullptr, temp, temp_bytes, nullptr, nullptr,
-                            stream);
+                            nullptr, stream);
 }

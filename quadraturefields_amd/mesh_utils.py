@@ -67,6 +67,9 @@ def trimesh_ray_offset(vertices) -> float:
     return float(np.clip(1e-4 * (100.0 / diag), 1e-8, np.inf))
 
 
+_resolve_device = _C.resolve_device
+
+
 class _PermuteRowsFn(torch.autograd.Function):
     """``x[perm]`` for a PERMUTATION ``perm``: the backward is a plain scatter (``grad_in[perm] = grad_out``).  torch's
     own indexing backward has to assume repeated indices and sorts them first (a segmented sort + merge: 20 launches,
@@ -119,7 +122,7 @@ class RayIntersector:
             raise ValueError(f"max_hits must be in 1..{_C.QF_BVH_MAX_HITS}")
         self.mesh = mesh
         self.max_hits = int(max_hits)
-        self.device = torch.device(device)
+        self.device = _resolve_device(device)
         # "trimesh": the separation follows the mesh -- trimesh derives it from the CURRENT mesh's extent, so it is
         # recomputed whenever the vertices are updated (update_intersector)
         self._min_separation_auto = isinstance(min_separation, str)
@@ -133,6 +136,8 @@ class RayIntersector:
         self.last_order = None           # coherent processing order of the most recent image-shaped sample_device()
         self._raster_backoff = 0         # frames left to skip the camera-coherent intersector after an overflow
         self.repaired_frames = 0         # frames on which some pixels overflowed K and were repaired through the BVH
+        self.camera_mismatch_frames = 0  # frames whose rays were not their camera's pixel grid (see camera_mismatch)
+        self._warned_mismatch = False
         self._raster_streak = 0          # consecutive camera-coherent attempts that overflowed (see want_raster)
         self._raster_trying = False
         self.scratch_slot = 0            # see _frame_scratch
@@ -263,6 +268,22 @@ class RayIntersector:
         self._raster_trying = True
         return True
 
+    def camera_mismatch(self) -> None:
+        """A frame's rays were NOT the pixel grid of the camera that came with them (the pass's device-side check,
+        ``qf_raster_intersect`` ray_flag: origin, direction within 0.02 px of the own pixel, unit length).  That frame was
+        answered exactly by the BVH inside its repair launch; the next frames go straight to the BVH traversal (same
+        back-off as an overflowing scene: 1 frame, doubling while it keeps happening), and the caller is told once."""
+        self.camera_mismatch_frames += 1
+        if not self._warned_mismatch:
+            import warnings
+            self._warned_mismatch = True
+            warnings.warn("RayIntersector: the rays passed with camera= are not that camera's pixel grid (origin, direction "
+                          "within 0.02 px of the own pixel centre, unit length -- e.g. jittered directions, a stale "
+                          "make_camera, another up_sample or ray order); the frame was intersected exactly through the BVH "
+                          "instead of the camera-coherent pass (about 5x slower).  Pass camera=None for such rays.",
+                          stacklevel=3)
+        self.raster_overflowed()
+
     def raster_overflowed(self) -> None:
         self._raster_trying = False
         self._raster_streak += 1
@@ -305,6 +326,7 @@ class RayIntersector:
         # counts | overflow counter | origin flag, zeroed by one fill (qf_raster_intersect's layout convention)
         counts = torch.empty((n + 2,), dtype=torch.int32, device=self.device)
         hit_count, overflow = counts[:n], counts[n:n + 1]
+        self._raster_words = counts[n:]                       # (overflow counter, ray flag): ``hits`` reads both at once
         _C.check(_C.lib().qf_raster_intersect(self._handle, ctypes.byref(camera), _C.ptr(o), _C.ptr(d), n, k,
                                               _C.ptr(hit_tri), _C.ptr(hit_t), _C.ptr(hit_count), _C.ptr(overflow),
                                               1 if sort_lists else 0, 0, _C.ptr(counts[n + 1:]), _C.stream()),
@@ -325,9 +347,13 @@ class RayIntersector:
             image_width = camera.width
         if self.want_raster(camera):
             hit_tri, hit_t, hit_count, overflow = self._hits_raster(o, d, k, camera)
-            if int(overflow.item()) == 0:
+            ovf, bad_rays = self._raster_words.tolist()
+            if ovf == 0 and bad_rays == 0:
                 return hit_tri, hit_t, hit_count, o, d
-            self.raster_overflowed()            # some ray has more than K candidates: exact K-nearest via the BVH
+            if bad_rays:                        # not this camera's pixel grid (the pass wrote nothing): the BVH answers
+                self.camera_mismatch()
+            else:
+                self.raster_overflowed()        # some ray has more than K candidates: exact K-nearest via the BVH
         hit_tri, hit_t, hit_count = self._hits_bvh(o, d, k, image_width)
         return hit_tri, hit_t, hit_count, o, d
 
@@ -376,7 +402,9 @@ class RayIntersector:
         # offsets scan copies it to the frame's pinned block together with the sample total (one readback)
         # (... and the origin flag behind that: qf_raster_intersect's layout convention)
         counts = torch.empty((n + 2,), dtype=torch.int32, device=self.device)
-        hit_count, overflow, origin_flag = counts[:n], counts[n:n + 1], counts[n + 1:]
+        # overflow: 2 words -- the overflow counter and the pass's ray flag (raised: the rays are not this camera's pixel
+        # grid; the passes then write nothing and the repair launch below traverses every ray)
+        hit_count, overflow, origin_flag = counts[:n], counts[n:], counts[n + 1:]
         wide = max(int(self.raster_wide), 0)
         # a camera that sees part of the scene (parallel.band_camera sets .cull): cull the triangles in chunks first
         cull = 1 if getattr(camera, "cull", False) else 0
@@ -420,13 +448,13 @@ class RayIntersector:
         upfront = self.min_separation > 0 and self._rule_upfront > 0
         if upfront:
             self._rule_upfront -= 1
-        self._repair(o, d, k, int(camera.width), hit_tri, hit_t, hit_count, with_mask=upfront)
+        self._repair(o, d, k, int(camera.width), hit_tri, hit_t, hit_count, with_mask=upfront, all_flag=origin_flag)
         return hit_tri, hit_t, hit_count, overflow
 
     #: frames that decide the re-origin rule up front after one frame's optimistic pack found a close pair
     RULE_UPFRONT_FRAMES = 64
 
-    def _repair(self, o, d, k, width, hit_tri, hit_t, hit_count, with_mask):
+    def _repair(self, o, d, k, width, hit_tri, hit_t, hit_count, with_mask, all_flag=None):
         n = o.shape[0]
         mask = raw = None
         if with_mask:
@@ -434,7 +462,7 @@ class RayIntersector:
             raw = torch.empty((n,), dtype=torch.int32, device=self.device)
         _C.check(_C.lib().qf_bvh_repair_overflow(self._handle, _C.ptr(o), _C.ptr(d), n, k, int(width),
                                                  _C.ptr(hit_tri), _C.ptr(hit_t), _C.ptr(hit_count), _C.ptr(mask), _C.ptr(raw),
-                                                 _C.stream()), "qf_bvh_repair_overflow")
+                                                 _C.ptr(all_flag), _C.stream()), "qf_bvh_repair_overflow")
         hit_count._qf_keep = (mask, raw) if mask is not None else None
 
     def pack_hits(self, o, d, k, hit_tri, hit_t, hit_count, overflow, width, lean=False, layout=True,
@@ -472,14 +500,18 @@ class RayIntersector:
         if image:
             height = n // width
             tile_base = torch.empty((((width + 7) // 8) * ((height + 7) // 8),), dtype=torch.int64, device=dev)
+        # the camera-coherent pass's ray flag rides behind its overflow counter (``_hits_raster_frame``): to host[3]
+        ray_flag = overflow[1:] if (overflow is not None and overflow.numel() >= 2) else None
         if bool(lean) and image:              # render-only frame: tile bases + total, no per-ray offsets
             _C.check(_C.lib().qf_tile_offsets(_C.ptr(hit_count), k, int(width), n // int(width), _C.ptr(tile_base),
-                                              _C.ptr(buf[n:]), _C.ptr(overflow), ctypes.c_void_p(host.data_ptr()),
-                                              _C.ptr(dropped), _C.stream()), "qf_tile_offsets")     # (zeroes ``dropped``)
+                                              _C.ptr(buf[n:]), _C.ptr(overflow), _C.ptr(ray_flag),
+                                              ctypes.c_void_p(host.data_ptr()), _C.ptr(dropped), _C.stream()),
+                     "qf_tile_offsets")       # (zeroes ``dropped``)
         else:
             _C.check(_C.lib().qf_frame_offsets(_C.ptr(hit_count), n, k, int(width) if image else 0, n // width if image else 0,
                                                _C.ptr(buf), _C.ptr(tile_base), _C.ptr(temp), temp.numel(), _C.ptr(overflow),
-                                               ctypes.c_void_p(host.data_ptr()), _C.stream()), "qf_frame_offsets")
+                                               _C.ptr(ray_flag), ctypes.c_void_p(host.data_ptr()), _C.stream()),
+                     "qf_frame_offsets")
         ev.record()                           # (total, overflow) are in pinned memory once this event has passed
         lean = bool(lean) and image
         want_layout = layout
@@ -553,6 +585,8 @@ class RayIntersector:
         o, d, k, width, lean, host, (ev, ev_flag), arrays, order, layout, _lists, frame = pending
         ev.synchronize()
         total, ovf = int(host[0]), int(host[1])
+        if int(host[3]):
+            self.camera_mismatch()
         self._rule_pending = None
         if ev_flag is not None and not lean[0]:
             if defer_rule_check:
@@ -598,6 +632,8 @@ class RayIntersector:
         if pend is not None:
             ev, host, n_rays, k = pend
             ev.synchronize()
+            if int(host[3]):
+                self.camera_mismatch()
             self._overflow_policy(int(host[1]), n_rays, k)
         while self._fused_pending:
             self._settle_fused_policy(0)
@@ -611,6 +647,8 @@ class RayIntersector:
         while len(self._fused_pending) > keep:
             ev, host, n_rays, k = self._fused_pending.pop(0)
             ev.synchronize()
+            if int(host[3]):
+                self.camera_mismatch()
             self._overflow_policy(int(host[1]), n_rays, k)
 
     def pack_hits_device(self, pending):
@@ -764,7 +802,7 @@ class RayIntersector:
         dev = self.device
         cap = n * k
         hit_tri, hit_t, _ = self._alloc_hits(n, k)
-        counts = torch.empty((n + 2,), dtype=torch.int32, device=dev)         # counts | overflow | origin flag
+        counts = torch.empty((n + 2,), dtype=torch.int32, device=dev)         # counts | overflow | ray flag
         final_count = torch.empty((n,), dtype=torch.int32, device=dev)
         tile_base = torch.empty((((w + 7) // 8) * ((h + 7) // 8),), dtype=torch.int64, device=dev)
         xyz_c = torch.empty((cap, 3), dtype=torch.float32, device=dev)
@@ -903,7 +941,7 @@ class MeshFinetune:
 
     def __init__(self, vertices, faces, scaling, device="cuda:0") -> None:
         self.vertices = np.array(vertices).astype(np.float32)
-        self.device = torch.device(device)
+        self.device = _resolve_device(device)
         self.faces = torch.from_numpy(np.asarray(faces)).to(self.device).long()
         # one 16-byte row per triangle (sum d w | sum w): qf_mesh_update_d's four atomics of a sample are one request
         self._cache = torch.zeros((self.faces.shape[0], 4), device=self.device)
@@ -957,12 +995,12 @@ class MeshIntersection:
         self.num_repeat = num_repeat
         self.num_intersections = num_intersections
         self.render_step_size = render_step_size
-        self.device = torch.device(device)
+        self.device = _resolve_device(device)
         self.mesh.vertices *= scale
         self.vertices = torch.from_numpy(self.mesh.vertices.astype(np.float32)).to(self.device)
         # min_hit_separation: the re-origin distance of the reference's trimesh intersector (default), a distance in
         # world units, or 0 / None to count every hit (``RayIntersector``)
-        self.rayintersector = RayIntersector(self.mesh, max_hits=self.num_intersections, device=device,
+        self.rayintersector = RayIntersector(self.mesh, max_hits=self.num_intersections, device=self.device,
                                              min_separation=min_hit_separation)
 
     def find_deltas(self, boundary, depth):

@@ -153,7 +153,7 @@ class FrameRenderer:
                                                      bg_color=self.bg_color, packed=packed)
         return rgb, alpha, depth, frame
 
-    def _render_async_one_call(self, origins, viewdirs, camera, k, render_bkgd, packed):
+    def _render_async_one_call(self, origins, viewdirs, camera, k, render_bkgd, packed, _switched=False):
         """``render_async`` when the whole frame is the library's fixed sequence (``qf_frame_render``: intersection,
         repair, tile offsets, tile pack, the field -- NGP or spherical-Gaussian head --, tile compositor): the buffers are allocated here, the launches are
         enqueued by ONE bound call instead of six -- the host cost of a frame drops from ~0.28 ms to what the
@@ -161,9 +161,10 @@ class FrameRenderer:
         arguments, same pixels."""
         ri = self.mesh_intersect.rayintersector
         rf = self.radiance_field
-        if torch._C._cuda_getDevice() != ri.device.index:       # launch on the intersector's device
+        # launch on the intersector's device (its index is resolved at construction, _C.resolve_device; one switch at most)
+        if not _switched and torch._C._cuda_getDevice() != ri.device.index:
             with torch.cuda.device(ri.device):
-                return self._render_async_one_call(origins, viewdirs, camera, k, render_bkgd, packed)
+                return self._render_async_one_call(origins, viewdirs, camera, k, render_bkgd, packed, _switched=True)
         prepared = ri.fused_frame_job(origins, viewdirs, k, camera)
         if prepared is None:                  # the intersector's policy moved while settling an earlier frame
             return self.render_async(origins, viewdirs, camera, 0.0, render_bkgd, packed)

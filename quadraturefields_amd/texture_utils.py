@@ -34,7 +34,7 @@ class FeatureCompression:
         self.texture_size = texture_size
         self.compression_type = compression_type
         self.lambda_thres = lambda_thres
-        self.device = torch.device(device)
+        self.device = _C.resolve_device(device)
         if not (1 <= num_lobes <= _C.QF_MAX_LOBES):
             raise ValueError(f"num_lobes must be in 1..{_C.QF_MAX_LOBES}")
         if initialize:

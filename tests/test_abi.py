@@ -41,7 +41,7 @@ def test_host_only_entry_points(lib):
     """Status strings and the grid level table are host computations: callable without a GPU."""
     from quadraturefields_amd import _C
     from oracle import fields as ofields
-    assert lib.qf_abi_version() == _C.ABI_VERSION == 4
+    assert lib.qf_abi_version() == _C.ABI_VERSION == 5
     assert lib.qf_status_string(0) == b"ok"
     assert b"invalid" in lib.qf_status_string(-1)
     for log2_T, pls in [(19, ofields.ngp_per_level_scale(4096, 16, 16)), (21, ofields.ngp_per_level_scale(4096, 16, 16)),

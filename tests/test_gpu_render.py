@@ -593,3 +593,49 @@ def test_frame_job_is_validated(device):
     job, frame = fresh()
     _C.check(_C.lib().qf_frame_render(ri._handle, ctypes.byref(job), _C.stream()), "qf_frame_render")
     assert int(frame.total_dev.item()) > 100
+
+
+def test_one_call_frame_with_rays_that_are_not_the_cameras_goes_through_the_bvh(device):
+    """qf_frame_render with a camera that does not describe the rays (jittered directions; the wrong focal length;
+    ``device="cuda"`` without an index): the pass's device-side ray check routes the WHOLE frame through the
+    BVH inside the same bound call, and the pixels are those of the camera-less BVH render, bit for bit -- no host round
+    trip, no silently dropped hits, no RecursionError."""
+    import warnings
+    from quadraturefields_amd import synthetic
+    from quadraturefields_amd.mesh_utils import MeshIntersection, make_camera
+    from quadraturefields_amd.render import FrameRenderer
+    mesh, _, field = _scene(device)
+    mi = MeshIntersection(mesh, simplify_mesh=False, scale=1.0, num_intersections=25, device="cuda")     # index-less
+    assert mi.device.index == torch.cuda.current_device() and mi.rayintersector.device.index is not None
+    fr = FrameRenderer(mi, field)
+    ri = mi.rayintersector
+    w, h = 136, 96
+    focal = synthetic.lego_focal(800) * w / 800.0
+    c2w = synthetic.orbit_cameras(2, seed=5)[1]
+    o, d = synthetic.camera_rays(c2w, focal, w, h, device=device)
+    cam = make_camera(c2w, focal, w, h)
+    assert ri.fused_frame_ready(cam, 25)
+    good = fr.render_async(o, d, cam)                       # consistent rays: the one-call frame on the fast path
+    ref = fr.render(o, d, image_width=w)
+    assert torch.equal(good[0], ref[0]) and torch.equal(good[1], ref[1]) and torch.equal(good[2], ref[2])
+    ri._settle_fused_policy(0)
+    assert ri.camera_mismatch_frames == 0
+    g = torch.Generator().manual_seed(1)
+    noise = (torch.rand(w * h, 3, generator=g).to(device) - 0.5) * (1.0 / focal)          # ~ +-0.5 px
+    dj = d + noise
+    dj = (dj / dj.norm(dim=1, keepdim=True)).contiguous()
+    for o2, d2, cam2 in ((o, dj, cam), (o, d, make_camera(c2w, focal * 0.9, w, h))):
+        ri._raster_backoff = 0
+        want = fr.render(o2, d2, image_width=w)             # BVH traversal
+        ri._raster_backoff = 0
+        assert ri.fused_frame_ready(cam2, 25)
+        before = ri.camera_mismatch_frames
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            got = fr.render_async(o2, d2, cam2)
+            n_got = ri.frame_samples()
+            ri._settle_fused_policy(0)
+        assert ri.camera_mismatch_frames == before + 1
+        assert n_got == want[3] > 1000
+        for a, b in zip(got[:3], want[:3]):
+            assert torch.equal(a, b)
