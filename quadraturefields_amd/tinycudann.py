@@ -187,6 +187,32 @@ def sh4(d: torch.Tensor) -> torch.Tensor:
         0.59004358992664352 * x * (3.0 * y2 - x2)], dim=-1)
 
 
+def _grid_rows_for(log2_t: int, cfg: "_GridConfig") -> int:
+    return int(_C.make_grid_desc(cfg.n_levels, log2_t, cfg.base_resolution, cfg.per_level_scale).offset[cfg.n_levels])
+
+
+def _explain_params_size(owner: str, got: int, n_network: int, grid: "_GridConfig") -> str:
+    """The message a wrong-sized ``params`` gets: what the flat vector is made of here, and which hash-map size the
+    checkpoint's length would fit (the usual cause: a checkpoint trained with another ``log2_hashmap_size``)."""
+    want = n_network + (grid.n_params if grid is not None else 0)
+    parts = [f"{owner}: checkpoint `params` has {got} entries, this module expects {want}"]
+    if grid is not None:
+        parts.append(f"= [{n_network} network weights | {grid.n_features} x {grid.n_rows} grid rows] "
+                     f"(log2_hashmap_size={grid.log2_hashmap_size}, n_levels={grid.n_levels}, "
+                     f"base_resolution={grid.base_resolution}, per_level_scale={grid.per_level_scale:.6g}; "
+                     "tcnn's flat order, SURVEY.md A.1-A.2, restated from memory)")
+        fits = [t for t in range(10, 25) if n_network + grid.n_features * _grid_rows_for(t, grid) == got]
+        if fits:
+            parts.append(f"-- the checkpoint's length fits log2_hashmap_size={fits[0]} with the same levels")
+    else:
+        parts.append(f"= {n_network} network weights (row-major [out,in] per layer, inputs padded to 16)")
+    return " ".join(parts)
+
+
+def _rms(t: torch.Tensor) -> float:
+    return float(t.detach().double().pow(2).mean().sqrt()) if t.numel() else 0.0
+
+
 class Encoding(nn.Module):
     """tcnn.Encoding: hash grid (field.py:157-171) or the SH-degree-4 composite (ngp.py:325-338)."""
 
@@ -207,6 +233,14 @@ class Encoding(nn.Module):
             self.n_output_dims = self.grid.n_output_dims
             # tcnn default: U(-1e-4, 1e-4)
             self.params = nn.Parameter((torch.rand(self.grid.n_params) * 2 - 1) * 1e-4)
+
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        v = state_dict.get(prefix + "params")
+        if v is not None and self.grid is not None and v.numel() != self.params.numel():
+            error_msgs.append(_explain_params_size(f"{prefix}Encoding", v.numel(), 0, self.grid))
+            state_dict = {k: t for k, t in state_dict.items() if k != prefix + "params"}       # (torch would only repeat it)
+            strict = False
+        super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if self.grid is None:
@@ -232,6 +266,14 @@ class Network(nn.Module):
         self.network_config = network_config
         self.dims = _mlp_dims(n_input_dims, n_output_dims, network_config)
         self.params = nn.Parameter(_xavier_flat(self.dims))
+
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        v = state_dict.get(prefix + "params")
+        if v is not None and v.numel() != self.params.numel():
+            error_msgs.append(_explain_params_size(f"{prefix}Network {self.dims}", v.numel(), self.params.numel(), None))
+            state_dict = {k: t for k, t in state_dict.items() if k != prefix + "params"}
+            strict = False
+        super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs)
 
     def forward(self, x):
         """Library-GEMM evaluation (training route); inference runs inside the fused field kernel.  tcnn pads the
@@ -260,6 +302,51 @@ class NetworkWithInputEncoding(nn.Module):
         net = _xavier_flat(self.dims)
         grid = (torch.rand(self.grid.n_params) * 2 - 1) * 1e-4
         self.params = nn.Parameter(torch.cat([net, grid]))
+
+    #: ``layout_check`` verdicts
+    LAYOUT_OK, LAYOUT_SUSPECT = "network|grid", "grid|network?"
+
+    def layout_check(self, flat: torch.Tensor):
+        """Does a flat ``params`` vector look like ``[network | grid]`` -- the order this module assumes -- or like the
+        transposed ``[grid | network]``?  The order is the one from-memory fact about tcnn whose failure
+        would be silent and total on a real checkpoint: the sizes match either way and every output is garbage.  The two
+        halves are told apart by magnitude: tcnn initialises the tables U(-1e-4, 1e-4) and after training the finest
+        levels' rows are still orders of magnitude smaller in RMS than the 3 072 dense Xavier-scale MLP weights.  Under
+        the assumed order rms(first 3 072) / rms(rest) is large; under the transposed one rms(LAST 3 072) / rms(the rest
+        before it) is.  Returns (verdict, assumed_ratio, transposed_ratio)."""
+        n = self.n_network_params
+        flat = flat.detach().reshape(-1)
+        if flat.numel() != self.params.numel() or flat.numel() <= 2 * n:
+            return self.LAYOUT_OK, float("nan"), float("nan")
+        eps = 1e-30
+        assumed = _rms(flat[:n]) / (_rms(flat[n:]) + eps)
+        transposed = _rms(flat[-n:]) / (_rms(flat[:-n]) + eps)
+        suspect = transposed > 1.0 and transposed > 4.0 * assumed
+        return (self.LAYOUT_SUSPECT if suspect else self.LAYOUT_OK), assumed, transposed
+
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        """Reference checkpoints (ngp.py:709-727; train_finetune.py:407-409 ``load_state_dict``): a wrong-sized ``params``
+        gets an error that names the expected ``[3072 | 2 x rows]`` split; a right-sized one is checked for the transposed
+        order and WARNED about (not refused: the heuristic cannot prove it)."""
+        v = state_dict.get(prefix + "params")
+        if v is not None and v.numel() != self.params.numel():
+            error_msgs.append(_explain_params_size(f"{prefix}NetworkWithInputEncoding", v.numel(), self.n_network_params,
+                                                   self.grid))
+            state_dict = {k: t for k, t in state_dict.items() if k != prefix + "params"}
+            strict = False
+        elif v is not None:
+            verdict, assumed, transposed = self.layout_check(v)
+            if verdict != self.LAYOUT_OK:
+                import warnings
+                n = self.n_network_params
+                warnings.warn(
+                    f"{prefix}params: this checkpoint looks like [grid | network], not the [network ({n}) | grid "
+                    f"({self.grid.n_features} x {self.grid.n_rows} rows)] order this module assumes for tcnn's flat "
+                    f"parameter vector (SURVEY.md A.2, restated from memory): rms(first {n}) / rms(rest) = {assumed:.3g} "
+                    f"but rms(last {n}) / rms(before) = {transposed:.3g} -- the dense MLP weights seem to sit at the END.  "
+                    "Loaded as is; if the render is garbage, move the last "
+                    f"{n} entries to the front (torch.cat([p[-{n}:], p[:-{n}]])).", stacklevel=2)
+        super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs)
 
     # views into the flat parameter vector (no copies)
     def network_params(self) -> torch.Tensor:
