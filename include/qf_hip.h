@@ -679,9 +679,13 @@ int qf_split_layout(const int64_t *index_ray, int64_t n, int32_t width, int32_t 
  * utils.py:596-600): cache_d[index_tri[i]] += d[i] * w[i], cache_w[index_tri[i]] += w[i] in one launch (fp32
  * atomics, as torch's index_add_).  cache [n_faces, 4]: cache_d in columns 0-2 and cache_w in column 3 of one
  * 16-byte row per triangle, so that a sample's four atomics are one memory request.  d == NULL: the displacement
- * is identically zero, only the weight column moves.                                                */
+ * is identically zero, only the weight column moves.
+ * A triangle id outside [0, n_faces) is skipped (the reference's scatter_add raises on it); skipped (or NULL): a device
+ * int32 that is INCREMENTED once per such sample -- the caller zeroes it and raises when it reads a non-zero count.
+ * cache must be ordinary (coarse-grained) device memory: the kernel uses the hardware's fp32 add atomics
+ * (unsafeAtomicAdd), which are not coherent on fine-grained / host-mapped allocations.                       */
 int qf_mesh_update_d(const float *d /* [n,3] or NULL */, const float *w /* [n] */, const int64_t *index_tri, int64_t n,
-                     int64_t n_faces, float *cache /* [n_faces,4] */, void *stream);
+                     int64_t n_faces, float *cache /* [n_faces,4] */, int32_t *skipped /* or NULL */, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Baked spherical-Gaussian textures.

@@ -144,7 +144,7 @@ _SIGNATURES = {
     "qf_resort_by_depth": (c_int, [_P, _P, c_int64, _P, _P]),
     "qf_resort_samples": (c_int, [_P, _P, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "qf_split_layout": (c_int, [_P, c_int64, c_int32, c_int32, _P, _P, _P, _P, _P, _P, _P]),
-    "qf_mesh_update_d": (c_int, [_P, _P, _P, c_int64, c_int64, _P, _P]),
+    "qf_mesh_update_d": (c_int, [_P, _P, _P, c_int64, c_int64, _P, _P, _P]),
     "qf_texel_indices": (c_int, [_P, _P, _P, _P, _P, c_int64, c_int32, _P, _P]),
     "qf_texel_records_pack": (c_int, [_P, _P, _P, c_int64, _P, _P]),
     "qf_texel_indices_packed": (c_int, [_P, _P, _P, c_int64, c_int32, _P, _P]),

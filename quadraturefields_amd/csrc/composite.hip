@@ -866,8 +866,12 @@ __global__ __launch_bounds__(64) void split_order_kernel(const int32_t *hit_coun
 // q, so the four atomics of a sample are one instruction on one 16-byte piece of one line -- the memory pipeline carries
 // them as ONE request (the trick of grid_backward_table_kernel).  The atomic rate is per request (~1.9e10/s chip-wide),
 // so 10^6 samples cost ~50 us instead of the ~200 us of four separate atomics per lane.
+// A triangle id outside [0, n_faces) cannot be accumulated (torch's index_add_ / torch_scatter raise on it): the sample
+// is skipped and, when the caller passes a counter, COUNTED -- MeshFinetune raises on a non-zero count the next time
+// it synchronises anyway (update_faces), so corrupt ids (a stale sample set after a mesh swap) do not vanish silently.
 __global__ void mesh_update_d_kernel(const float *__restrict__ d, const float *__restrict__ w,
-                                     const int64_t *__restrict__ index_tri, int64_t n, int64_t n_faces, float *cache)
+                                     const int64_t *__restrict__ index_tri, int64_t n, int64_t n_faces, float *cache,
+                                     int32_t *__restrict__ skipped)
 {
 #pragma clang fp contract(off)
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -875,6 +879,7 @@ __global__ void mesh_update_d_kernel(const float *__restrict__ d, const float *_
         for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
             const int64_t t = index_tri[i];
             if (t >= 0 && t < n_faces) unsafeAtomicAdd(cache + t * 4 + 3, w[i]);
+            else if (skipped) atomicAdd(skipped, 1);
         }
         return;
     }
@@ -882,7 +887,10 @@ __global__ void mesh_update_d_kernel(const float *__restrict__ d, const float *_
         const int64_t i = e >> 2;
         const int c = (int)(e & 3);
         const int64_t t = index_tri[i];
-        if (t < 0 || t >= n_faces) continue;
+        if (t < 0 || t >= n_faces) {
+            if (skipped && c == 0) atomicAdd(skipped, 1);
+            continue;
+        }
         const float wi = w[i];
         unsafeAtomicAdd(cache + t * 4 + c, c < 3 ? d[i * 3 + c] * wi : wi);
     }
@@ -916,13 +924,13 @@ extern "C" int qf_split_layout(const int64_t *index_ray, int64_t n, int32_t widt
 }
 
 extern "C" int qf_mesh_update_d(const float *d, const float *w, const int64_t *index_tri, int64_t n, int64_t n_faces,
-                                float *cache, void *stream)
+                                float *cache, int32_t *skipped, void *stream)
 {
     if (n < 0 || n_faces < 0) return QF_ERR_INVALID_ARGUMENT;
     if (n == 0) return QF_OK;
     if (!w || !index_tri || !cache) return QF_ERR_INVALID_ARGUMENT;
     hipLaunchKernelGGL(mesh_update_d_kernel, dim3(qf_grid_1d(d ? 4 * n : n, 256)), dim3(256), 0, qf_stream(stream), d, w,
-                       index_tri, n, n_faces, cache);
+                       index_tri, n, n_faces, cache, skipped);
     QF_LAUNCH_CHECK();
     return QF_OK;
 }

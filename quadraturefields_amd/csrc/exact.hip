@@ -2668,10 +2668,14 @@ extern "C" int qf_raster_intersect_slabs(qf_bvh *bvh, const qf_camera *cam, cons
     const int stop_at = sel_cap + 1;
     // the counts at the start of each later pass, in one record with the ray's direction: rewritten between the passes
     if (bvh->slab_snapshot_rays < n_rays) {
+        // hipFree synchronises the device: grow geometrically, so that a renderer whose ray count creeps up (row bands
+        // that move with the cost profile) frees O(log n) times in its life and a steady-state frame never does
+        const int64_t grown = bvh->slab_snapshot_rays * 2 > n_rays ? bvh->slab_snapshot_rays * 2 : n_rays;
         if (bvh->d_slab_snapshot) (void)hipFree(bvh->d_slab_snapshot);
         bvh->d_slab_snapshot = nullptr;
-        QF_HIP_TRY(hipMalloc((void **)&bvh->d_slab_snapshot, (size_t)n_rays * sizeof(float4)));
-        bvh->slab_snapshot_rays = n_rays;
+        bvh->slab_snapshot_rays = 0;
+        QF_HIP_TRY(hipMalloc((void **)&bvh->d_slab_snapshot, (size_t)grown * sizeof(float4)));
+        bvh->slab_snapshot_rays = grown;
     }
     float4 *snapshot = reinterpret_cast<float4 *>(bvh->d_slab_snapshot);
     for (int j = 0; j < n_slabs; ++j) {

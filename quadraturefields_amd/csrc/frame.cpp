@@ -12,7 +12,29 @@ extern "C" int qf_frame_render(qf_bvh *bvh, const qf_frame_job *job, void *strea
     if (!j.rays_o || !j.rays_d || !j.hit_tri || !j.hit_t || !j.hit_count || !j.final_count || !j.tile_base || !j.total ||
         !j.dropped || !j.xyz_c || !j.dirs_c || !j.depth_c)
         return QF_ERR_INVALID_ARGUMENT;
-    if (j.field && (!j.rgb_c || !j.sigma_c || !j.table || !j.base_w)) return QF_ERR_INVALID_ARGUMENT;   // before any launch
+    // The whole job is checked BEFORE the first launch: the entry points below repeat these tests, but by the
+    // time qf_field_forward or qf_composite_tiles would refuse, four kernels have run, the handle's cull parity has
+    // flipped and the pinned block has been written -- a C caller would get INVALID_ARGUMENT for a half-executed frame.
+    if (j.field) {
+        const qf_field_desc &f = *j.field;
+        if (!j.rgb_c || !j.sigma_c || !j.table || !j.base_w) return QF_ERR_INVALID_ARGUMENT;
+        // the frame composites colours: the head must produce them (qf_field_forward's own rules per head)
+        if (f.head == QF_HEAD_NGP) {
+            if (!j.head_ngp_w) return QF_ERR_INVALID_ARGUMENT;
+        } else if (f.head == QF_HEAD_SG) {
+            const qf_sg_head *s = j.head_sg;
+            if (!s || !s->w1 || !s->b1 || !s->w2 || !s->b2 || !s->wout || !s->bout) return QF_ERR_INVALID_ARGUMENT;
+            if (f.n_lobes < 1 || f.n_lobes > QF_MAX_LOBES) return QF_ERR_UNSUPPORTED;
+        } else {
+            return QF_ERR_INVALID_ARGUMENT;       // QF_HEAD_NONE / QF_HEAD_SG_FEATURES give the compositor no rgb
+        }
+        for (int k = 0; k < 3; ++k)
+            if (!(f.aabb[3 + k] > f.aabb[k])) return QF_ERR_INVALID_ARGUMENT;
+        // ... and the compositor's (qf_composite_tiles): an image to write, a known background, its colour when custom
+        if (j.bg_mode < 0 || j.bg_mode > 3) return QF_ERR_INVALID_ARGUMENT;
+        if (!j.out_packed && (!j.out_rgb || !j.out_alpha || !j.out_depth)) return QF_ERR_INVALID_ARGUMENT;
+        if (j.bg_mode == QF_BG_CUSTOM && !j.bkgd) return QF_ERR_INVALID_ARGUMENT;
+    }
     const int64_t cap = j.n_rays * (int64_t)j.max_hits;
     int32_t *overflow = j.hit_count + j.n_rays;
     // 1. camera-coherent intersection (lists in arrival order), 2. exact K nearest for the pixels that overflowed

@@ -52,6 +52,19 @@ def _on_device(fn):
     return wrapped
 
 
+def mesh_depth_complexity(vertices, faces) -> float:
+    """Mean number of surface crossings of a random line through the mesh's bounding box: 2 * area(mesh) / area(box)
+    (Cauchy-Crofton).  0 for an empty or flat mesh."""
+    v = np.asarray(vertices, dtype=np.float64).reshape(-1, 3)
+    f = np.asarray(faces).reshape(-1, 3)
+    if v.shape[0] == 0 or f.shape[0] == 0:
+        return 0.0
+    area = 0.5 * np.linalg.norm(np.cross(v[f[:, 1]] - v[f[:, 0]], v[f[:, 2]] - v[f[:, 0]]), axis=1).sum()
+    e = v.max(axis=0) - v.min(axis=0)
+    box = 2.0 * (e[0] * e[1] + e[1] * e[2] + e[0] * e[2])
+    return float(2.0 * area / box) if box > 0 else 0.0
+
+
 def trimesh_ray_offset(vertices) -> float:
     """The distance trimesh 3.23.5 re-originates a ray past each hit in ``RayMeshIntersector.intersects_id``
     (``ray_pyembree.py``: ``clip(_ray_offset_factor * self._scale, _ray_offset_floor, inf)`` with
@@ -145,6 +158,15 @@ class RayIntersector:
         self._rule_pending = None        # the frame whose optimistic pack has not been checked yet (rule_violated)
         self.rule_redone_frames = 0      # frames packed twice because the optimistic check failed
         self.raster_wide = 0             # > 0: the camera-coherent pass keeps this many candidates per ray (dense scenes)
+        # The overflow policy's STARTING point, from the mesh alone (the first frame of a dense-shell
+        # scene ran the plain pass into ~30 ms of overflow atomics and whole-image repair before the policy switched).
+        # Cauchy-Crofton: a random line through a convex body K crosses a surface of area S inside it 2 S / area(dK)
+        # times on average; with K = the mesh's bounding box this is the mean depth complexity of a ray that meets the
+        # box (5.5 for the 12-shell Lego stand-in, 16.7 for configs[2]'s 36 shells).  At half of K or more most object
+        # rays overflow K: start with the wide / depth-slab lists (``_seed_policy``).  Only the start: the per-frame
+        # overflow counts keep steering afterwards, and the state survives ``update_intersector`` / a replaced ``inter``.
+        self.depth_complexity = mesh_depth_complexity(mesh.vertices, mesh.faces)
+        self._policy_seeded = False
         self.raster_slabs = int(os.environ.get("QF_RASTER_SLABS", self.RASTER_SLABS))      # (env: experiments)
         self._wide_scratch = {}
         self._scratch = {}               # per-ray-count frame scratch, see _frame_scratch
@@ -381,7 +403,9 @@ class RayIntersector:
             # the tile pack's dropped-hit counter: its own fixed word (the kernel that publishes it leaves it at zero
             # for the next frame, so it must not move with n)
             dropped = torch.zeros((1,), dtype=torch.int32, device=self.device)
-            s = self._scratch[key] = [0, None, None, host, (torch.cuda.Event(), torch.cuda.Event()), dropped]
+            # s[6]: how many frames have used this block (``frame_samples`` refuses a frame whose counts a later frame
+            # has overwritten: the pinned block, ``dropped`` and the total word are shared per (stream, slot))
+            s = self._scratch[key] = [0, None, None, host, (torch.cuda.Event(), torch.cuda.Event()), dropped, 0]
         if n > s[0]:
             cap = max(n, 2 * s[0]) if s[0] else n
             nbytes = int(_C.lib().qf_frame_offsets_temp_bytes(cap))
@@ -391,7 +415,14 @@ class RayIntersector:
             s[1] = torch.zeros((cap + 3,), dtype=torch.int64, device=self.device)
             s[2] = torch.empty((nbytes,), dtype=torch.uint8, device=self.device)
             s[0] = cap
+        s[6] += 1
+        self._scratch_stamp = (s, s[6])             # the frame being set up takes this stamp (``_stamp``)
         return s[1][:n + 3], s[2], s[3], s[4], s[5]
+
+    def _stamp(self, frame):
+        """Tie ``frame`` to the scratch block it was packed through and that block's use count at the time."""
+        frame._scratch, frame._seq = self._scratch_stamp
+        return frame
 
     @_on_device
     def _hits_raster_frame(self, o, d, k, camera):
@@ -405,6 +436,7 @@ class RayIntersector:
         # overflow: 2 words -- the overflow counter and the pass's ray flag (raised: the rays are not this camera's pixel
         # grid; the passes then write nothing and the repair launch below traverses every ray)
         hit_count, overflow, origin_flag = counts[:n], counts[n:], counts[n + 1:]
+        self._seed_policy(k)
         wide = max(int(self.raster_wide), 0)
         # a camera that sees part of the scene (parallel.band_camera sets .cull): cull the triangles in chunks first
         cull = 1 if getattr(camera, "cull", False) else 0
@@ -531,6 +563,7 @@ class RayIntersector:
             frame = SimpleNamespace(depth_c=depth_c, hit_count=hit_count, max_hits=int(k), tile_base=tile_base,
                                     width=int(width), height=n // int(width), total=0, tri_c=None,
                                     total_dev=buf[n:n + 1])      # the slot count, on the device (int64)
+            self._stamp(frame)
         if lean:
             # render-only frame: the tile kernel writes the coherent copies directly; no ray-major arrays, no order,
             # no inverse map exist for it (the six sample arrays come back as None).  It also applies the re-origin
@@ -612,6 +645,19 @@ class RayIntersector:
             self.last_frame = frame
         return [None if t is None else t[:total] for t in arrays], (order[:total] if order is not None else None)
 
+    #: ``depth_complexity / K`` from which the first frame already uses the wide / depth-slab candidate lists
+    SEED_WIDE_AT = 0.5
+
+    def _seed_policy(self, k: int) -> None:
+        """Before the first camera-coherent frame: dense scenes (mean depth complexity >= half of K) start in the dense
+        mode instead of learning it from a frame's overflow count (see ``depth_complexity``)."""
+        if self._policy_seeded:
+            return
+        self._policy_seeded = True
+        wide = min(self.RASTER_WIDE_FACTOR * k, self.RASTER_WIDE_MAX)
+        if self.raster_wide == 0 and wide > k and self.depth_complexity >= self.SEED_WIDE_AT * k:
+            self.raster_wide = wide
+
     def _overflow_policy(self, ovf: int, n_rays: int, k: int) -> None:
         """``ovf`` candidates beyond K in the camera-coherent pass of a frame (those rays were already repaired on the
         device, qf_bvh_repair_overflow): steer the next frames' intersector."""
@@ -671,13 +717,21 @@ class RayIntersector:
         self.last_frame = frame
         return frame
 
-    def frame_samples(self) -> int:
-        """Quadrature points of the most recent image-shaped pack (``last_frame``): for a render-only frame the slots
-        of the coherent arrays minus the hits its re-origin rule dropped."""
-        f = self.last_frame
+    def frame_samples(self, frame=None) -> int:
+        """Quadrature points of the most recent image-shaped pack (``last_frame``), or of ``frame`` (what
+        ``render_async`` / ``sample_frame_device`` returned): for a render-only frame the slots of the coherent arrays
+        minus the hits its re-origin rule dropped.  A frame packed WITHOUT a host wait keeps its counts in words that the
+        next frame on the same stream reuses (the pinned block, the dropped-hit counter, the total): ask before that
+        frame is sampled -- afterwards this raises instead of handing out another frame's count."""
+        f = self.last_frame if frame is None else frame
         if f is None:
             return 0
         if f.samples is None:
+            sc = getattr(f, "_scratch", None)
+            if sc is not None and sc[6] != f._seq:
+                raise RuntimeError("frame_samples: this render-only frame's counts have not been read yet and a later frame "
+                                   "has since reused the words they live in (same stream and scratch slot); ask for a "
+                                   "frame's sample count before the next frame is sampled")
             total = f.total
             src = getattr(f, "total_src", None)
             if src is not None:                 # packed without a host wait: the count is read now
@@ -775,8 +829,9 @@ class RayIntersector:
     def fused_frame_ready(self, camera, max_hits: Optional[int] = None) -> bool:
         """Does ``sample_frame_device`` reduce to the fixed sequence ``qf_frame_render`` composes -- the plain
         camera-coherent pass (no wide candidate lists, no back-off to the BVH path) with the re-origin rule left to the
-        tile pack?  No side effects."""
+        tile pack?  No side effects (beyond seeding the policy from the mesh the first time anyone asks)."""
         k = self.max_hits if max_hits is None else int(max_hits)
+        self._seed_policy(k)
         return (camera is not None and self._raster_backoff <= 0 and int(self.raster_wide) <= k
                 and not (self.min_separation > 0 and self._rule_upfront > 0))
 
@@ -826,6 +881,7 @@ class RayIntersector:
                                 total=cap, tri_c=tri_c, total_dev=buf[n:n + 1], samples=None, total_src=(ev, host),
                                 dropped_src=(ev_flag, host), dropped_dev=dropped,
                                 _keep=(hit_tri, hit_t, counts, o, d, camera))
+        self._stamp(frame)
         return job, frame, (ev, host, n, k, xyz_c, dirs_c)
 
     def fused_frame_done(self, frame, token) -> None:
@@ -949,22 +1005,36 @@ class MeshFinetune:
         self.cache_w = self._cache[:, 3]
         self.cache_w[:] = 1e-8
         self.scaling = scaling
+        # samples whose triangle id was outside [0, n_faces): counted on the device by update_d, raised by check_ids()
+        self._skipped = torch.zeros((1,), dtype=torch.int32, device=self.device)
 
     @torch.no_grad()
     def update_d(self, d, w, index_tri):
         """cache_d[tri] += d * w, cache_w[tri] += w (mesh_utils.py:126-131) in one launch (``qf_mesh_update_d``).
-        ``d`` may be None: a displacement that is identically zero (``scaling == 0``) leaves cache_d as it is."""
+        ``d`` may be None: a displacement that is identically zero (``scaling == 0``) leaves cache_d as it is.
+        The reference's ``scatter_add`` raises at once on a triangle id outside the mesh; here such samples are skipped
+        and counted on the device (no host wait per split), and ``check_ids`` -- called by ``update_faces``, which
+        synchronises anyway -- raises ``IndexError``."""
         n = int(w.shape[0])
         if n == 0:
             return
         with torch.cuda.device(self.device):
             _C.check(_C.lib().qf_mesh_update_d(
                 _C.ptr(_C.f32c(d.reshape(-1, 3))) if d is not None else None, _C.ptr(_C.f32c(w.reshape(-1))),
-                _C.ptr(_C.i64c(index_tri.reshape(-1))), n, int(self.faces.shape[0]), _C.ptr(self._cache), _C.stream()),
-                "qf_mesh_update_d")
+                _C.ptr(_C.i64c(index_tri.reshape(-1))), n, int(self.faces.shape[0]), _C.ptr(self._cache),
+                _C.ptr(self._skipped), _C.stream()), "qf_mesh_update_d")
+
+    def check_ids(self) -> None:
+        """Raises if any ``update_d`` since the last check saw a triangle id outside ``[0, n_faces)`` (host wait)."""
+        bad = int(self._skipped.item())
+        if bad:
+            self._skipped.zero_()
+            raise IndexError(f"MeshFinetune.update_d: {bad} sample(s) carried a triangle id outside [0, "
+                             f"{int(self.faces.shape[0])}) and were skipped (stale samples after a mesh swap?)")
 
     @torch.no_grad()
     def update_faces(self):
+        self.check_ids()
         deformation = torch.clip(self.cache_d / self.cache_w.unsqueeze(1), -self.scaling, self.scaling)
         df_vertices = torch.repeat_interleave(deformation, dim=0, repeats=3)
         flat = self.faces.flatten()

@@ -162,6 +162,22 @@ def test_mesh_update_d_matches_index_add(device):
     assert torch.equal(mf.cache_d, before) and torch.allclose(mf.cache_w, cw + (cw - 1e-8), rtol=1e-5)
     mf.reset_d()
     assert float(mf.cache_d.abs().max()) == 0.0
+    # ids outside the mesh (the reference's scatter_add raises on them): skipped, counted, and raised by the next
+    # update_faces / check_ids -- not silently dropped
+    mf.check_ids()
+    bad = tri.clone()
+    bad[5], bad[77], bad[900] = n_f, -1, n_f + 12345
+    mf.update_d(d, wgt, bad)
+    keep = torch.ones(n, dtype=torch.bool, device=device)
+    keep[[5, 77, 900]] = False
+    cd2 = torch.zeros(n_f, 3, device=device).index_add_(0, tri[keep], (d * wgt[:, None])[keep])
+    assert torch.allclose(mf.cache_d, cd2, atol=1e-5)
+    with pytest.raises(IndexError, match="3 sample"):
+        mf.update_faces()
+    mf.check_ids()                                         # the count was consumed
+    mf.update_d(None, wgt, bad)                            # the weight-only route counts too
+    with pytest.raises(IndexError, match="3 sample"):
+        mf.check_ids()
 
 
 def test_sample_offsets_hand_written_scan(device):

@@ -469,6 +469,9 @@ def test_frame_without_host_wait_equals_the_frame_with_it(device, scaling):
         queued.append((o, d, cam, fr.render_async(o, d, cam, scaling=scaling)))
     ri = mi.rayintersector
     n_last = ri.frame_samples()
+    assert ri.frame_samples(queued[-1][3][3]) == n_last              # by frame: the newest one still owns its count words
+    with pytest.raises(RuntimeError, match="a later frame has since reused"):
+        ri.frame_samples(queued[0][3][3])                            # an older one does not: refused, not another frame's count
     for o, d, cam, (rgb_a, alpha_a, depth_a, frame) in queued:
         rgb, alpha, depth, n = fr.render(o, d, scaling=scaling, camera=cam)
         assert torch.equal(rgb, rgb_a) and torch.equal(alpha, alpha_a) and torch.equal(depth, depth_a)
@@ -588,6 +591,36 @@ def test_frame_job_is_validated(device):
     job.head_ngp_w = _C.ptr(field.mlp_head.params.detach()).value
     with pytest.raises(ValueError):
         _C.check(_C.lib().qf_frame_render(ri._handle, ctypes.byref(job), _C.stream()), "qf_frame_render")
+    # ... nor one whose field / compositor half is incomplete: no image to write, a custom background without its colour,
+    # an unknown background mode, a head that does not match the descriptor.  ALL refused before the first launch
+    # (ADVICE r3): the handle's state and the pinned block are untouched.
+    out = torch.empty((w * h, 5), device=device)
+    rgbs, sig = torch.empty((w * h * 25, 3), device=device), torch.empty((w * h * 25,), device=device)
+    bad_desc = field._field_desc(_C.HEAD_NONE, 0)
+
+    def spoil_no_image(j): j.out_packed = None
+    def spoil_custom_bg(j): j.bg_mode = _C.BG_CUSTOM
+    def spoil_bg_mode(j): j.bg_mode = 7
+    def spoil_head_ptr(j): j.head_ngp_w = None
+    def spoil_head_kind(j): j.field = ctypes.addressof(bad_desc)
+
+    for spoil in (spoil_no_image, spoil_custom_bg, spoil_bg_mode, spoil_head_ptr, spoil_head_kind):
+        job, frame = fresh()
+        job.field = ctypes.addressof(desc)
+        job.table, job.base_w = _C.ptr(field.mlp_base.grid_params()).value, _C.ptr(field.mlp_base.network_params()).value
+        job.head_ngp_w = _C.ptr(field.mlp_head.params.detach()).value
+        job.rgb_c, job.sigma_c, job.out_packed = rgbs.data_ptr(), sig.data_ptr(), out.data_ptr()
+        job.delta_const, job.bg_mode = 5e-3, _C.BG_WHITE
+        spoil(job)
+        torch.cuda.synchronize()
+        host = ri._frame_scratch(w * h)[2]
+        host[:] = -5                                      # the pinned block: any launch of the frame would rewrite it
+        frame.tile_base.fill_(-9)
+        with pytest.raises((ValueError, _C.QFError)):
+            _C.check(_C.lib().qf_frame_render(ri._handle, ctypes.byref(job), _C.stream()), "qf_frame_render")
+        torch.cuda.synchronize()
+        assert host.tolist() == [-5, -5, -5, -5], spoil.__name__
+        assert bool((frame.tile_base == -9).all()), spoil.__name__
     torch.cuda.synchronize()
     # sampling only (field = NULL) is a valid job: the tile pack's slot count arrives in total[0]
     job, frame = fresh()
