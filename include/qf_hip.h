@@ -492,7 +492,15 @@ int64_t qf_frame_offsets_temp_bytes(int64_t n_rays);
 int qf_frame_offsets(const int32_t *hit_count, int64_t n_rays, int32_t max_hits, int32_t width, int32_t height,
                      int64_t *ray_offset /* [n_rays+1] */, int64_t *tile_base /* or NULL */, void *temp,
                      int64_t temp_bytes, const int32_t *overflow_in, const int32_t *ray_flag_in, int64_t *host_out,
-                     void *stream);
+                     int32_t band_rows, void *stream);
+/* band_rows (here and on qf_coherent_layout; 0 = off): the tile grid of the coherent order restarts every band_rows
+ * rows, so that the samples of rows [b band_rows, (b+1) band_rows) are ONE contiguous run of the order -- positions
+ * [ray_offset[b band_rows width], ray_offset[(b+1) band_rows width]), the same range they occupy ray-major.  With
+ * band_rows = chunk / width the 160 000-ray windows of the reference's eval loop (generate_splits,
+ * train_finetune.py:419-439) are then slices of ONE frame-wide layout instead of a layout search per window.
+ * tile_base then has qf_banded_tile_count(width, height, band_rows) entries (a band's last tile row is partial when
+ * band_rows is not a multiple of 8); qf_pack_tiles / qf_composite_tiles take unbanded frames only.                 */
+int64_t qf_banded_tile_count(int32_t width, int32_t height, int32_t band_rows);
 
 /* The same for a frame that is only rendered: tile_base (as above) and *total (device int64) alone -- what
  * qf_pack_tiles and qf_composite_tiles take -- in two launches, without the per-ray offsets.              */
@@ -568,7 +576,8 @@ int qf_coherent_order(const int32_t *hit_count, const int64_t *ray_offset, const
 /* Same order together with its inverse: inverse[sample] = position (see qf_pack_samples).  order may be NULL
  * (a render-only frame streams the coherent copies and only needs the inverse).                  */
 int qf_coherent_layout(const int32_t *hit_count, const int64_t *ray_offset, const int64_t *tile_base,
-                       int32_t width, int32_t height, int32_t *order, int32_t *inverse, void *stream);
+                       int32_t width, int32_t height, int32_t *order, int32_t *inverse,
+                       int32_t band_rows /* as qf_frame_offsets' */, void *stream);
 
 /* derive_properties (utils.py:863-898; the eval render of train_finetune.py:597-607) on a frame whose per-sample
  * colours, densities and depths are stored in the coherent order above (rgb_c / sigma_c = qf_field_forward's outputs

@@ -134,13 +134,14 @@ _SIGNATURES = {
     "qf_sample_offsets_temp_bytes": (c_int64, [c_int64]),
     "qf_sample_offsets": (c_int, [_P, c_int64, c_int32, _P, _P, c_int64, _P]),
     "qf_frame_offsets_temp_bytes": (c_int64, [c_int64]),
-    "qf_frame_offsets": (c_int, [_P, c_int64, c_int32, c_int32, c_int32, _P, _P, _P, c_int64, _P, _P, _P, _P]),
+    "qf_frame_offsets": (c_int, [_P, c_int64, c_int32, c_int32, c_int32, _P, _P, _P, c_int64, _P, _P, _P, c_int32, _P]),
+    "qf_banded_tile_count": (c_int64, [c_int32, c_int32, c_int32]),
     "qf_tile_offsets": (c_int, [_P, c_int32, c_int32, c_int32, _P, _P, _P, _P, _P, _P, _P]),
     "qf_pack_tiles": (c_int, [_P, _P, c_int32, c_int32, c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_float, _P, _P, _P, c_int32, _P]),
     "qf_pack_samples": (c_int, [_P, _P, c_int64, c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_float, _P, _P]),
     "qf_tile_totals": (c_int, [_P, c_int32, c_int32, _P, _P]),
     "qf_coherent_order": (c_int, [_P, _P, _P, c_int32, c_int32, _P, _P]),
-    "qf_coherent_layout": (c_int, [_P, _P, _P, c_int32, c_int32, _P, _P, _P]),
+    "qf_coherent_layout": (c_int, [_P, _P, _P, c_int32, c_int32, _P, _P, c_int32, _P]),
     "qf_resort_by_depth": (c_int, [_P, _P, c_int64, _P, _P]),
     "qf_resort_samples": (c_int, [_P, _P, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "qf_split_layout": (c_int, [_P, c_int64, c_int32, c_int32, _P, _P, _P, _P, _P, _P, _P]),

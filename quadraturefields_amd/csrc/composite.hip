@@ -438,11 +438,7 @@ namespace {
 
 __device__ __forceinline__ int tile_lane_ray(int tile, int lane, int w, int h, int tiles_x, int64_t *ray)
 {
-    const int px = (tile % tiles_x) * 8 + (lane & 7);
-    const int py = (tile / tiles_x) * 8 + (lane >> 3);
-    if (px >= w || py >= h) return 0;
-    *ray = (int64_t)py * w + px;
-    return 1;
+    return qf_tile_lane_ray(tile, lane, w, h, tiles_x, 0, ray);
 }
 
 __global__ __launch_bounds__(64) void tile_totals_kernel(const int32_t *hit_count, int w, int h, int tiles_x,
@@ -460,13 +456,13 @@ __global__ __launch_bounds__(64) void tile_totals_kernel(const int32_t *hit_coun
 // order[pos] = sample (ray-major index) for every position of the coherent sequence; optionally the inverse map too.
 __global__ __launch_bounds__(64) void coherent_order_kernel(const int32_t *hit_count, const int64_t *ray_offset,
                                                             const int64_t *tile_base, int w, int h, int tiles_x,
-                                                            int32_t *order, int32_t *inverse)
+                                                            int32_t *order, int32_t *inverse, int band_rows)
 {
     const int tile = blockIdx.x, lane = threadIdx.x;
     int64_t ray = 0;
     int cnt = 0;
     int64_t first = 0;
-    if (tile_lane_ray(tile, lane, w, h, tiles_x, &ray)) { cnt = hit_count[ray]; first = ray_offset[ray]; }
+    if (qf_tile_lane_ray(tile, lane, w, h, tiles_x, band_rows, &ray)) { cnt = hit_count[ray]; first = ray_offset[ray]; }
     int64_t base = tile_base[tile];
     const unsigned long long below = (1ull << lane) - 1ull;
     for (int k = 0;; ++k) {
@@ -694,19 +690,21 @@ extern "C" int qf_coherent_order(const int32_t *hit_count, const int64_t *ray_of
     if (width < 1 || height < 1 || !hit_count || !ray_offset || !tile_base || !order) return QF_ERR_INVALID_ARGUMENT;
     const int tiles_x = (width + 7) / 8, tiles_y = (height + 7) / 8;
     hipLaunchKernelGGL(coherent_order_kernel, dim3(tiles_x * tiles_y), dim3(64), 0, qf_stream(stream), hit_count,
-                       ray_offset, tile_base, (int)width, (int)height, tiles_x, order, (int32_t *)nullptr);
+                       ray_offset, tile_base, (int)width, (int)height, tiles_x, order, (int32_t *)nullptr, 0);
     QF_LAUNCH_CHECK();
     return QF_OK;
 }
 
 extern "C" int qf_coherent_layout(const int32_t *hit_count, const int64_t *ray_offset, const int64_t *tile_base,
-                                  int32_t width, int32_t height, int32_t *order, int32_t *inverse, void *stream)
+                                  int32_t width, int32_t height, int32_t *order, int32_t *inverse, int32_t band_rows,
+                                  void *stream)
 {
-    if (width < 1 || height < 1 || !hit_count || !ray_offset || !tile_base || !inverse)       // order may be NULL
+    if (width < 1 || height < 1 || band_rows < 0 || !hit_count || !ray_offset || !tile_base || !inverse)    // order may be NULL
         return QF_ERR_INVALID_ARGUMENT;
-    const int tiles_x = (width + 7) / 8, tiles_y = (height + 7) / 8;
-    hipLaunchKernelGGL(coherent_order_kernel, dim3(tiles_x * tiles_y), dim3(64), 0, qf_stream(stream), hit_count,
-                       ray_offset, tile_base, (int)width, (int)height, tiles_x, order, inverse);
+    const int tiles_x = (width + 7) / 8;
+    hipLaunchKernelGGL(coherent_order_kernel, dim3((unsigned)qf_banded_tiles(width, height, band_rows)), dim3(64), 0,
+                       qf_stream(stream), hit_count, ray_offset, tile_base, (int)width, (int)height, tiles_x, order, inverse,
+                       (int)band_rows);
     QF_LAUNCH_CHECK();
     return QF_OK;
 }

@@ -49,7 +49,7 @@ __device__ __forceinline__ int64_t block_inclusive_scan(int64_t v, int64_t *s_wa
 __global__ __launch_bounds__(kFoThreads) void frame_partials_kernel(const int32_t *__restrict__ hit_count, int64_t n_rays,
                                                                     int32_t cap, int n_blocks, int w, int h, int tiles_x,
                                                                     int n_tiles, int64_t *__restrict__ partial,
-                                                                    int64_t *__restrict__ tile_total)
+                                                                    int64_t *__restrict__ tile_total, int band_rows)
 {
     __shared__ int64_t s_wave[kFoThreads / 64];
     if ((int)blockIdx.x < n_blocks) {
@@ -70,8 +70,8 @@ __global__ __launch_bounds__(kFoThreads) void frame_partials_kernel(const int32_
     }
     const int tile = ((int)blockIdx.x - n_blocks) * (kFoThreads / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (tile >= n_tiles) return;
-    const int px = (tile % tiles_x) * 8 + (lane & 7), py = (tile / tiles_x) * 8 + (lane >> 3);
-    int64_t cnt = (px < w && py < h) ? clamped(hit_count, (int64_t)py * w + px, n_rays, cap) : 0;
+    int64_t ray = 0;
+    int64_t cnt = qf_tile_lane_ray(tile, lane, w, h, tiles_x, band_rows, &ray) ? clamped(hit_count, ray, n_rays, cap) : 0;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
     if (lane == 0) tile_total[tile] = cnt;
@@ -147,6 +147,12 @@ __global__ __launch_bounds__(kFoThreads) void frame_ray_offsets_kernel(const int
 
 }  // namespace
 
+extern "C" int64_t qf_banded_tile_count(int32_t width, int32_t height, int32_t band_rows)
+{
+    if (width < 1 || height < 1 || band_rows < 0) return -1;
+    return qf_banded_tiles(width, height, band_rows);
+}
+
 extern "C" int64_t qf_frame_offsets_temp_bytes(int64_t n_rays)
 {
     if (n_rays < 0) return -1;
@@ -155,9 +161,11 @@ extern "C" int64_t qf_frame_offsets_temp_bytes(int64_t n_rays)
 
 extern "C" int qf_frame_offsets(const int32_t *hit_count, int64_t n_rays, int32_t max_hits, int32_t width, int32_t height,
                                 int64_t *ray_offset, int64_t *tile_base, void *temp, int64_t temp_bytes,
-                                const int32_t *overflow_in, const int32_t *ray_flag_in, int64_t *host_out, void *stream)
+                                const int32_t *overflow_in, const int32_t *ray_flag_in, int64_t *host_out, int32_t band_rows,
+                                void *stream)
 {
-    if (n_rays < 0 || n_rays >= 0x7fffffff || max_hits < 1 || width < 0 || height < 0) return QF_ERR_INVALID_ARGUMENT;
+    if (n_rays < 0 || n_rays >= 0x7fffffff || max_hits < 1 || width < 0 || height < 0 || band_rows < 0)
+        return QF_ERR_INVALID_ARGUMENT;
     if (!ray_offset || !temp || (n_rays > 0 && !hit_count)) return QF_ERR_INVALID_ARGUMENT;
     if (temp_bytes < qf_frame_offsets_temp_bytes(n_rays)) return QF_ERR_INVALID_ARGUMENT;
     const bool tiles = tile_base != nullptr;
@@ -165,12 +173,13 @@ extern "C" int qf_frame_offsets(const int32_t *hit_count, int64_t n_rays, int32_
     hipStream_t st = qf_stream(stream);
     const int n_blocks = (int)qf_div_up(n_rays, kFoRays);
     const int tiles_x = tiles ? (width + 7) / 8 : 0;
-    const int n_tiles = tiles ? tiles_x * ((height + 7) / 8) : 0;
+    const int n_tiles = tiles ? (int)qf_banded_tiles(width, height, band_rows) : 0;
     int64_t *partial = reinterpret_cast<int64_t *>(temp);
     const int tile_blocks = (int)qf_div_up(n_tiles, kFoThreads / 64);
     if (n_blocks + tile_blocks > 0) {
         hipLaunchKernelGGL(frame_partials_kernel, dim3((unsigned)(n_blocks + tile_blocks)), dim3(kFoThreads), 0, st, hit_count,
-                           n_rays, max_hits, n_blocks, (int)width, (int)height, tiles_x, n_tiles, partial, tile_base);
+                           n_rays, max_hits, n_blocks, (int)width, (int)height, tiles_x, n_tiles, partial, tile_base,
+                           (int)band_rows);
         QF_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(frame_scan_kernel, dim3(1), dim3(kFoThreads), 0, st, partial, n_blocks, tile_base, n_tiles,
@@ -198,7 +207,7 @@ extern "C" int qf_tile_offsets(const int32_t *hit_count, int32_t max_hits, int32
     const int n_tiles = tiles_x * ((height + 7) / 8);
     const int tile_blocks = (int)qf_div_up(n_tiles, kFoThreads / 64);
     hipLaunchKernelGGL(frame_partials_kernel, dim3((unsigned)tile_blocks), dim3(kFoThreads), 0, st, hit_count, n_rays, max_hits,
-                       0, (int)width, (int)height, tiles_x, n_tiles, (int64_t *)nullptr, tile_base);
+                       0, (int)width, (int)height, tiles_x, n_tiles, (int64_t *)nullptr, tile_base, 0);
     hipLaunchKernelGGL(frame_scan_kernel, dim3(1), dim3(kFoThreads), 0, st, (int64_t *)nullptr, 0, tile_base, n_tiles, total,
                        overflow_in, host_out, zero_word, ray_flag_in);
     QF_LAUNCH_CHECK();
@@ -217,5 +226,5 @@ extern "C" int qf_sample_offsets(const int32_t *hit_count, int64_t n_rays, int32
 {
     if (temp_bytes < qf_sample_offsets_temp_bytes(n_rays)) return QF_ERR_INVALID_ARGUMENT;
     return qf_frame_offsets(hit_count, n_rays, max_hits, 0, 0, ray_offset, nullptr, temp, temp_bytes, nullptr, nullptr,
-                            nullptr, stream);
+                            nullptr, 0, stream);
 }

@@ -105,6 +105,30 @@ def _permute_rows(x, perm):
     return _PermuteRowsFn.apply(x, perm) if x.requires_grad else x[perm]
 
 
+class SampleSet(tuple):
+    """The six sample tensors of a frame -- ``(xyzs, dirs, index_ray, ts, index_tri, origins)``, what the reference's
+    loader hands to the renderers (nerf_synthetic.py:256-257); this IS that tuple -- plus, as attributes, one frame-wide
+    coherent layout cut at the windows of ``generate_splits``: ``cuts`` (first sample of every window, and the total),
+    ``window_rays``, ``num_rays``, ``inverse`` / ``order`` (sample <-> position, int32) and the streamed copies
+    ``xyz_c`` / ``dirs_c``.  A window's samples are ``[cuts[w], cuts[w+1])`` in the ray-major arrays AND in the copies."""
+
+    def __new__(cls, arrays, **meta):
+        obj = super().__new__(cls, arrays)
+        obj.__dict__.update(meta)
+        return obj
+
+
+class SampleWindow(tuple):
+    """One window of a ``SampleSet`` (``generate_splits``): the reference's 6-tuple of the window's samples (views), plus
+    ``base`` = the window's first sample and the same range of the frame's layout (``inverse`` / ``order`` hold FRAME
+    positions: subtract ``base``)."""
+
+    def __new__(cls, arrays, **meta):
+        obj = super().__new__(cls, arrays)
+        obj.__dict__.update(meta)
+        return obj
+
+
 class _InterView:
     """``RayIntersector.inter``: the native module's two methods, bound to the adapter's BVH."""
 
@@ -498,7 +522,7 @@ class RayIntersector:
         hit_count._qf_keep = (mask, raw) if mask is not None else None
 
     def pack_hits(self, o, d, k, hit_tri, hit_t, hit_count, overflow, width, lean=False, layout=True,
-                  defer_rule_check=False, want_tri=False):
+                  defer_rule_check=False, want_tri=False, band_rows=0):
         """Per-ray hit lists -> ([xyzs, dirs, index_ray, ts, index_tri, origins] or None, coherent order or None).
 
         The output size is data dependent.  Instead of stalling on it, the offsets are scanned on the device, the
@@ -509,18 +533,22 @@ class RayIntersector:
         device, the count only steers the intersector policy.  ``pack_hits_begin`` / ``pack_hits_end`` are the two halves, for callers
         that keep several frames in flight on different streams."""
         return self.pack_hits_end(self.pack_hits_begin(o, d, k, hit_tri, hit_t, hit_count, overflow, width, lean, layout,
-                                                       want_tri), defer_rule_check)
+                                                       want_tri, band_rows=band_rows), defer_rule_check)
 
     @_on_device
     def pack_hits_begin(self, o, d, k, hit_tri, hit_t, hit_count, overflow, width, lean=False, layout=True,
-                        want_tri=False, publish=True):
+                        want_tri=False, publish=True, band_rows=0):
         """Enqueue scan, readback, pack and ordering on the current stream; no host wait.  ``lean`` (image-shaped
         batches only): a caller that only renders reads the streamed copies in ``last_layout`` / ``last_frame``, so the
         tile kernel (``qf_pack_tiles``) writes just those and the six ray-major arrays come back as None.
         ``want_tri`` (lean frames): also the samples' triangle ids in that order (``last_frame.tri_c``; the baked-texture
         render looks its texels up by triangle).  ``layout=False``: no processing order at all.  ``publish=False`` (lean
         frames packed by ``pack_hits_device``): the tile pack's dropped-hit count stays in device memory -- no
-        publishing launch; ``frame_samples()`` copies it when asked."""
+        publishing launch; ``frame_samples()`` copies it when asked.
+        ``band_rows`` (ray-major packs of an image only): the coherent layout's tile grid restarts every ``band_rows`` rows
+        (``qf_frame_offsets`` band_rows), so that the samples of each band of rows -- a window of the reference's eval loop
+        -- are one contiguous run of the coherent copies, at the same positions they have ray-major; the bands' sample
+        boundaries come back with the frame's 16-byte readback (``last_band_cuts``)."""
         n = o.shape[0]
         dev = self.device
         buf, temp, host, (ev, ev_flag), dropped = self._frame_scratch(n)
@@ -529,9 +557,14 @@ class RayIntersector:
         self.last_image_shape = (int(width), n // int(width)) if width > 0 and n % width == 0 else None
         # sample offsets (+ total) and, for an image, the tile bases of the coherent order: three small launches
         tile_base = None
+        band_rows = int(band_rows) if (image and not lean and band_rows and band_rows > 0) else 0
+        tile_band = band_rows if (band_rows and band_rows < n // width) else 0      # one band = the plain tile grid
+        self.last_band_cuts = None
         if image:
             height = n // width
-            tile_base = torch.empty((((width + 7) // 8) * ((height + 7) // 8),), dtype=torch.int64, device=dev)
+            n_tiles = ((width + 7) // 8) * ((height + 7) // 8) if not tile_band else \
+                int(_C.lib().qf_banded_tile_count(int(width), height, tile_band))
+            tile_base = torch.empty((n_tiles,), dtype=torch.int64, device=dev)
         # the camera-coherent pass's ray flag rides behind its overflow counter (``_hits_raster_frame``): to host[3]
         ray_flag = overflow[1:] if (overflow is not None and overflow.numel() >= 2) else None
         if bool(lean) and image:              # render-only frame: tile bases + total, no per-ray offsets
@@ -542,8 +575,15 @@ class RayIntersector:
         else:
             _C.check(_C.lib().qf_frame_offsets(_C.ptr(hit_count), n, k, int(width) if image else 0, n // width if image else 0,
                                                _C.ptr(buf), _C.ptr(tile_base), _C.ptr(temp), temp.numel(), _C.ptr(overflow),
-                                               _C.ptr(ray_flag), ctypes.c_void_p(host.data_ptr()), _C.stream()),
+                                               _C.ptr(ray_flag), ctypes.c_void_p(host.data_ptr()), tile_band, _C.stream()),
                      "qf_frame_offsets")
+            if band_rows:
+                # the bands' first samples = the ray offsets at the bands' first rays: a handful of int64 that ride to
+                # pinned memory beside the total, so that generate_splits needs neither a search nor a host wait
+                edges = self._band_edges(n, int(width), band_rows)
+                cuts_host = self._band_cut_buffer(edges.shape[0])
+                cuts_host.copy_(buf.index_select(0, edges), non_blocking=True)
+                self.last_band_cuts = (cuts_host, band_rows * int(width))
         ev.record()                           # (total, overflow) are in pinned memory once this event has passed
         lean = bool(lean) and image
         want_layout = layout
@@ -592,8 +632,11 @@ class RayIntersector:
             index_tri = torch.empty((cap,), dtype=torch.int64, device=dev)
             depth = torch.empty((cap,), dtype=torch.float32, device=dev)
             if image:                         # the coherent order and its inverse
-                order, inverse = self.coherent_layout(hit_count, buf, cap, width, tile_base, want_order=True)
+                order, inverse = self.coherent_layout(hit_count, buf, cap, width, tile_base, want_order=True,
+                                                      band_rows=tile_band)
                 layout = (inverse, xyz_c, dirs_c)
+                if tile_band:                 # a banded tile grid: not the geometry qf_composite_tiles walks
+                    frame.band_rows = tile_band
             _C.check(_C.lib().qf_pack_samples(_C.ptr(o), _C.ptr(d), n, k, _C.ptr(hit_tri), _C.ptr(hit_t),
                                               _C.ptr(hit_count), _C.ptr(buf), _C.ptr(xyz), _C.ptr(dirs),
                                               _C.ptr(index_ray), _C.ptr(depth), _C.ptr(index_tri), _C.ptr(org),
@@ -602,7 +645,7 @@ class RayIntersector:
                      "qf_pack_samples")
         if optimistic:
             ev_flag.record()
-        return (o, d, k, width, (lean, want_layout), host, (ev, ev_flag if (optimistic or lean) else None),
+        return (o, d, k, width, (lean, want_layout, band_rows), host, (ev, ev_flag if (optimistic or lean) else None),
                 [xyz, dirs, index_ray, depth, index_tri, org], order, layout,
                 (hit_tri, hit_t, hit_count, keep),    # the lists stay referenced until the kernels reading them ran
                 frame)
@@ -774,14 +817,16 @@ class RayIntersector:
     def _repack_exact(self, pending):
         """The optimistic pack of ``pending`` failed its check: decide the rule per ray (keep masks over the same
         lists) and pack again."""
-        o, d, k, width, (lean, want_layout), _host, _evs, _arrays, _order, _layout, (hit_tri, hit_t, hit_count, _keep), _frame = pending
+        o, d, k, width, (lean, want_layout, band_rows), _host, _evs, _arrays, _order, _layout, (hit_tri, hit_t, hit_count, _keep), _frame = pending
         self._rule_violation()
         self._repair(o, d, k, width, hit_tri, hit_t, hit_count, with_mask=True)
-        return self.pack_hits_end(self.pack_hits_begin(o, d, k, hit_tri, hit_t, hit_count, None, width, lean, want_layout))
+        return self.pack_hits_end(self.pack_hits_begin(o, d, k, hit_tri, hit_t, hit_count, None, width, lean, want_layout,
+                                                       band_rows=band_rows))
 
     @_on_device
     def sample_device(self, origins, vectors, max_hits: Optional[int] = None, image_width: int = 0, camera=None,
-                      lean: bool = False, layout: bool = True, defer_rule_check: bool = False, want_tri: bool = False):
+                      lean: bool = False, layout: bool = True, defer_rule_check: bool = False, want_tri: bool = False,
+                      band_rows: int = 0):
         """Packed, sorted samples on the device: [xyzs, dirs, index_ray, ts, index_tri, origins] -- the six
         tensors the reference's DataLoader hands to the renderers (nerf_synthetic.py:256-257) -- or None
         when no ray hits anything.  ``lean`` with a camera: a render-only frame -- six Nones; the samples are in
@@ -801,7 +846,7 @@ class RayIntersector:
             hit_tri, hit_t, hit_count = self._hits_bvh(o, d, k, image_width)
             overflow = None
         data, self.last_order = self.pack_hits(o, d, k, hit_tri, hit_t, hit_count, overflow, int(image_width), lean,
-                                               layout, defer_rule_check, want_tri)
+                                               layout, defer_rule_check, want_tri, band_rows)
         return data
 
     @_on_device
@@ -896,7 +941,29 @@ class RayIntersector:
         self.last_frame = frame
 
     @_on_device
-    def coherent_layout(self, hit_count, ray_offset, total: int, width: int, tile_base=None, want_order=True):
+    def _band_edges(self, n_rays: int, width: int, band_rows: int) -> torch.Tensor:
+        """First ray of every band of ``band_rows`` rows, and ``n_rays``: int64 on the device, cached."""
+        key = (n_rays, width, band_rows)
+        cache = self.__dict__.setdefault("_band_edge_cache", {})
+        e = cache.get(key)
+        if e is None:
+            if len(cache) > 8:
+                cache.clear()
+            step = band_rows * width
+            e = cache[key] = torch.tensor(list(range(0, n_rays, step)) + [n_rays], dtype=torch.int64, device=self.device)
+        return e
+
+    def _band_cut_buffer(self, m: int) -> torch.Tensor:
+        """Pinned int64 [m], two alternating per size (the previous frame's cuts may not have been read yet)."""
+        ring = self.__dict__.setdefault("_band_cut_ring", {})
+        r = ring.get(m)
+        if r is None:
+            r = ring[m] = [[torch.empty((m,), dtype=torch.int64).pin_memory() for _ in range(4)], 0]
+        r[1] += 1
+        return r[0][r[1] % len(r[0])]
+
+    def coherent_layout(self, hit_count, ray_offset, total: int, width: int, tile_base=None, want_order=True,
+                        band_rows: int = 0):
         """``coherent_order`` and its inverse map (``inverse[sample] = position``).  Given the inverse,
         ``qf_pack_samples`` also writes ``xyz[order]`` / ``dirs[order]``, so ``field(xyz_c, dirs_c)`` reads and writes
         sequentially (the indirection through ``order`` costs it 10 %), and
@@ -913,7 +980,8 @@ class RayIntersector:
         order = torch.empty((total,), dtype=torch.int32, device=dev) if want_order else None
         inverse = torch.empty((total,), dtype=torch.int32, device=dev)
         _C.check(_C.lib().qf_coherent_layout(_C.ptr(hit_count), _C.ptr(ray_offset), _C.ptr(tile_base), width, height,
-                                             _C.ptr(order), _C.ptr(inverse), _C.stream()), "qf_coherent_layout")
+                                             _C.ptr(order), _C.ptr(inverse), int(band_rows), _C.stream()),
+                 "qf_coherent_layout")
         return order, inverse
 
     @_on_device
@@ -1077,11 +1145,29 @@ class MeshIntersection:
         """Constant step for every sample (mesh_utils.py:225-231; B-4)."""
         return torch.full((depth.shape[0],), self.render_step_size, dtype=torch.float32, device=self.device)
 
-    def sampling_raytrace_device(self, vectors, origins, image_width: int = 0, camera=None, layout: bool = True):
+    def sampling_raytrace_device(self, vectors, origins, image_width: int = 0, camera=None, layout: bool = True,
+                                 window_rays: int = 0):
         """Fast path of ``sampling_raytrace_numpy``: same six arrays, on the device, no host round trip.
-        ``camera`` (``make_camera``): the rays are that camera's full pixel grid -> camera-coherent intersector."""
-        return self.rayintersector.sample_device(origins, vectors, self.num_intersections, image_width, camera,
-                                                 layout=layout)
+        ``camera`` (``make_camera``): the rays are that camera's full pixel grid -> camera-coherent intersector.
+        ``window_rays`` (with a camera or an image width, and ``layout``): the caller will cut the frame into windows of
+        this many rays (``generate_splits``, 160 000 in the reference's eval loop).  When that is a whole number of rows the
+        result is a ``SampleSet``: the same six tensors (it IS a tuple of them) that also carries ONE frame-wide coherent
+        layout whose tile grid restarts at every window, so that ``generate_splits`` hands out windows without a search or
+        a host wait and ``render_image_finetune_with_occgrid`` streams each of them without deriving a layout."""
+        ri = self.rayintersector
+        width = int(camera.width) if camera is not None else int(image_width)
+        band_rows = 0
+        if layout and window_rays and width > 0 and window_rays % width == 0:
+            band_rows = int(window_rays) // width
+        data = ri.sample_device(origins, vectors, self.num_intersections, image_width, camera, layout=layout,
+                                band_rows=band_rows)
+        if data is None or not band_rows or ri.last_band_cuts is None or ri.last_layout is None:
+            return data
+        cuts_host, band_rays = ri.last_band_cuts
+        inverse, xyz_c, dirs_c = ri.last_layout
+        n_rays = int(vectors.shape[0]) if hasattr(vectors, "shape") else int(len(vectors))
+        return SampleSet(data, cuts=cuts_host.tolist(), window_rays=band_rays, num_rays=n_rays, inverse=inverse,
+                         order=ri.last_order, xyz_c=xyz_c, dirs_c=dirs_c, width=width)
 
     def sampling_raytrace_numpy(self, vectors, origins, random=0):
         """numpy 7-tuple (points, dirs, index_ray, depth, index_tri, 0, origins) sorted by (ray, depth), or None

@@ -18,6 +18,7 @@ import torch
 from . import _C
 from .datasets.utils import Rays, namedtuple_map
 from .field import Field as _Field
+from .mesh_utils import SampleSet, SampleWindow
 
 NERF_SYNTHETIC_SCENES = ["chair", "drums", "ficus", "hotdog", "lego", "materials", "mic", "ship"]
 # imported by both harness scripts (train_finetune.py:18, test_baking_texture_images.py:23) and only used to pick the
@@ -51,6 +52,18 @@ def generate_splits(data, num_rays, chunk_size=160000):
     xyzs, dirs, index_ray, ts, index_tri, origins = data
     chunks = []
     n = int(index_ray.shape[0])
+    if (isinstance(data, SampleSet) and int(chunk_size) == data.window_rays and int(num_rays) == data.num_rays
+            and data.cuts[-1] == n):
+        # a loader item cut for exactly these windows (SubjectLoader -> sampling_raytrace_device(window_rays=)): the
+        # windows' boundaries came back with the frame's own readback and the frame-wide coherent layout restarts at every
+        # window -- views only, no launch, no host wait; empty windows are skipped as the reference does (:427-428)
+        for a, b in zip(data.cuts[:-1], data.cuts[1:]):
+            if b > a:
+                chunks.append(SampleWindow(tuple(t[a:b] for t in (xyzs, dirs, index_ray, ts, index_tri, origins)),
+                                           base=a, inverse=data.inverse[a:b],
+                                           order=None if data.order is None else data.order[a:b],
+                                           xyz_c=data.xyz_c[a:b], dirs_c=data.dirs_c[a:b], num_rays=data.num_rays))
+        return chunks
     if n > 0 and index_ray.is_cuda and index_ray.dim() == 1 and index_ray.dtype == torch.int64:
         edges = torch.arange(0, int(num_rays) + int(chunk_size), int(chunk_size), dtype=torch.int64, device=index_ray.device)
         cuts = torch.searchsorted(index_ray, edges)
@@ -164,6 +177,9 @@ def composite_frame(color_c, density_c, frame, render_step_size: float, render_b
     density_c = _C.f32c(density_c.reshape(-1))
     dev = color_c.device
     n = frame.depth_c.shape[0]
+    if getattr(frame, "band_rows", 0):
+        raise ValueError("composite_frame: this frame's layout is cut into row bands (a loader item for generate_splits); "
+                         "composite it with derive_properties(sample_index=inverse)")
     if color_c.shape[0] != n or density_c.shape[0] != n:
         raise ValueError(f"composite_frame: {n} samples in the frame, {color_c.shape[0]} colours, {density_c.shape[0]} densities")
     n_rays = frame.width * frame.height
@@ -262,7 +278,28 @@ def render_image_finetune_with_occgrid(
     inference = not (torch.is_grad_enabled() and (xyzs.requires_grad or ts.requires_grad or _module_trains(radiance_field)
                                                   or _module_trains(field_net)))
     auto_inverse = None
-    if order is None and inference and xyzs.shape[0] > 0:
+    window = data if (isinstance(data, SampleWindow) and inference and order is None and xyzs.shape[0] > 0
+                      and data.num_rays == num_rays and data.inverse.device == device) else None
+    if window is not None:
+        # a window of a loader item that came with its frame-wide coherent layout (generate_splits): positions relative
+        # to the window's first sample -- one subtraction instead of the four launches of qf_split_layout
+        deforms = field_net is not None and scaling != 0
+        auto_inverse = window.inverse - window.base
+        if deforms and isinstance(field_net, _Field) and window.order is not None:
+            order = window.order - window.base
+        if not deforms:
+            # no deformation: the samples ARE sorted by (ray, depth), the re-sort of sampling_indexing is the identity
+            # (what FrameRenderer.render relies on too) and the loader's pack has already written the streamed copies:
+            # field on the window's slice of them, compositing through the inverse map -- no resort launch at all
+            rgbs, sigmas = radiance_field(window.xyz_c, window.dirs_c)
+            rgb, opacity, _, depth_img, weights = derive_properties(
+                rgbs, sigmas.reshape(-1), ts, float(mesh_intersect.render_step_size), None, index_ray, bg_color=bg_color,
+                render_bkgd=render_bkgd, N=num_rays, sample_index=auto_inverse)
+            if mesh_finetune is not None:
+                mesh_finetune.update_d(None, weights[:, 0].detach(), index_tri)
+            return (rgb.view((*rays_shape[:-1], -1)), opacity.view((*rays_shape[:-1], -1)),
+                    depth_img.view((*rays_shape[:-1], -1)), xyzs.shape[0], weights, xyzs, index_ray, loss, index_tri)
+    elif order is None and inference and xyzs.shape[0] > 0:
         # the reference's eval loop hands over a window of a frame and no processing order: derive the coherent order
         # from the window's own ray ids (qf_split_layout) when the intersector knows the frame's width, and let the
         # re-sort launch write the streamed copies -- locality only, same pixels
@@ -352,8 +389,14 @@ def render_image_bake_texture_images_with_occgrid(
     rays, rays_shape, num_rays = _flatten_rays(rays)
     device = mesh_intersect.device
     xyzs, dirs, index_ray, ts, index_tri, origins = _to_device(data, device)
-    points, deltas, boundary, dirs, index_ray, depth, index_tri, _ = mesh_intersect.sampling_indexing(
-        xyzs, origins, dirs, index_ray, ts, index_tri)
+    if isinstance(data, (SampleSet, SampleWindow)):
+        # the device loader's own pack: sorted by (ray, depth) by construction and nothing has displaced the samples
+        # since (this renderer has no deformation), so the re-sort of sampling_indexing (mesh_utils.py:389-412) is the
+        # identity and the constant step needs no boundaries -- one launch and one boolean-mask gather less per frame
+        points, depth, deltas, boundary = xyzs, ts, float(mesh_intersect.render_step_size), None
+    else:
+        points, deltas, boundary, dirs, index_ray, depth, index_tri, _ = mesh_intersect.sampling_indexing(
+            xyzs, origins, dirs, index_ray, ts, index_tri)
     texel = texel_indices(mesh_intersect, uv, points, index_tri, compressor.texture_size)
     if discretize:
         feats = compressor.get_features_from_texture_map(texel)

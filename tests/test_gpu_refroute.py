@@ -247,3 +247,96 @@ def test_reference_eval_loop_equals_the_frame_renderer(device, scaling):
         rgb_f, _, dep_f, _ = fr.render(rays.origins, rays.viewdirs, scaling=scaling, camera=item["camera"])
         assert torch.equal(rgb_a, rgb_f)
         assert torch.equal(dep_a, dep_f.reshape(-1))
+
+
+@pytest.mark.parametrize("scaling", [0.0, 0.05])
+@pytest.mark.parametrize("window_rows", [24, 20, 96, 200])
+def test_loader_items_cut_for_their_windows_give_the_same_frame(device, scaling, window_rows):
+    """Round 4: an evaluation item of the device loader carries ONE frame-wide coherent layout whose
+    tile grid restarts at every window of ``generate_splits`` (``SampleSet`` / ``qf_frame_offsets`` band_rows), so the
+    windows are views handed out without a search or a host wait and ``render_image_finetune_with_occgrid`` streams each
+    of them without deriving a layout (and, with scaling = 0, without the identity re-sort).  The assembled frame, the
+    per-window 9-tuples' sample tensors and the triangle weights must equal the round-3 route (plain six tensors ->
+    searchsorted windows -> qf_split_layout per window) BIT FOR BIT -- for windows that are whole tile rows (24), that cut
+    tile rows (20: the up_sample-2 case, 100 rows of 1600), one window = the frame (96) and a window larger than it."""
+    from quadraturefields_amd import synthetic, utils
+    from quadraturefields_amd.datasets.nerf_synthetic import SubjectLoader
+    from quadraturefields_amd.field import Field
+    from quadraturefields_amd.mesh_utils import MeshFinetune, SampleSet, SampleWindow
+    mesh, mi, field = _scene(device)
+    w = h = 96
+    cams = np.stack([np.asarray(c, dtype=np.float32) for c in synthetic.orbit_cameras(2, seed=6)])
+    ds = SubjectLoader.from_arrays(np.zeros((2, h, w, 4), np.uint8), cams, synthetic.lego_focal(800) * w / 800.0,
+                                   split="test", mesh_intersect=mi, device=device)
+    ds.WINDOW_RAYS = window_rows * w
+    torch.manual_seed(0)
+    field_net = Field(scale=1.5, precision=16, log2_T=14, L=16, max_res=512, min_res=16, output_dim=1, hidden_size=32,
+                      num_features=2, back_prop=False, nl="relu").to(device)
+    with torch.no_grad():
+        field_net.xyz_encoder.params.uniform_(-0.5, 0.5)
+
+    def loop(data, rays, bkgd, mf):
+        n = rays.origins.shape[0]
+        rgb = torch.ones((n, 3), device=device)
+        depth = torch.zeros((n,), device=device)
+        outs = []
+        splits = utils.generate_splits(data, n, chunk_size=window_rows * w)
+        for split in splits:
+            out = utils.render_image_finetune_with_occgrid(
+                field, field_net, None, rays, split, render_step_size=5e-3, render_bkgd=bkgd, mesh_intersect=mi,
+                mesh_finetune=mf, scaling=scaling)
+            rgb[split[2]] = out[0][split[2]]
+            depth[split[2]] = out[2].squeeze()[split[2]]
+            outs.append(out)
+        return rgb, depth, outs, splits
+
+    for i in range(2):
+        item = ds[i]
+        data, rays = item["data"], item["rays"]
+        assert isinstance(data, SampleSet) and len(data) == 6 and data.window_rays == window_rows * w
+        assert data.cuts[0] == 0 and data.cuts[-1] == data[0].shape[0] and len(data.cuts) == -(-h // window_rows) + 1
+        # the layout is a permutation of every window onto itself, and the streamed copies are the samples in that order
+        inv = data.inverse.long()
+        for a, b in zip(data.cuts[:-1], data.cuts[1:]):
+            assert b == a or (int(inv[a:b].min()) == a and int(inv[a:b].max()) == b - 1)
+        assert torch.equal(torch.sort(inv).values, torch.arange(inv.shape[0], device=device))
+        assert torch.equal(data.xyz_c[inv], data[0]) and torch.equal(data.dirs_c[inv], data[1])
+        assert torch.equal(data.order.long()[inv], torch.arange(inv.shape[0], device=device))
+        mf_new = MeshFinetune(mi.mesh.vertices, mi.mesh.faces, 0.05, device=device)
+        mf_old = MeshFinetune(mi.mesh.vertices, mi.mesh.faces, 0.05, device=device)
+        rgb_n, dep_n, outs_n, splits_n = loop(data, rays, item["color_bkgd"], mf_new)
+        assert all(isinstance(s, SampleWindow) for s in splits_n)
+        plain = tuple(t.clone() for t in data)                    # the reference's six tensors and nothing else
+        rgb_o, dep_o, outs_o, splits_o = loop(plain, rays, item["color_bkgd"], mf_old)
+        assert not any(isinstance(s, SampleWindow) for s in splits_o) and len(splits_o) == len(splits_n)
+        assert torch.equal(rgb_n, rgb_o) and torch.equal(dep_n, dep_o)
+        for a, b in zip(outs_n, outs_o):
+            assert a[3] == b[3]
+            for j in (0, 1, 2, 4, 5, 6, 8):                        # colours, opacities, depths, weights, positions, ids
+                assert torch.equal(a[j], b[j]), j
+        # update_d saw the same (weight, triangle) pairs; the atomics' order differs
+        assert torch.allclose(mf_new.cache_w, mf_old.cache_w, rtol=1e-5, atol=1e-7)
+        assert torch.allclose(mf_new.cache_d, mf_old.cache_d, rtol=1e-4, atol=1e-7)
+        # a different chunk size than the item was cut for: the general route, same frame
+        n = rays.origins.shape[0]
+        other = utils.generate_splits(data, n, chunk_size=17 * w)
+        assert not any(isinstance(s, SampleWindow) for s in other)
+        assert sum(s[0].shape[0] for s in other) == data[0].shape[0]
+    # the baked-texture renderer takes the same items (and skips its identity re-sort): covered by
+    # test_gpu_render.py::test_baked_texture_render_matches_oracle through plain tuples and below through SampleSets
+    from quadraturefields_amd.radiance_fields.ngp import NGPRadianceFieldSGNew
+    from quadraturefields_amd.texture_utils import FeatureCompression
+    lobes, size = 3, 256
+    tex = synthetic.random_textures(size, lobes, seed=3)
+    comp = FeatureCompression.from_arrays(tex["alpha"], tex["diffuse"], tex["colors"], tex["lambdas"],
+                                          compression_type="sigmoid", lambda_thres=7.5, device=device)
+    uv = torch.from_numpy(synthetic.scaled_uv(mesh, size)).to(device)
+    sg = NGPRadianceFieldSGNew(aabb=[-1.5] * 3 + [1.5] * 3, use_viewdirs=False, num_g_lobes=lobes, log2_hashmap_size=14).to(device)
+    item = ds[0]
+    kw = dict(texture=None, uv=uv, render_step_size=5e-3, render_bkgd=item["color_bkgd"], mesh_intersect=mi,
+              mesh_finetune=None, scaling=0, discretize=False, compressor=comp)
+    a = utils.render_image_bake_texture_images_with_occgrid(sg, item["rays"], item["data"], **kw)
+    b = utils.render_image_bake_texture_images_with_occgrid(sg, item["rays"], tuple(t.clone() for t in item["data"]), **kw)
+    for j in (0, 1, 2, 4, 5):
+        assert torch.equal(a[j], b[j]), j
+    assert a[3] == b[3] > 500

@@ -261,12 +261,16 @@ def test_crop_fixture_on_the_gpu(device):
     assert float((alpha.cpu() - torch.from_numpy(z["alpha"])).abs().max()) <= 2e-4
 
 
-def test_config3_bf16_dense_shell_frame_matches_the_bf16_oracle(device):
+@pytest.mark.parametrize("seeded", [True, False])
+def test_config3_bf16_dense_shell_frame_matches_the_bf16_oracle(device, seeded):
     """BASELINE configs[2] end to end at test size: a dense-shell scene (most object rays meet more than K = 6
     triangles), the camera-coherent pass with WIDE candidate lists -> K-nearest selection -> per-ray repair -> pack ->
     field_kernel_bf16 -> compositing, against brute-force quadrature points (bit-exact) and the bf16 oracle on them.
     Pixel tolerance 1e-2: bf16 field outputs agree to 2e-3 (test_bf16_ngp_matches_bf16_oracle) and are amplified by the
-    density exponential and the transmittance product; fp32-vs-bf16 itself moves pixels by several 1e-2."""
+    density exponential and the transmittance product; fp32-vs-bf16 itself moves pixels by several 1e-2.
+    ``seeded``: the dense mode is chosen BEFORE the first frame from the mesh's depth complexity (round 4: no first-frame
+    cliff, no frame ever repaired through the BVH); unseeded, it is learned from the first frame's overflow count as in
+    rounds 2-3 -- both must give the same, exact samples."""
     from quadraturefields_amd import synthetic
     from quadraturefields_amd.mesh_utils import MeshIntersection, make_camera
     from quadraturefields_amd.radiance_fields.ngp import NGPRadianceField
@@ -283,11 +287,15 @@ def test_config3_bf16_dense_shell_frame_matches_the_bf16_oracle(device):
     wts = helpers.oracle_ngp_weights(field)
     bf = om.BVHIntersector(mesh.vertices, mesh.faces)
     ri = mi.rayintersector
+    assert ri.depth_complexity > 0.5 * K                    # 10 shells: ~4.7 crossings per ray through the bounding box
+    if not seeded:
+        ri.SEED_WIDE_AT = float("inf")
     seen_wide = False
     for i, c2w in enumerate(synthetic.orbit_cameras(3, seed=8)):
         o, d = synthetic.camera_rays(c2w, focal, w, h)
         rgb, alpha, depth, n = fr.render(o.to(device), d.to(device), camera=make_camera(c2w, focal, w, h))
         seen_wide = seen_wide or ri.raster_wide > K
+        assert (ri.raster_wide > K) == (seeded or i > 0)    # seeded: wide from frame 0; learned: from frame 1
         sample = om.sampling_raytrace_numpy(bf, d.numpy(), o.numpy(), K)
         data = om.to_loader_tensors(sample)
         assert n == data[0].shape[0]
@@ -300,7 +308,8 @@ def test_config3_bf16_dense_shell_frame_matches_the_bf16_oracle(device):
                                              render_bkgd=None, N=w * h)[0]
         assert float((rgb.cpu() - rgb_o).abs().max()) <= 1e-2
         assert psnr(rgb.cpu(), rgb_o) >= 50.0
-    assert seen_wide and ri.repaired_frames >= 1          # the dense-scene policy (wide lists) was exercised
+    assert seen_wide                                        # the dense-scene policy (wide lists) was exercised
+    assert (ri.repaired_frames >= 1) == (not seeded)       # ... and only the learned route pays a repaired first frame
 
 
 def test_config5_baked_render_at_full_texture_size(device):
