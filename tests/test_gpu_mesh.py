@@ -719,7 +719,7 @@ def test_frame_offsets_equal_a_cumsum(device):
             tiles = torch.empty((((w + 7) // 8) * ((h + 7) // 8),), dtype=torch.int64, device=device)
         _C.check(_C.lib().qf_frame_offsets(_C.ptr(cnt), n, k, w, n // w if w else 0, _C.ptr(buf), _C.ptr(tiles),
                                            _C.ptr(temp), temp.numel(), _C.ptr(ovf), _C.ptr(flag),
-                                           ctypes.c_void_p(host.data_ptr()), _C.stream()), "qf_frame_offsets")
+                                           ctypes.c_void_p(host.data_ptr()), 0, _C.stream()), "qf_frame_offsets")
         torch.cuda.synchronize()
         c = cnt.clamp(max=k).long()
         want = torch.cumsum(c, 0) - c
