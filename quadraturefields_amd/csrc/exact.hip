@@ -743,15 +743,15 @@ __device__ __forceinline__ void camera_rays_check(const uint32_t *__restrict__ o
     for (int64_t r = first; r < n_rays; r += stride) {
         const uint32_t o0 = o_bits[r * 3], o1 = o_bits[r * 3 + 1], o2 = o_bits[r * 3 + 2];
         const float dx = rays_d[r * 3], dy = rays_d[r * 3 + 1], dz = rays_d[r * 3 + 2];
-        bad |= (o0 != c0) | (o1 != c1) | (o2 != c2);
+        bad = bad || o0 != c0 || o1 != c1 || o2 != c2;
         const float xc = cam.r00 * dx + cam.r10 * dy + cam.r20 * dz;    // R^T d, as tri_setup projects R^T (v - c)
         const float yc = cam.r01 * dx + cam.r11 * dy + cam.r21 * dz;
         const float zv = -(cam.r02 * dx + cam.r12 * dy + cam.r22 * dz);
         const float sx = cam.fx * (xc / zv) + cam.px0, sy = -cam.fy * (yc / zv) + cam.py0;
         const float px = (float)(int)(r % cam.w), py = (float)(int)(r / cam.w);
         // (negated comparisons: a NaN anywhere counts as a violation)
-        bad |= !(zv > 0.0f) | !(fabsf(sx - px) <= kRayPixelTol) | !(fabsf(sy - py) <= kRayPixelTol);
-        bad |= !(fabsf(dx * dx + dy * dy + dz * dz - 1.0f) <= kRayUnitTol);
+        bad = bad || !(zv > 0.0f) || !(fabsf(sx - px) <= kRayPixelTol) || !(fabsf(sy - py) <= kRayPixelTol) ||
+              !(fabsf(dx * dx + dy * dy + dz * dz - 1.0f) <= kRayUnitTol);
     }
     if (bad) *flag = 1;
 }

@@ -293,9 +293,10 @@ def test_config3_bf16_dense_shell_frame_matches_the_bf16_oracle(device, seeded):
     seen_wide = False
     for i, c2w in enumerate(synthetic.orbit_cameras(3, seed=8)):
         o, d = synthetic.camera_rays(c2w, focal, w, h)
-        rgb, alpha, depth, n = fr.render(o.to(device), d.to(device), camera=make_camera(c2w, focal, w, h))
+        ri._seed_policy(K)
+        assert (ri.raster_wide > K) == (seeded or i > 0)    # the mode frame i runs in: seeded -> wide from frame 0 on;
+        rgb, alpha, depth, n = fr.render(o.to(device), d.to(device), camera=make_camera(c2w, focal, w, h))     # learned -> from frame 1
         seen_wide = seen_wide or ri.raster_wide > K
-        assert (ri.raster_wide > K) == (seeded or i > 0)    # seeded: wide from frame 0; learned: from frame 1
         sample = om.sampling_raytrace_numpy(bf, d.numpy(), o.numpy(), K)
         data = om.to_loader_tensors(sample)
         assert n == data[0].shape[0]

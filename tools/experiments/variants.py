@@ -1,0 +1,128 @@
+"""Experiment builds of libqf_hip.so (round 4): textual variants of ONE csrc file each, compiled beside the package.
+
+    python tools/experiments/variants.py NAME [NAME ...]      # builds tools/experiments/_build/libqf_NAME.so
+    python tools/experiments/variants.py --list
+
+A variant = (source file, [(anchor text, replacement text[, occurrences, which]), ...], extra hipcc flags).  The anchor
+must occur exactly once (or `occurrences` times) in the product source (asserted: a variant that no longer applies fails loudly instead of silently measuring the
+product kernel); the patched copy is compiled, the other objects are the product build's (csrc/_obj), misc.cpp is
+rebuilt with the experiment ABI offset (+1000), so the library only loads with QF_HIP_LIBRARY_EXPERIMENT=1 and can never
+be mistaken for -- or left behind as -- the product library.  hipcc cross-compiles gfx950 in the build container; the
+.so travels to the GPU box with gpurun (git-ignored).  The PRODUCT sources are never touched.
+
+Experiment kernels may return garbage VALUES; only their timing and counters mean anything.
+"""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+CSRC = os.path.join(ROOT, "quadraturefields_amd", "csrc")
+OUT = os.path.join(ROOT, "tools", "experiments", "_build")
+FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
+         "-Wall", "-Wno-unused-function", "-Wno-unused-variable", "-Wno-unused-but-set-variable"]
+EXTRA = {"exact.hip": ["-ffp-contract=off"]}
+
+# ----------------------------------------------------------------------------------------------------------------------
+# field_kernel: where does its 1.32 ms go?  
+_NO_MLP = ("        // ---- base MLP 32 -> 64 (ReLU) -> 16\n", """        // EXPERIMENT no_mlp: the gathers and the blend stay live (every lane's eight features reach an output through two
+        // cross-quartet adds), the whole MFMA chain and the heads are gone
+        {
+            float s_ = ((feat[0] + feat[1]) + (feat[2] + feat[3])) + ((feat[4] + feat[5]) + (feat[6] + feat[7]));
+            s_ += __shfl_xor(s_, 16, 64);
+            s_ += __shfl_xor(s_, 32, 64);
+            if (HEAD == QF_HEAD_NGP || HEAD == QF_HEAD_SG) s_ += a.dirs[pt * 3 + 0] + a.dirs[pt * 3 + 1] + a.dirs[pt * 3 + 2];
+            if (g == 0 && valid) {
+                if (a.sigma) a.sigma[pt] = selector ? s_ : 0.0f;
+                if (a.rgb) { a.rgb[pt * 3 + 0] = s_; a.rgb[pt * 3 + 1] = s_; a.rgb[pt * 3 + 2] = s_; }
+            }
+            continue;
+        }
+        // ---- base MLP 32 -> 64 (ReLU) -> 16
+""")
+_NO_GATHER = ("            for (int c = 0; c < 8; ++c) val[j][c] = a.table[idx[c]];\n",
+              "            // EXPERIMENT no_gather: the index arithmetic stays live, the table is never read\n"
+              "            for (int c = 0; c < 8; ++c) val[j][c] = make_float2((float)(idx[c] & 1023u) * 1e-3f, frac[j][c % 3]);\n",
+              2, 0)            # the line occurs in field_kernel (first) and in deform_kernel: field_kernel's
+
+# ----------------------------------------------------------------------------------------------------------------------
+# bvh8_traverse_kernel: what is a ray's traversal made of?  
+_TRAV_STATS_DECL = ("struct TravArgs {\n", """// EXPERIMENT trav_stats: [0] rays, [1] node steps (per octet), [2] leaf steps (per octet), [3] triangles tested,
+// [4] node steps (per WAVE: iterations of the node loop with at least one octet in it), [5] leaf steps per wave,
+// [6] pages beyond the first, [7] hits accepted into a list
+__device__ unsigned long long qf_trav_stats[8];
+extern "C" int qf_trav_stats_read(unsigned long long *out, int reset)
+{
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(qf_trav_stats), sizeof(qf_trav_stats)) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(qf_trav_stats), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#define QF_STAT_OCT(k, v) do { if (j == 0) atomicAdd(&qf_trav_stats[k], (unsigned long long)(v)); } while (0)
+#define QF_STAT_WAVE(k) do { if ((int)(threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1) atomicAdd(&qf_trav_stats[k], 1ull); } while (0)
+struct TravArgs {
+""")
+_TRAV_STATS_RAY = ("    for (int page = 0; page < kMaxPages; ++page) {\n        list.count = 0;\n",
+                   "    QF_STAT_OCT(0, 1);\n    for (int page = 0; page < kMaxPages; ++page) {\n        if (page) QF_STAT_OCT(6, 1);\n        list.count = 0;\n")
+_TRAV_STATS_NODE = ("                const float4 *np = nodes + (size_t)cur * 16 + j * 2;\n",
+                    "                QF_STAT_OCT(1, 1); QF_STAT_WAVE(4);\n                const float4 *np = nodes + (size_t)cur * 16 + j * 2;\n")
+_TRAV_STATS_LEAF = ("                const int first = packed >> 3, cnt = (packed & 7) + 1;\n                bool h = false;\n",
+                    "                const int first = packed >> 3, cnt = (packed & 7) + 1;\n                QF_STAT_OCT(2, 1); QF_STAT_OCT(3, cnt); QF_STAT_WAVE(5);\n                bool h = false;\n")
+_TRAV_STATS_HIT = ("                if (m8) {\n                    const int n = __popc(m8);\n                    if (list.count + n <= Kc) {\n",
+                   "                if (m8) {\n                    const int n = __popc(m8);\n                    QF_STAT_OCT(7, n);\n                    if (list.count + n <= Kc) {\n")
+
+VARIANTS = {
+    "no_mlp": ("field_eval.hip", [_NO_MLP], []),
+    "no_gather": ("field_eval.hip", [_NO_GATHER], []),
+    "trav_stats": ("exact.hip", [_TRAV_STATS_DECL, _TRAV_STATS_RAY, _TRAV_STATS_NODE, _TRAV_STATS_LEAF, _TRAV_STATS_HIT], []),
+}
+
+
+def _run(cmd):
+    p = subprocess.run(cmd, capture_output=True, text=True)
+    if p.returncode != 0:
+        raise SystemExit("failed: %s\n%s" % (" ".join(cmd), p.stderr))
+    if p.stderr.strip():
+        sys.stderr.write(p.stderr)
+
+
+def build(name):
+    src, edits, flags = VARIANTS[name]
+    sys.path.insert(0, ROOT)
+    from quadraturefields_amd import build as product
+    product.build()                                     # the product objects (csrc/_obj), up to date
+    os.makedirs(OUT, exist_ok=True)
+    text = open(os.path.join(CSRC, src)).read()
+    for edit in edits:
+        anchor, repl = edit[0], edit[1]
+        expect, which = (edit[2], edit[3]) if len(edit) == 4 else (1, 0)       # (occurrences expected, the one to replace)
+        if text.count(anchor) != expect:
+            raise SystemExit(f"variant {name}: anchor occurs {text.count(anchor)} times in {src} (expected {expect}):\n{anchor}")
+        at = -1
+        for _ in range(which + 1):
+            at = text.index(anchor, at + 1)
+        text = text[:at] + repl + text[at + len(anchor):]
+    patched = os.path.join(OUT, f"{name}_{src}")
+    open(patched, "w").write(text)
+    stem = os.path.splitext(src)[0]
+    obj = os.path.join(OUT, f"{name}_{stem}.o")
+    hipcc = "/opt/rocm/bin/hipcc"
+    _run([hipcc] + FLAGS + EXTRA.get(src, []) + flags + ["-x", "hip", "-c", patched, "-o", obj])
+    misc = os.path.join(OUT, "misc_exp.o")
+    _run([hipcc] + FLAGS + ["-DQF_ABI_VERSION_OFFSET=1000", "-x", "hip", "-c", os.path.join(CSRC, "misc.cpp"), "-o", misc])
+    others = [os.path.join(product.OBJ_DIR, f) for f in sorted(os.listdir(product.OBJ_DIR))
+              if f.endswith(".o") and f not in (stem + ".o", "misc.o")]
+    lib = os.path.join(OUT, f"libqf_{name}.so")
+    _run([hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", lib, obj, misc] + others)
+    print("built", lib)
+    return lib
+
+
+if __name__ == "__main__":
+    if "--list" in sys.argv or len(sys.argv) < 2:
+        print("\n".join(VARIANTS))
+    else:
+        for n in sys.argv[1:]:
+            build(n)
