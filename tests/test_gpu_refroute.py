@@ -162,6 +162,20 @@ def test_mesh_update_d_matches_index_add(device):
     assert torch.equal(mf.cache_d, before) and torch.allclose(mf.cache_w, cw + (cw - 1e-8), rtol=1e-5)
     mf.reset_d()
     assert float(mf.cache_d.abs().max()) == 0.0
+    # a batch too small for the chunk-merging kernel takes the plain one: same sums
+    m = 3000
+    mf.update_d(d[:m], wgt[:m], tri[:m])
+    cd_s = torch.zeros(n_f, 3, device=device).index_add_(0, tri[:m], (d * wgt[:, None])[:m])
+    cw_s = (torch.ones(n_f, device=device) * 1e-8).index_add_(0, tri[:m], wgt[:m])
+    assert torch.allclose(mf.cache_d, cd_s, atol=1e-5) and torch.allclose(mf.cache_w, cw_s, rtol=1e-5)
+    # heavy duplication inside a chunk (what a frame's samples look like: x-neighbours share triangles) -- merged in LDS
+    few = torch.randint(0, 7, (n,), generator=g).to(device)
+    mf.reset_d()
+    mf.update_d(d, wgt, few)
+    cd_f = torch.zeros(n_f, 3, device=device).index_add_(0, few, d * wgt[:, None])
+    cw_f = (torch.ones(n_f, device=device) * 1e-8).index_add_(0, few, wgt)
+    assert torch.allclose(mf.cache_d, cd_f, rtol=1e-4, atol=1e-4) and torch.allclose(mf.cache_w, cw_f, rtol=1e-4)
+    mf.reset_d()
     # ids outside the mesh (the reference's scatter_add raises on them): skipped, counted, and raised by the next
     # update_faces / check_ids -- not silently dropped
     mf.check_ids()
