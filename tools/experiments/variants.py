@@ -73,7 +73,50 @@ _TRAV_STATS_LEAF = ("                const int first = packed >> 3, cnt = (packe
 _TRAV_STATS_HIT = ("                if (m8) {\n                    const int n = __popc(m8);\n                    if (list.count + n <= Kc) {\n",
                    "                if (m8) {\n                    const int n = __popc(m8);\n                    QF_STAT_OCT(7, n);\n                    if (list.count + n <= Kc) {\n")
 
+# ----------------------------------------------------------------------------------------------------------------------
+# texture_shade_packed_kernel: record stride / order and the LDS code tables
+_TEX_DECL = ("constexpr int kTexelRecord = QF_TEXEL_RECORD_BYTES;\n", """constexpr int kTexelRecord = QF_TEXEL_RECORD_BYTES;
+// EXPERIMENT: where texel px = y * size + x lives in the record array
+__device__ __forceinline__ int64_t exp_rec_off(int64_t px, int size)
+{
+#if defined(QF_EXP_TEX_TILED) || defined(QF_EXP_TEX_MORTON)
+    const int y = (int)(px / size), x = (int)(px - (int64_t)y * size);
+#if defined(QF_EXP_TEX_MORTON)
+    const int xi = x & 7, yi = y & 7;
+    const int in = (xi & 1) | ((yi & 1) << 1) | ((xi & 2) << 1) | ((yi & 2) << 2) | ((xi & 4) << 2) | ((yi & 4) << 3);
+#else
+    const int in = (y & 7) * 8 + (x & 7);
+#endif
+    px = ((int64_t)(y >> 3) * (size >> 3) + (x >> 3)) * 64 + in;
+#endif
+    return px * QF_EXP_TEX_STRIDE;
+}
+""")
+_TEX_PACK_DST = ("        uint4 *dst = reinterpret_cast<uint4 *>(records + px * kTexelRecord);\n",
+                 "        uint4 *dst = reinterpret_cast<uint4 *>(records + exp_rec_off(px, t.size));\n")
+_TEX_PACK_N = ("        for (int k = 0; k < kTexelRecord / 16; ++k) dst[k] = rec.q[k];\n",
+               "        for (int k = 0; k < QF_EXP_TEX_STRIDE / 16; ++k) dst[k] = rec.q[k];\n")
+_TEX_SHADE_SRC = ("        const uint4 *src = reinterpret_cast<const uint4 *>(records + px * kTexelRecord);\n",
+                  "        const uint4 *src = reinterpret_cast<const uint4 *>(records + exp_rec_off(px, size));\n")
+_TEX = [_TEX_DECL, _TEX_PACK_DST, _TEX_PACK_N, _TEX_SHADE_SRC]
+
+# (cos, sin) of the azimuth code and (sin, cos) of the elevation code as ONE 8-byte LDS read each (ds_read_b64: 64 banks)
+_TEX_LDS_DECL = ("    __shared__ float s_sigma[256], s_col[256], s_caz[256], s_saz[256], s_sel[256], s_cel[256], s_lam[256];\n",
+                 "    __shared__ float s_sigma[256], s_col[256], s_lam[256];\n    __shared__ float2 s_az[256], s_el[256];\n")
+_TEX_LDS_FILL = ("        s_caz[c] = cosf(az);\n        s_saz[c] = sinf(az);\n        s_sel[c] = sinf(el);\n        s_cel[c] = cosf(el);\n",
+                 "        s_az[c] = make_float2(cosf(az), sinf(az));\n        s_el[c] = make_float2(sinf(el), cosf(el));\n")
+_TEX_LDS_USE = ("                const float se = s_sel[c_el];\n                const float x0 = s_caz[c_az] * se, x1 = s_saz[c_az] * se, x2 = s_cel[c_el];\n",
+                "                const float2 az2 = s_az[c_az], el2 = s_el[c_el];\n                const float se = el2.x;\n"
+                "                const float x0 = az2.x * se, x1 = az2.y * se, x2 = el2.y;\n")
+_TEX_LDS = [_TEX_LDS_DECL, _TEX_LDS_FILL, _TEX_LDS_USE]
+
 VARIANTS = {
+    "tex_stride48": ("exact.hip", _TEX, ["-DQF_EXP_TEX_STRIDE=48"]),
+    "tex_tiled64": ("exact.hip", _TEX, ["-DQF_EXP_TEX_STRIDE=64", "-DQF_EXP_TEX_TILED"]),
+    "tex_tiled48": ("exact.hip", _TEX, ["-DQF_EXP_TEX_STRIDE=48", "-DQF_EXP_TEX_TILED"]),
+    "tex_morton48": ("exact.hip", _TEX, ["-DQF_EXP_TEX_STRIDE=48", "-DQF_EXP_TEX_MORTON"]),
+    "tex_ldspair": ("exact.hip", _TEX_LDS, []),
+    "tex_ldspair_tiled48": ("exact.hip", _TEX + _TEX_LDS, ["-DQF_EXP_TEX_STRIDE=48", "-DQF_EXP_TEX_TILED"]),
     "no_mlp": ("field_eval.hip", [_NO_MLP], []),
     "no_gather": ("field_eval.hip", [_NO_GATHER], []),
     "trav_stats": ("exact.hip", [_TRAV_STATS_DECL, _TRAV_STATS_RAY, _TRAV_STATS_NODE, _TRAV_STATS_LEAF, _TRAV_STATS_HIT], []),
