@@ -324,17 +324,8 @@ __device__ __forceinline__ void oct_traverse_ray(const TravArgs &ta, int64_t ray
                     continue;
                 }
                 const int n = __popc(m8);
-                // Which hit child next?  Front to back only matters once the K-list is full (t_limit prunes the boxes
-                // behind the K-th hit): until then every hit child is visited whatever the order, and the first set bit
-                // of the mask replaces the octet-wide DPP minimum (round 4: the lists of the Lego-like scenes never
-                // fill -- 6 hits per ray against K = 25 -- and the chain was a fifth of a node step's instructions).
-                int nearest;
-                if (t_limit == INFINITY) {
-                    nearest = __ffs(m8) - 1;
-                } else {
-                    const unsigned key = hit ? ((__float_as_uint(tn) & ~7u) | (unsigned)j) : 0xffffffffu;
-                    nearest = (int)(oct_min_u32(key) & 7u);
-                }
+                const unsigned key = hit ? ((__float_as_uint(tn) & ~7u) | (unsigned)j) : 0xffffffffu;
+                const int nearest = (int)(oct_min_u32(key) & 7u);
                 if (hit && j != nearest) {
                     const unsigned others = m8 & ~(1u << nearest);
                     stack[sp + __popc(others & ((1u << j) - 1u))] = tok;

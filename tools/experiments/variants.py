@@ -110,7 +110,51 @@ _TEX_LDS_USE = ("                const float se = s_sel[c_el];\n                
                 "                const float x0 = az2.x * se, x1 = az2.y * se, x2 = el2.y;\n")
 _TEX_LDS = [_TEX_LDS_DECL, _TEX_LDS_FILL, _TEX_LDS_USE]
 
+# ----------------------------------------------------------------------------------------------------------------------
+# field_kernel_bf16 (configs[2]): the same two stubs, and the x-neighbour pair of a cell as ONE 8-byte request when its two
+# rows are adjacent
+_B_NO_MLP = ("        // ---- base MLP\n", """        // EXPERIMENT bf16_no_mlp
+        {
+            float s_ = ((feat[0] + feat[1]) + (feat[2] + feat[3])) + ((feat[4] + feat[5]) + (feat[6] + feat[7]));
+            s_ += __shfl_xor(s_, 16, 64);
+            s_ += __shfl_xor(s_, 32, 64);
+            if (HEAD == QF_HEAD_NGP || HEAD == QF_HEAD_SG) s_ += a.dirs[pt * 3 + 0] + a.dirs[pt * 3 + 1] + a.dirs[pt * 3 + 2];
+            if (g == 0 && valid) {
+                if (a.sigma) a.sigma[pt] = selector ? s_ : 0.0f;
+                if (a.rgb) { a.rgb[pt * 3 + 0] = s_; a.rgb[pt * 3 + 1] = s_; a.rgb[pt * 3 + 2] = s_; }
+            }
+            continue;
+        }
+        // ---- base MLP
+""")
+_B_GATHER = "            for (int c = 0; c < 8; ++c) raw[j][c] = a.table[idx[c]];\n"
+_B_NO_GATHER = (_B_GATHER, "            for (int c = 0; c < 8; ++c) raw[j][c] = (idx[c] & 1023u) << 20;      // EXPERIMENT bf16_no_gather\n")
+_B_XPAIR = (_B_GATHER, """            // EXPERIMENT bf16_xpair: corners c, c+1 are the cell's x-neighbours; adjacent rows (always on a dense level,
+            // for even cx on a hashed one) come with one unaligned 8-byte load
+            for (int c = 0; c < 8; c += 2) {
+                typedef uint32_t u32x2u_ __attribute__((ext_vector_type(2), aligned(4)));
+                const uint32_t i0 = idx[c], i1 = idx[c + 1];
+                const uint32_t lo = i0 < i1 ? i0 : i1, hi = i0 < i1 ? i1 : i0;
+                const bool adj = hi - lo == 1u;
+                u32x2u_ v = {0u, 0u};
+                uint32_t s0 = 0u, s1 = 0u;
+                if (adj) v = *reinterpret_cast<const u32x2u_ *>(a.table + lo);
+                else { s0 = a.table[i0]; s1 = a.table[i1]; }
+                raw[j][c] = adj ? (i0 < i1 ? v.x : v.y) : s0;
+                raw[j][c + 1] = adj ? (i0 < i1 ? v.y : v.x) : s1;
+            }
+""")
+
+# bvh8_traverse_kernel: any hit child next instead of the nearest (no DPP minimum): what is front-to-back order worth?
+_TRAV_UNORDERED = ("                const unsigned key = hit ? ((__float_as_uint(tn) & ~7u) | (unsigned)j) : 0xffffffffu;\n"
+                   "                const int nearest = (int)(oct_min_u32(key) & 7u);\n",
+                   "                const int nearest = __ffs(m8) - 1;      // EXPERIMENT trav_unordered\n")
+
 VARIANTS = {
+    "trav_unordered": ("exact.hip", [_TRAV_UNORDERED], []),
+    "bf16_no_mlp": ("field_eval_bf16.hip", [_B_NO_MLP], []),
+    "bf16_no_gather": ("field_eval_bf16.hip", [_B_NO_GATHER], []),
+    "bf16_xpair": ("field_eval_bf16.hip", [_B_XPAIR], []),
     "tex_stride48": ("exact.hip", _TEX, ["-DQF_EXP_TEX_STRIDE=48"]),
     "tex_tiled64": ("exact.hip", _TEX, ["-DQF_EXP_TEX_STRIDE=64", "-DQF_EXP_TEX_TILED"]),
     "tex_tiled48": ("exact.hip", _TEX, ["-DQF_EXP_TEX_STRIDE=48", "-DQF_EXP_TEX_TILED"]),

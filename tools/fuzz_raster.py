@@ -70,6 +70,10 @@ def main():
             compared += 1
             continue
         tri_r, t_r, cnt_r, ovf = ri._hits_raster(o, d, 25, cam)
+        if int(ri._raster_words[1].item()):     # the pass's ray check (camera_rays_check) on rays that ARE this camera's grid
+            print(f"GUARD FALSE POSITIVE case {case}: mesh {key} image {w}x{h} focal {focal:.1f} / {cam.fy:.1f} "
+                  f"principal ({cam.cx:.1f}, {cam.cy:.1f})")
+            sys.exit(1)
         if int(ovf.item()):
             skipped += 1
             continue
