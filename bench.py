@@ -316,11 +316,12 @@ def config3_line(device, steps=5, warm=4):
 
 
 def config5_line(device, scene, steps=8, warm=3, texture_size=4096, lobes=6):
-    """BASELINE configs[4]: render from the baked SG textures (4096^2 uint8 texture set, L = 6) through
-    render_image_bake_texture_images_with_occgrid on the bench mesh and cameras."""
+    """BASELINE configs[4]: render from the baked SG textures (4096^2 uint8 texture set, L = 6) through the frame path on
+    the bench mesh and cameras -- on the mesh's own atlas (one contiguous (azimuth, elevation) chart per shell: what an
+    xatlas output looks like; the line's top-level numbers, as in rounds 2-3) and on SURVEY.md 8(d)'s random per-triangle
+    charts (no texel locality at all between neighbouring triangles: the worst case), both in ``uv_sets``."""
     from quadraturefields_amd import synthetic
-    from quadraturefields_amd.mesh_utils import make_camera
-    from quadraturefields_amd.render import FrameRenderer
+    from quadraturefields_amd.mesh_utils import MeshIntersection
     from quadraturefields_amd.texture_utils import FeatureCompression
     mesh, mi, field = scene
     tex = synthetic.random_textures(texture_size, lobes, seed=42)
@@ -328,6 +329,31 @@ def config5_line(device, scene, steps=8, warm=3, texture_size=4096, lobes=6):
                                           compression_type="sigmoid", lambda_thres=7.5, device=device)
     del tex
     uv = torch.from_numpy(synthetic.scaled_uv(mesh, texture_size)).to(device)
+    line = _config5_uv_set(device, mi, uv, comp, steps, warm, texture_size, lobes)
+    charted = {k: line[k] for k in ("ms_per_frame", "rays_per_s", "quadrature_points_per_frame")}
+    charted["shade_ms"] = line["roofline"]["avg_launch_ms"]
+    charted["roofline_frac"] = line["roofline"]["frac"]
+    charted["what"] = "one contiguous (azimuth, elevation) chart per shell in a 4 x 3 atlas (synthetic.shell_mesh)"
+    # the same triangles with their vertices unshared, every triangle its own 4-texel chart at a random place
+    mesh_r, uv_r = synthetic.per_triangle_charts(mesh, texture_size, seed=42)
+    mi_r = MeshIntersection(mesh_r, simplify_mesh=False, scale=1.0, num_intersections=MAX_HITS, render_step_size=STEP,
+                            device=device)
+    rnd = _config5_uv_set(device, mi_r, torch.from_numpy(uv_r).to(device), comp, steps, warm, texture_size, lobes)
+    del mi_r
+    line["uv_sets"] = {
+        "charted": charted,
+        "per_triangle_random": {"ms_per_frame": rnd["ms_per_frame"], "rays_per_s": rnd["rays_per_s"],
+                                "quadrature_points_per_frame": rnd["quadrature_points_per_frame"],
+                                "shade_ms": rnd["roofline"]["avg_launch_ms"], "roofline_frac": rnd["roofline"]["frac"],
+                                "what": "SURVEY.md 8(d): a 4-texel chart per triangle at a uniformly random place of the "
+                                        "atlas (synthetic.per_triangle_charts; vertices unshared)"}}
+    return line
+
+
+def _config5_uv_set(device, mi, uv, comp, steps, warm, texture_size, lobes):
+    from quadraturefields_amd import synthetic
+    from quadraturefields_amd.mesh_utils import make_camera
+    from quadraturefields_amd.render import FrameRenderer
     from quadraturefields_amd.radiance_fields.ngp import NGPRadianceFieldSGNew
     sg = NGPRadianceFieldSGNew(aabb=[-1.5] * 3 + [1.5] * 3, use_viewdirs=False, num_g_lobes=lobes,
                                log2_hashmap_size=14).to(device)          # only features_to_rgb's owner (B-17)
@@ -379,7 +405,8 @@ def config5_line(device, scene, steps=8, warm=3, texture_size=4096, lobes=6):
                      "points_per_launch": ppl, "avg_launch_ms": shade_ms,
                      "note": "one 64-B texel record + position, triangle id and direction per sample (the 128-B triangle "
                              "records are shared by neighbouring samples); the gather of isolated 64-B sectors out of a "
-                             "1.07 GB record array is request-bound, not byte-bound"},
+                             "1.07 GB record array is request-bound, not byte-bound: 79 % of the measured HBM sector-gather "
+                             "rate (profiles/r4/texture_variants.md)"},
     }
 
 
@@ -877,6 +904,8 @@ def main():
             "bvh_fallback_frames": getattr(stages, "fallbacks", 0),
             "overflow_repaired_frames": mi.rayintersector.repaired_frames,
             "reorigin_rule_redone_frames": mi.rayintersector.rule_redone_frames,
+            "camera_mismatch_frames": mi.rayintersector.camera_mismatch_frames,     # frames the pass's ray check sent to the BVH
+            "mesh_depth_complexity": mi.rayintersector.depth_complexity,
             "frames_in_flight": args.pipeline,
             "host_wait_per_frame": not nowait,
             "parallelism": f"{world} rank(s), the frames dealt round-robin to the ranks, one frame per rank per step"

@@ -53,6 +53,10 @@ struct qf_bvh {
     int32_t max_stack8 = 1;          // exact bound of the wide traversal's per-ray stack for this tree
     float eps = 0.f;                 // box inflation (absolute), fixed at build time
     float min_sep = 0.f;             // > 0: the trimesh/Embree re-origin rule (qf_bvh_set_min_separation)
+    // mean crossings of a random line through the mesh's bounding box, 2 area(mesh) / area(box) (Cauchy-Crofton), from
+    // the build-time vertices: with fewer than max_hits / 2 the K-lists (almost) never fill and the general traversal
+    // visits the hit children in ANY order (exact.hip, bvh_launch)
+    float depth_complexity = 0.f;
     std::vector<float> h_nodes;      // binary tree (build, host refit, inspection)
     std::vector<float> h_nodes8;     // wide tree mirror
     std::vector<int32_t> level_start8;   // [levels + 1]

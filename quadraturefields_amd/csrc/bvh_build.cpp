@@ -467,6 +467,20 @@ extern "C" int qf_bvh_create_ex(const float *tri_verts, int64_t n_tri, int32_t s
     qf_bvh *bvh = new (std::nothrow) qf_bvh();
     if (!bvh) return QF_ERR_INVALID_ARGUMENT;
     build_host(bvh, tri_verts, n_tri, sah_depth);
+    {   // depth complexity (see bvh.h): triangle areas and the bounding box in double
+        double area = 0.0, lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+        for (int64_t t = 0; t < n_tri; ++t) {
+            const float *v = tri_verts + 9 * (size_t)t;
+            const double e1[3] = {(double)v[3] - v[0], (double)v[4] - v[1], (double)v[5] - v[2]};
+            const double e2[3] = {(double)v[6] - v[0], (double)v[7] - v[1], (double)v[8] - v[2]};
+            const double cx = e1[1] * e2[2] - e1[2] * e2[1], cy = e1[2] * e2[0] - e1[0] * e2[2], cz = e1[0] * e2[1] - e1[1] * e2[0];
+            area += 0.5 * std::sqrt(cx * cx + cy * cy + cz * cz);
+            for (int k = 0; k < 9; ++k) { lo[k % 3] = std::min(lo[k % 3], (double)v[k]); hi[k % 3] = std::max(hi[k % 3], (double)v[k]); }
+        }
+        const double ex = hi[0] - lo[0], ey = hi[1] - lo[1], ez = hi[2] - lo[2];
+        const double box = n_tri > 0 ? 2.0 * (ex * ey + ey * ez + ex * ez) : 0.0;
+        bvh->depth_complexity = box > 0.0 ? (float)(2.0 * area / box) : 0.f;
+    }
     if (bvh->max_depth > QF_BVH_MAX_DEPTH) { qf_bvh_destroy(bvh); return QF_ERR_UNSUPPORTED; }   // cannot happen, see bvh.h
     int rc = collapse8(bvh);
     if (rc == QF_OK) rc = upload(bvh, tri_verts);

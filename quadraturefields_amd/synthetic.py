@@ -161,3 +161,21 @@ def scaled_uv(mesh: TriMesh, texture_size: int) -> np.ndarray:
     uv = mesh.visual.uv - 1e-7
     uv = np.array(uv).astype(np.float32) * texture_size
     return np.clip(uv, 0, texture_size - 1)
+
+
+def per_triangle_charts(mesh: TriMesh, texture_size: int, seed: int = 42, texels: float = 4.0):
+    """SURVEY.md 8d's OTHER UV set for configs[4]: random per-triangle charts -- every triangle gets its own little
+    right-angled chart (legs of ``texels`` texels) at a uniformly random place of the atlas, so neighbouring triangles
+    share NO texel locality (the worst case for the texture fetch; the (azimuth, elevation) charts ``shell_mesh`` gives its
+    shells are the contiguous-chart case, what an xatlas output looks like).  Per-vertex UVs cannot say that with shared
+    vertices, so the mesh comes back with its vertices unshared (3 per face, ``faces = arange``): same triangles, same
+    triangle ids.  Returns (mesh, uv already scaled to texels as ``scaled_uv`` does)."""
+    rng = np.random.default_rng(seed)
+    f = np.asarray(mesh.faces)
+    v = np.asarray(mesh.vertices)[f.reshape(-1)]                       # [3F, 3]
+    faces = np.arange(3 * f.shape[0], dtype=np.int64).reshape(-1, 3)
+    t = float(texture_size)
+    corner = rng.uniform(0.0, t - texels - 1.0, size=(f.shape[0], 2))
+    uv = np.stack([corner, corner + np.array([texels, 0.0]), corner + np.array([0.0, texels])], axis=1).reshape(-1, 2)
+    uv = np.clip(uv.astype(np.float32), 0, texture_size - 1)
+    return TriMesh(v.copy(), faces, uv / t), uv
