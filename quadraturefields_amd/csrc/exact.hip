@@ -474,208 +474,6 @@ __global__ __launch_bounds__(kTravThreads) void bvh8_traverse_kernel(TravArgs a)
     oct_traverse_ray<kOrdered>(a, ray, j, q, oct_base);
 }
 
-// ---- Rays that share nothing (a training batch: random pixels of random cameras, train_finetune.py:296-305).  In the
-// kernel above a wave's eight octets run in lockstep from a common start: measured (profiles/r4/bvh_traversal_stats.md)
-// on 2^17 such rays the octets are busy in 23 % of the node-loop iterations and 41 % of the leaf steps -- the wave runs
-// until its longest ray is done, and eight unrelated rays spend most of that waiting for each other.  Here an octet
-// that finishes its ray FETCHES THE NEXT one from its workgroup's pool (kPoolRays consecutive rays, an LDS counter)
-// and joins the others' current iteration: one loop carries fetch, the node loop (while any octet of the wave stands
-// on a node), one leaf step, and the end-of-page / write-out of the octets whose stack ran empty.  The per-ray
-// arithmetic, the list handling and the paging are oct_traverse_ray's, statement for statement -- the hits are
-// identical (tests/test_gpu_mesh.py compares both kernels with the brute force and with each other).
-constexpr int kPoolRays = 256;       // rays a workgroup's 32 octets share: 8 per octet on average
-
-template <bool kOrdered>
-__global__ __launch_bounds__(kTravThreads) void bvh8_traverse_pool_kernel(TravArgs ta)
-{
-    __shared__ int s_next;
-    const int tid = threadIdx.x, j = tid & 7, q = tid >> 3;
-    const int oct_base = (tid & 63) & 56;
-    const int block = xcd_block(ta);
-    if (block >= ta.n_blocks) return;
-    if (tid == 0) s_next = 0;
-    __syncthreads();
-    const int64_t pool_first = (int64_t)block * kPoolRays;
-    const int pool_n = (int)((ta.n_rays - pool_first) < kPoolRays ? (ta.n_rays - pool_first) : kPoolRays);
-
-    const int K = ta.max_hits, Kc = ta.list_cap;
-    const float min_sep = ta.min_sep;
-    const float4 *__restrict__ nodes = ta.nodes;
-    const float4 *__restrict__ tris = ta.tris;
-    const int stack_cap = ta.stack_cap;
-    uint64_t *keys = trav_lds + (size_t)q * Kc;
-    uint64_t *sorted = trav_lds + (size_t)kOctRays * Kc + (size_t)q * Kc;        // only when min_sep > 0
-    int *stack = reinterpret_cast<int *>(trav_lds + (size_t)kOctRays * Kc * (min_sep > 0.0f ? 2 : 1)) + (size_t)q * stack_cap;
-
-    // the octet's state (octet-uniform: all eight lanes hold the same values)
-    int64_t ray = -1;
-    bool pool_open = true;
-    float ox = 0.f, oy = 0.f, oz = 0.f, dx = 0.f, dy = 0.f, dz = 0.f, ix = 0.f, iy = 0.f, iz = 0.f, nx = 0.f, ny = 0.f, nz = 0.f;
-    OctList list;
-    list.keys = keys; list.K = Kc; list.j = j;
-    list.count = 0; list.worst = ~0ull; list.worst_slot = 0;
-    int kept = 0, sp = 0, cur = kDone, page = 0;
-    float last_t = 0.0f, t_lo = 0.0f, t_accept = 0.0f, t_limit = INFINITY;
-    uint64_t lo_key = 0;
-
-    for (;;) {
-        // ---- an idle octet takes the next ray of the pool
-        if (ray < 0 && pool_open) {
-            int idx = 0;
-            if (j == 0) idx = atomicAdd(&s_next, 1);
-            idx = oct_bcast(idx, oct_base, 0);
-            if (idx < pool_n) {
-                ray = pool_first + idx;
-                ox = ta.rays_o[ray * 3]; oy = ta.rays_o[ray * 3 + 1]; oz = ta.rays_o[ray * 3 + 2];
-                dx = ta.rays_d[ray * 3]; dy = ta.rays_d[ray * 3 + 1]; dz = ta.rays_d[ray * 3 + 2];
-                ix = safe_inv(dx); iy = safe_inv(dy); iz = safe_inv(dz);
-                nx = -(ox * ix); ny = -(oy * iy); nz = -(oz * iz);
-                kept = 0; last_t = 0.0f; lo_key = 0; t_lo = 0.0f; t_accept = 0.0f; page = 0;
-                list.count = 0; list.worst = ~0ull; list.worst_slot = 0;
-                t_limit = INFINITY; sp = 0;
-                cur = ta.root_is_valid ? 0 : kDone;
-            } else {
-                pool_open = false;
-            }
-        }
-        if (__ballot(ray >= 0) == 0ull) break;          // wave-uniform: every octet of the wave is out of rays
-
-        // ---- nodes: while any octet of the wave stands on one
-        while (ray >= 0 && cur >= 0) {
-            const float4 *np = nodes + (size_t)cur * 16 + j * 2;
-            const float4 a = np[0];                 // lo.xyz, hi.x
-            const float4 b = np[1];                 // hi.yz, token, 0
-            const float ax = __builtin_fmaf(a.x, ix, nx), bx = __builtin_fmaf(a.w, ix, nx);
-            const float ay = __builtin_fmaf(a.y, iy, ny), by = __builtin_fmaf(b.x, iy, ny);
-            const float az = __builtin_fmaf(a.z, iz, nz), bz = __builtin_fmaf(b.y, iz, nz);
-            const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
-            const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz)) * 1.0000005f;
-            const int tok = __float_as_int(b.z);
-            const bool hit = tok != kDone && !(tn > tf) && !(tn * 0.999999f > t_limit) && !(tf < t_lo);
-            const unsigned m8 = (unsigned)(__ballot(hit) >> oct_base) & 0xffu;
-            if (m8 == 0) {
-                cur = kDone;
-                if (sp > 0) cur = stack[--sp];
-                continue;
-            }
-            const int n = __popc(m8);
-            int nearest;
-            if (kOrdered) {
-                const unsigned key = hit ? ((__float_as_uint(tn) & ~7u) | (unsigned)j) : 0xffffffffu;
-                nearest = (int)(oct_min_u32(key) & 7u);
-            } else {
-                nearest = __ffs(m8) - 1;
-            }
-            if (hit && j != nearest) {
-                const unsigned others = m8 & ~(1u << nearest);
-                stack[sp + __popc(others & ((1u << j) - 1u))] = tok;
-            }
-            sp += n - 1;
-            cur = oct_bcast(tok, oct_base, nearest);
-            oct_lds_sync();
-        }
-
-        // ---- one leaf step for the octets that stand on a leaf
-        if (ray >= 0 && cur != kDone) {
-            const int packed = ~cur;
-            const int first = packed >> 3, cnt = (packed & 7) + 1;
-            bool h = false;
-            uint64_t key = 0;
-            if (j < cnt) {
-                const float4 a = tris[(size_t)(first + j) * 3 + 0];
-                const float4 b = tris[(size_t)(first + j) * 3 + 1];
-                const float4 c = tris[(size_t)(first + j) * 3 + 2];
-                float t;
-                if (mt_hit(a, b, c, ox, oy, oz, dx, dy, dz, &t)) {
-                    key = hit_key(t, __float_as_int(a.w));
-                    h = key > lo_key && t > t_accept && key < list.worst;
-                }
-            }
-            const unsigned m8 = (unsigned)(__ballot(h) >> oct_base) & 0xffu;
-            if (m8) {
-                const int n = __popc(m8);
-                if (list.count + n <= Kc) {
-                    if (h) keys[list.count + __popc(m8 & ((1u << j) - 1u))] = key;
-                    list.count += n;
-                    oct_lds_sync();
-                    if (list.count == Kc) list.find_worst();
-                } else {                                    // the list fills up or is full: one hit at a time
-                    for (unsigned mm = m8; mm; mm &= mm - 1u) {
-                        const int src = __ffs(mm) - 1;
-                        const uint64_t k = ((uint64_t)(unsigned)oct_bcast((int)(unsigned)(key >> 32), oct_base, src) << 32) |
-                                           (unsigned)oct_bcast((int)(unsigned)key, oct_base, src);
-                        if (list.count < Kc) {
-                            if (j == 0) keys[list.count] = k;
-                            ++list.count;
-                            oct_lds_sync();
-                            if (list.count == Kc) list.find_worst();
-                        } else if (k < list.worst) {
-                            if (j == 0) keys[list.worst_slot] = k;
-                            oct_lds_sync();
-                            list.find_worst();
-                        }
-                    }
-                }
-                if (list.count == Kc) t_limit = key_t(list.worst);
-            }
-            cur = kDone;
-            if (sp > 0) cur = stack[--sp];
-        }
-
-        // ---- the stack ran empty: the page is complete -- write it out, or start the next page (re-origin rule)
-        if (ray >= 0 && cur == kDone) {
-            float *my_t = ta.hit_t + ray * K;
-            int32_t *my_tri = ta.hit_tri + ray * K;
-            const int count = list.count;
-            bool done;
-            if (!(min_sep > 0.0f)) {
-                for (int e = j; e < count; e += 8) {
-                    const uint64_t k = keys[e];
-                    int rank = 0;
-                    for (int i = 0; i < count; ++i) rank += keys[i] < k ? 1 : 0;
-                    my_t[rank] = key_t(k);
-                    my_tri[rank] = key_id(k);
-                }
-                kept = count;
-                done = true;
-            } else {
-                for (int e = j; e < count; e += 8) {
-                    const uint64_t k = keys[e];
-                    int rank = 0;
-                    for (int i = 0; i < count; ++i) rank += keys[i] < k ? 1 : 0;
-                    sorted[rank] = k;
-                }
-                oct_lds_sync();
-                for (int i = 0; i < count && kept < K; ++i) {       // the re-origin chain, front to back
-                    const uint64_t k = sorted[i];
-                    const float t = key_t(k);
-                    if (kept == 0 || t > last_t + min_sep) {
-                        if (j == 0) { my_t[kept] = t; my_tri[kept] = key_id(k); }
-                        ++kept;
-                        last_t = t;
-                    }
-                }
-                done = count < Kc || kept >= K || page + 1 >= kMaxPages;
-                if (!done) {                                         // the hits beyond this page: traverse again
-                    lo_key = sorted[Kc - 1];
-                    t_lo = key_t(lo_key) * 0.999999f;
-                    t_accept = last_t + min_sep;
-                    ++page;
-                    list.count = 0; list.worst = ~0ull; list.worst_slot = 0;
-                    t_limit = INFINITY; sp = 0;
-                    cur = ta.root_is_valid ? 0 : kDone;
-                }
-                oct_lds_sync();
-            }
-            if (done) {
-                for (int i = kept + j; i < K; i += 8) { my_t[i] = INFINITY; my_tri[i] = -1; }
-                if (j == 0) ta.hit_count[ray] = kept;
-                ray = -1;
-            }
-        }
-    }
-}
-
 // The repair pass after the camera-coherent intersector: only the rays whose candidate list overflowed (count > K) are
 // traversed.  With keep_mask (and min_sep > 0) the same launch decides the re-origin rule for every OTHER ray's
 // complete, unordered list without rewriting it (oct_keep_mask): keep_mask[ray], raw_count[ray] = the length of the
@@ -2389,12 +2187,9 @@ static int bvh_launch(const qf_bvh *bvh, const float *rays_o, const float *rays_
     a.tcol_offset = (int)tcol_offset;
     a.all_flag = only_overflowed ? all_flag : nullptr;
     if (only_overflowed) n_blocks = qf_div_up(n_rays, kTravThreads);        // 256 consecutive rays per workgroup
-    // plain batches (no image shape: training rays): octets that fetch their next ray from a workgroup pool
-    const bool pooled = !only_overflowed && image_width == 0 && n_rays >= 4 * kPoolRays;
-    if (pooled) n_blocks = qf_div_up(n_rays, kPoolRays);
     int64_t per_xcd = qf_div_up(n_blocks, 8);
     a.stripe_blocks = 0;
-    if (!only_overflowed && !pooled) {
+    if (!only_overflowed) {
         // image: stripes of two tile rows; a large plain batch: stripes of 256 blocks (8 192 consecutive rays) -- it may well
         // be a row-major image handed over without its width, and contiguous eighths would be as lopsided as bands
         // (1.65 -> 1.01 ms for the bench frame); batches under 2^18 rays keep contiguous eighths (a 2^17-ray batch sorted
@@ -2411,17 +2206,11 @@ static int bvh_launch(const qf_bvh *bvh, const float *rays_o, const float *rays_
     // front-to-back order only pays when the K-lists fill: a mesh whose rays meet K/2 triangles or more on average
     const bool ordered = bvh->depth_complexity >= 0.5f * (float)max_hits;
     const void *fn = only_overflowed ? reinterpret_cast<const void *>(bvh8_repair_kernel)
-                     : pooled ? (ordered ? reinterpret_cast<const void *>(bvh8_traverse_pool_kernel<true>)
-                                         : reinterpret_cast<const void *>(bvh8_traverse_pool_kernel<false>))
-                              : (ordered ? reinterpret_cast<const void *>(bvh8_traverse_kernel<true>)
-                                         : reinterpret_cast<const void *>(bvh8_traverse_kernel<false>));
+                                     : (ordered ? reinterpret_cast<const void *>(bvh8_traverse_kernel<true>)
+                                                : reinterpret_cast<const void *>(bvh8_traverse_kernel<false>));
     if (lds > 48 * 1024) QF_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     if (only_overflowed)
         hipLaunchKernelGGL(bvh8_repair_kernel, dim3((unsigned)(per_xcd * 8)), dim3(kTravThreads), lds, qf_stream(stream), a);
-    else if (pooled && ordered)
-        hipLaunchKernelGGL(bvh8_traverse_pool_kernel<true>, dim3((unsigned)(per_xcd * 8)), dim3(kTravThreads), lds, qf_stream(stream), a);
-    else if (pooled)
-        hipLaunchKernelGGL(bvh8_traverse_pool_kernel<false>, dim3((unsigned)(per_xcd * 8)), dim3(kTravThreads), lds, qf_stream(stream), a);
     else if (ordered)
         hipLaunchKernelGGL(bvh8_traverse_kernel<true>, dim3((unsigned)(per_xcd * 8)), dim3(kTravThreads), lds, qf_stream(stream), a);
     else
