@@ -536,10 +536,7 @@ int qf_pack_samples(const float *rays_o, const float *rays_d, int64_t n_rays, in
                     const int64_t *ray_offset, float *xyz, float *dirs, int64_t *index_ray,
                     float *depth, int64_t *index_tri, float *origins, const int32_t *inverse,
                     float *xyz_c, float *dirs_c, float *depth_c /* [n] or NULL */, const uint64_t *keep_mask,
-                    const int32_t *raw_count, float min_separation, int32_t *close_flag,
-                    int32_t *tri_c /* [n] or NULL (with inverse): the triangle ids in that order too, int32 -- what
-                                      qf_mesh_update_d_i32 merges best (a tile's rank-k samples share triangles) */,
-                    void *stream);
+                    const int32_t *raw_count, float min_separation, int32_t *close_flag, void *stream);
 
 /* qf_pack_samples for a frame that is only rendered (rays = a row-major width x height image): writes the positions,
  * unit directions and depths of the samples DIRECTLY in the coherent order below -- the order qf_field_forward streams
@@ -580,10 +577,7 @@ int qf_coherent_order(const int32_t *hit_count, const int64_t *ray_offset, const
  * (a render-only frame streams the coherent copies and only needs the inverse).                  */
 int qf_coherent_layout(const int32_t *hit_count, const int64_t *ray_offset, const int64_t *tile_base,
                        int32_t width, int32_t height, int32_t *order, int32_t *inverse,
-                       int32_t band_rows /* as qf_frame_offsets' */,
-                       int32_t *order_rel, int32_t *inverse_rel /* or NULL; banded layouts: the same two maps counted from
-                          the first sample of the band a sample lies in -- what a window indexes its own slices with */,
-                       void *stream);
+                       int32_t band_rows /* as qf_frame_offsets' */, void *stream);
 
 /* derive_properties (utils.py:863-898; the eval render of train_finetune.py:597-607) on a frame whose per-sample
  * colours, densities and depths are stored in the coherent order above (rgb_c / sigma_c = qf_field_forward's outputs
@@ -598,9 +592,7 @@ int qf_composite_tiles(const float *rgb_c /* [n,3] */, const float *sigma_c /* [
                        float delta_const, const int32_t *hit_count /* [w*h] */, int32_t max_hits,
                        const int64_t *tile_base, int32_t width, int32_t height, int32_t bg_mode,
                        const float *bkgd /* [3] or NULL */, float *out_rgb, float *out_alpha, float *out_depth,
-                       float *weights_c, float *out_packed, int64_t tile_base_offset /* subtracted from every tile base: 0 for a frame; the first sample of a
-                          window of a banded frame, whose slices of rgb_c / sigma_c / depth_c start there */,
-                       void *stream);
+                       float *weights_c, float *out_packed, void *stream);
 
 /* out_rows[y] = sum over the pixels of row y of min(hit_count, max_hits): quadrature points per pixel row of a frame
  * (band).  No reference counterpart: the cost profile the band-sharded renderer balances its cuts with.   */
@@ -703,10 +695,6 @@ int qf_split_layout(const int64_t *index_ray, int64_t n, int32_t width, int32_t 
  * (unsafeAtomicAdd), which are not coherent on fine-grained / host-mapped allocations.                       */
 int qf_mesh_update_d(const float *d /* [n,3] or NULL */, const float *w /* [n] */, const int64_t *index_tri, int64_t n,
                      int64_t n_faces, float *cache /* [n_faces,4] */, int32_t *skipped /* or NULL */, void *stream);
-/* ... with int32 ids (the tile-ordered ids of qf_pack_samples' tri_c / qf_pack_tiles).  Batches of 8 192 samples or more
- * merge a 1024-sample chunk's duplicate triangles in LDS before the global atomics (either entry).             */
-int qf_mesh_update_d_i32(const float *d, const float *w, const int32_t *index_tri, int64_t n, int64_t n_faces,
-                         float *cache, int32_t *skipped, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Baked spherical-Gaussian textures.

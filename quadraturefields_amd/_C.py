@@ -95,7 +95,7 @@ _SIGNATURES = {
     "qf_sum_reduce": (c_int, [_P, c_int32, _P, c_int64, c_int64, _P, _P]),
     "qf_derive_properties": (c_int, [_P, _P, _P, _P, c_float, _P, c_int64, c_int64, c_int32, _P, _P, _P, _P, _P, _P, _P]),
     "qf_deform_resort_tiles": (c_int, [_P, c_float, _P, _P, _P, _P, c_int32, _P, c_int64, _P, c_int32, c_int32, _P, _P, _P]),
-    "qf_composite_tiles": (c_int, [_P, _P, _P, c_float, _P, c_int32, _P, c_int32, c_int32, c_int32, _P, _P, _P, _P, _P, _P, c_int64, _P]),
+    "qf_composite_tiles": (c_int, [_P, _P, _P, c_float, _P, c_int32, _P, c_int32, c_int32, c_int32, _P, _P, _P, _P, _P, _P, _P]),
     "qf_row_sample_counts": (c_int, [_P, c_int32, c_int32, c_int32, _P, _P]),
     "qf_derive_properties_backward": (c_int, [_P, _P, _P, _P, c_float, _P, c_int64, c_int64, c_int32, _P, _P, _P, _P, _P, _P, _P, _P]),
     "qf_pack_info": (c_int, [_P, c_int64, c_int64, _P, _P]),
@@ -138,15 +138,14 @@ _SIGNATURES = {
     "qf_banded_tile_count": (c_int64, [c_int32, c_int32, c_int32]),
     "qf_tile_offsets": (c_int, [_P, c_int32, c_int32, c_int32, _P, _P, _P, _P, _P, _P, _P]),
     "qf_pack_tiles": (c_int, [_P, _P, c_int32, c_int32, c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_float, _P, _P, _P, c_int32, _P]),
-    "qf_pack_samples": (c_int, [_P, _P, c_int64, c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_float, _P, _P, _P]),
+    "qf_pack_samples": (c_int, [_P, _P, c_int64, c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_float, _P, _P]),
     "qf_tile_totals": (c_int, [_P, c_int32, c_int32, _P, _P]),
     "qf_coherent_order": (c_int, [_P, _P, _P, c_int32, c_int32, _P, _P]),
-    "qf_coherent_layout": (c_int, [_P, _P, _P, c_int32, c_int32, _P, _P, c_int32, _P, _P, _P]),
+    "qf_coherent_layout": (c_int, [_P, _P, _P, c_int32, c_int32, _P, _P, c_int32, _P]),
     "qf_resort_by_depth": (c_int, [_P, _P, c_int64, _P, _P]),
     "qf_resort_samples": (c_int, [_P, _P, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "qf_split_layout": (c_int, [_P, c_int64, c_int32, c_int32, _P, _P, _P, _P, _P, _P, _P]),
     "qf_mesh_update_d": (c_int, [_P, _P, _P, c_int64, c_int64, _P, _P, _P]),
-    "qf_mesh_update_d_i32": (c_int, [_P, _P, _P, c_int64, c_int64, _P, _P, _P]),
     "qf_texel_indices": (c_int, [_P, _P, _P, _P, _P, c_int64, c_int32, _P, _P]),
     "qf_texel_records_pack": (c_int, [_P, _P, _P, c_int64, _P, _P]),
     "qf_texel_indices_packed": (c_int, [_P, _P, _P, c_int64, c_int32, _P, _P]),

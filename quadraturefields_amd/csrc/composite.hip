@@ -456,8 +456,7 @@ __global__ __launch_bounds__(64) void tile_totals_kernel(const int32_t *hit_coun
 // order[pos] = sample (ray-major index) for every position of the coherent sequence; optionally the inverse map too.
 __global__ __launch_bounds__(64) void coherent_order_kernel(const int32_t *hit_count, const int64_t *ray_offset,
                                                             const int64_t *tile_base, int w, int h, int tiles_x,
-                                                            int32_t *order, int32_t *inverse, int band_rows,
-                                                            int32_t *order_rel, int32_t *inverse_rel)
+                                                            int32_t *order, int32_t *inverse, int band_rows)
 {
     const int tile = blockIdx.x, lane = threadIdx.x;
     int64_t ray = 0;
@@ -465,11 +464,6 @@ __global__ __launch_bounds__(64) void coherent_order_kernel(const int32_t *hit_c
     int64_t first = 0;
     if (qf_tile_lane_ray(tile, lane, w, h, tiles_x, band_rows, &ray)) { cnt = hit_count[ray]; first = ray_offset[ray]; }
     int64_t base = tile_base[tile];
-    // *_rel (banded layouts): the same two maps counted from the band's first sample -- what a window of the frame indexes
-    // its own slices with (a band's samples are [ray_offset[first ray of the band], ...) ray-major AND in the order)
-    int64_t band_base = 0;
-    if ((order_rel || inverse_rel) && band_rows > 0 && band_rows < h)
-        band_base = ray_offset[(int64_t)(tile / (tiles_x * ((band_rows + 7) / 8))) * band_rows * w];
     const unsigned long long below = (1ull << lane) - 1ull;
     for (int k = 0;; ++k) {
         const unsigned long long mask = __ballot(cnt > k);
@@ -478,8 +472,6 @@ __global__ __launch_bounds__(64) void coherent_order_kernel(const int32_t *hit_c
             const int64_t pos = base + __popcll(mask & below), smp = first + k;
             if (order) order[pos] = (int32_t)smp;
             if (inverse) inverse[smp] = (int32_t)pos;
-            if (order_rel) order_rel[pos] = (int32_t)(smp - band_base);
-            if (inverse_rel) inverse_rel[smp] = (int32_t)(pos - band_base);
         }
         base += __popcll(mask);
     }
@@ -495,14 +487,14 @@ __global__ __launch_bounds__(64) void composite_tiles_kernel(
     const float *__restrict__ rgb_c, const float *__restrict__ sigma_c, const float *__restrict__ depth_c,
     float delta_const, const int32_t *__restrict__ hit_count, int max_hits, const int64_t *__restrict__ tile_base, int w,
     int h, int tiles_x, int bg_mode, const float *__restrict__ bkgd, float *__restrict__ out_rgb, float *__restrict__ out_alpha,
-    float *__restrict__ out_depth, float *__restrict__ weights_c, float *__restrict__ out_packed, int64_t base_offset)
+    float *__restrict__ out_depth, float *__restrict__ weights_c, float *__restrict__ out_packed)
 {
     const int tile = blockIdx.x, lane = threadIdx.x;
     int64_t ray = 0;
     int cnt = 0;
     const int inside = tile_lane_ray(tile, lane, w, h, tiles_x, &ray);
     if (inside) cnt = hit_count[ray] < max_hits ? hit_count[ray] : max_hits;
-    int64_t base = tile_base[tile] - base_offset;     // (a window of a banded frame: its slices start at its first sample)
+    int64_t base = tile_base[tile];
     const unsigned long long below = (1ull << lane) - 1ull;
     RayAccum acc;
     unsigned long long mask = __ballot(cnt > 0);
@@ -658,8 +650,7 @@ extern "C" int qf_deform_resort_tiles(const float *f_c, float scaling, const flo
 extern "C" int qf_composite_tiles(const float *rgb_c, const float *sigma_c, const float *depth_c, float delta_const,
                                   const int32_t *hit_count, int32_t max_hits, const int64_t *tile_base, int32_t width,
                                   int32_t height, int32_t bg_mode, const float *bkgd, float *out_rgb, float *out_alpha,
-                                  float *out_depth, float *weights_c, float *out_packed, int64_t tile_base_offset,
-                                  void *stream)
+                                  float *out_depth, float *weights_c, float *out_packed, void *stream)
 {
     if (width < 1 || height < 1 || max_hits < 1 || bg_mode < 0 || bg_mode > 3) return QF_ERR_INVALID_ARGUMENT;
     if (!rgb_c || !sigma_c || !depth_c || !hit_count || !tile_base) return QF_ERR_INVALID_ARGUMENT;
@@ -668,7 +659,7 @@ extern "C" int qf_composite_tiles(const float *rgb_c, const float *sigma_c, cons
     const int tiles_x = (width + 7) / 8, tiles_y = (height + 7) / 8;
     hipLaunchKernelGGL(composite_tiles_kernel, dim3(tiles_x * tiles_y), dim3(64), 0, qf_stream(stream), rgb_c, sigma_c,
                        depth_c, delta_const, hit_count, (int)max_hits, tile_base, (int)width, (int)height, tiles_x, (int)bg_mode, bkgd,
-                       out_rgb, out_alpha, out_depth, weights_c, out_packed, tile_base_offset);
+                       out_rgb, out_alpha, out_depth, weights_c, out_packed);
     QF_LAUNCH_CHECK();
     return QF_OK;
 }
@@ -699,22 +690,21 @@ extern "C" int qf_coherent_order(const int32_t *hit_count, const int64_t *ray_of
     if (width < 1 || height < 1 || !hit_count || !ray_offset || !tile_base || !order) return QF_ERR_INVALID_ARGUMENT;
     const int tiles_x = (width + 7) / 8, tiles_y = (height + 7) / 8;
     hipLaunchKernelGGL(coherent_order_kernel, dim3(tiles_x * tiles_y), dim3(64), 0, qf_stream(stream), hit_count,
-                       ray_offset, tile_base, (int)width, (int)height, tiles_x, order, (int32_t *)nullptr, 0, (int32_t *)nullptr,
-                       (int32_t *)nullptr);
+                       ray_offset, tile_base, (int)width, (int)height, tiles_x, order, (int32_t *)nullptr, 0);
     QF_LAUNCH_CHECK();
     return QF_OK;
 }
 
 extern "C" int qf_coherent_layout(const int32_t *hit_count, const int64_t *ray_offset, const int64_t *tile_base,
                                   int32_t width, int32_t height, int32_t *order, int32_t *inverse, int32_t band_rows,
-                                  int32_t *order_rel, int32_t *inverse_rel, void *stream)
+                                  void *stream)
 {
     if (width < 1 || height < 1 || band_rows < 0 || !hit_count || !ray_offset || !tile_base || !inverse)    // order may be NULL
         return QF_ERR_INVALID_ARGUMENT;
     const int tiles_x = (width + 7) / 8;
     hipLaunchKernelGGL(coherent_order_kernel, dim3((unsigned)qf_banded_tiles(width, height, band_rows)), dim3(64), 0,
                        qf_stream(stream), hit_count, ray_offset, tile_base, (int)width, (int)height, tiles_x, order, inverse,
-                       (int)band_rows, order_rel, inverse_rel);
+                       (int)band_rows);
     QF_LAUNCH_CHECK();
     return QF_OK;
 }
@@ -877,9 +867,8 @@ __global__ __launch_bounds__(64) void split_order_kernel(const int32_t *hit_coun
 // A triangle id outside [0, n_faces) cannot be accumulated (torch's index_add_ / torch_scatter raise on it): the sample
 // is skipped and, when the caller passes a counter, COUNTED -- MeshFinetune raises on a non-zero count the next time
 // it synchronises anyway (update_faces), so corrupt ids (a stale sample set after a mesh swap) do not vanish silently.
-template <typename TriT>
 __global__ void mesh_update_d_kernel(const float *__restrict__ d, const float *__restrict__ w,
-                                     const TriT *__restrict__ index_tri, int64_t n, int64_t n_faces, float *cache,
+                                     const int64_t *__restrict__ index_tri, int64_t n, int64_t n_faces, float *cache,
                                      int32_t *__restrict__ skipped)
 {
 #pragma clang fp contract(off)
@@ -914,9 +903,9 @@ __global__ void mesh_update_d_kernel(const float *__restrict__ d, const float *_
 // The order of the fp32 additions differs from the unmerged kernel's (which is itself unordered: atomics).
 constexpr int kUdBlock = 256, kUdChunk = 1024, kUdSlots = 2048;
 
-template <bool kHasD, typename TriT>
+template <bool kHasD>
 __global__ __launch_bounds__(kUdBlock) void mesh_update_d_merged_kernel(const float *__restrict__ d, const float *__restrict__ w,
-                                                                        const TriT *__restrict__ index_tri, int64_t n,
+                                                                        const int64_t *__restrict__ index_tri, int64_t n,
                                                                         int64_t n_faces, float *cache,
                                                                         int32_t *__restrict__ skipped)
 {
@@ -1002,9 +991,8 @@ extern "C" int qf_split_layout(const int64_t *index_ray, int64_t n, int32_t widt
     return QF_OK;
 }
 
-template <typename TriT>
-static int mesh_update_d_launch(const float *d, const float *w, const TriT *index_tri, int64_t n, int64_t n_faces, float *cache,
-                                int32_t *skipped, void *stream)
+extern "C" int qf_mesh_update_d(const float *d, const float *w, const int64_t *index_tri, int64_t n, int64_t n_faces,
+                                float *cache, int32_t *skipped, void *stream)
 {
     if (n < 0 || n_faces < 0) return QF_ERR_INVALID_ARGUMENT;
     if (n == 0) return QF_OK;
@@ -1014,31 +1002,18 @@ static int mesh_update_d_launch(const float *d, const float *w, const TriT *inde
         const int64_t cap = (int64_t)qf_cu_count_cached() * 8;
         const unsigned grid = (unsigned)(chunks < cap ? chunks : cap);
         if (d)
-            hipLaunchKernelGGL((mesh_update_d_merged_kernel<true, TriT>), dim3(grid), dim3(kUdBlock), 0, qf_stream(stream), d, w,
+            hipLaunchKernelGGL(mesh_update_d_merged_kernel<true>, dim3(grid), dim3(kUdBlock), 0, qf_stream(stream), d, w,
                                index_tri, n, n_faces, cache, skipped);
         else
-            hipLaunchKernelGGL((mesh_update_d_merged_kernel<false, TriT>), dim3(grid), dim3(kUdBlock), 0, qf_stream(stream), d, w,
+            hipLaunchKernelGGL(mesh_update_d_merged_kernel<false>, dim3(grid), dim3(kUdBlock), 0, qf_stream(stream), d, w,
                                index_tri, n, n_faces, cache, skipped);
         QF_LAUNCH_CHECK();
         return QF_OK;
     }
-    hipLaunchKernelGGL(mesh_update_d_kernel<TriT>, dim3(qf_grid_1d(d ? 4 * n : n, 256)), dim3(256), 0, qf_stream(stream), d, w,
+    hipLaunchKernelGGL(mesh_update_d_kernel, dim3(qf_grid_1d(d ? 4 * n : n, 256)), dim3(256), 0, qf_stream(stream), d, w,
                        index_tri, n, n_faces, cache, skipped);
     QF_LAUNCH_CHECK();
     return QF_OK;
-}
-
-extern "C" int qf_mesh_update_d(const float *d, const float *w, const int64_t *index_tri, int64_t n, int64_t n_faces,
-                                float *cache, int32_t *skipped, void *stream)
-{
-    return mesh_update_d_launch(d, w, index_tri, n, n_faces, cache, skipped, stream);
-}
-
-// the same with int32 triangle ids (the tile-ordered ids of qf_pack_samples' tri_c / qf_pack_tiles)
-extern "C" int qf_mesh_update_d_i32(const float *d, const float *w, const int32_t *index_tri, int64_t n, int64_t n_faces,
-                                    float *cache, int32_t *skipped, void *stream)
-{
-    return mesh_update_d_launch(d, w, index_tri, n, n_faces, cache, skipped, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------

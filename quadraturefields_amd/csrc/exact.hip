@@ -1344,7 +1344,7 @@ __global__ __launch_bounds__(kPackRays) void pack_samples_kernel(
     int64_t *__restrict__ index_ray, float *__restrict__ depth, int64_t *__restrict__ index_tri,
     float *__restrict__ origins, const int32_t *__restrict__ inverse, float *__restrict__ xyz_c,
     float *__restrict__ dirs_c, float *__restrict__ depth_c, const uint64_t *__restrict__ keep_mask,
-    const int32_t *__restrict__ raw_count, float min_sep, int32_t *__restrict__ close_flag, int32_t *__restrict__ tri_c)
+    const int32_t *__restrict__ raw_count, float min_sep, int32_t *__restrict__ close_flag)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int K = max_hits, Kp = max_hits | 1;            // odd row stride: conflict-free column access
@@ -1478,7 +1478,6 @@ __global__ __launch_bounds__(kPackRays) void pack_samples_kernel(
             dirs_c[c * 3 + 1] = dy / nrm;
             dirs_c[c * 3 + 2] = dz / nrm;
             if (depth_c) depth_c[c] = (float)dep;
-            if (tri_c) tri_c[c] = s_tri[rl * Kp + k];
         }
     }
 }
@@ -2265,14 +2264,13 @@ extern "C" int qf_pack_samples(const float *rays_o, const float *rays_d, int64_t
                                const int64_t *ray_offset, float *xyz, float *dirs, int64_t *index_ray, float *depth,
                                int64_t *index_tri, float *origins, const int32_t *inverse, float *xyz_c, float *dirs_c,
                                float *depth_c, const uint64_t *keep_mask, const int32_t *raw_count,
-                               float min_separation, int32_t *close_flag, int32_t *tri_c, void *stream)
+                               float min_separation, int32_t *close_flag, void *stream)
 {
     if ((keep_mask == nullptr) != (raw_count == nullptr)) return QF_ERR_INVALID_ARGUMENT;
     if (n_rays < 0 || max_hits < 1 || max_hits > kMaxHits) return QF_ERR_INVALID_ARGUMENT;
     if (n_rays == 0) return QF_OK;
     if (!rays_o || !rays_d || !hit_tri || !hit_t || !hit_count || !ray_offset) return QF_ERR_INVALID_ARGUMENT;
     if (inverse && (!xyz_c || !dirs_c)) return QF_ERR_INVALID_ARGUMENT;
-    if (tri_c && !inverse) return QF_ERR_INVALID_ARGUMENT;
     if (!index_ray || !depth || !index_tri) return QF_ERR_INVALID_ARGUMENT;
     if ((xyz || dirs || origins) && (!xyz || !dirs || !origins)) return QF_ERR_INVALID_ARGUMENT;
     if (!xyz && !inverse) return QF_ERR_INVALID_ARGUMENT;      // the positions have to go somewhere
@@ -2282,7 +2280,7 @@ extern "C" int qf_pack_samples(const float *rays_o, const float *rays_d, int64_t
     if (blocks > 0x7fffffff) return QF_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(pack_samples_kernel, dim3((unsigned)blocks), dim3(kPackRays), lds, qf_stream(stream), rays_o, rays_d,
                        n_rays, (int)max_hits, hit_tri, hit_t, hit_count, ray_offset, xyz, dirs, index_ray, depth, index_tri,
-                       origins, inverse, xyz_c, dirs_c, depth_c, keep_mask, raw_count, min_separation, close_flag, tri_c);
+                       origins, inverse, xyz_c, dirs_c, depth_c, keep_mask, raw_count, min_separation, close_flag);
     QF_LAUNCH_CHECK();
     return QF_OK;
 }

@@ -61,5 +61,5 @@ extern "C" int qf_frame_render(qf_bvh *bvh, const qf_frame_job *job, void *strea
                           j.rgb_c, j.sigma_c, nullptr, nullptr, nullptr, stream);
     if (rc != QF_OK) return rc;
     return qf_composite_tiles(j.rgb_c, j.sigma_c, j.depth_c, j.delta_const, j.final_count, j.max_hits, j.tile_base, w, h,
-                              j.bg_mode, j.bkgd, j.out_rgb, j.out_alpha, j.out_depth, nullptr, j.out_packed, 0, stream);
+                              j.bg_mode, j.bkgd, j.out_rgb, j.out_alpha, j.out_depth, nullptr, j.out_packed, stream);
 }

@@ -109,10 +109,8 @@ class SampleSet(tuple):
     """The six sample tensors of a frame -- ``(xyzs, dirs, index_ray, ts, index_tri, origins)``, what the reference's
     loader hands to the renderers (nerf_synthetic.py:256-257); this IS that tuple -- plus, as attributes, one frame-wide
     coherent layout cut at the windows of ``generate_splits``: ``cuts`` (first sample of every window, and the total),
-    ``window_rays``, ``num_rays``, ``inverse`` / ``order`` (sample <-> position, int32; ``*_rel``: counted from the first
-    sample of the window a sample lies in), the streamed copies ``xyz_c`` / ``dirs_c`` / ``depth_c`` / ``tri_c`` and what the
-    tile compositor walks (``hit_count`` per ray, ``tile_base`` per tile, ``tiles_per_window``).  A window's samples are
-    ``[cuts[w], cuts[w+1])`` in the ray-major arrays AND in the copies."""
+    ``window_rays``, ``num_rays``, ``inverse`` / ``order`` (sample <-> position, int32) and the streamed copies
+    ``xyz_c`` / ``dirs_c``.  A window's samples are ``[cuts[w], cuts[w+1])`` in the ray-major arrays AND in the copies."""
 
     def __new__(cls, arrays, **meta):
         obj = super().__new__(cls, arrays)
@@ -122,9 +120,8 @@ class SampleSet(tuple):
 
 class SampleWindow(tuple):
     """One window of a ``SampleSet`` (``generate_splits``): the reference's 6-tuple of the window's samples (views), plus
-    ``base`` = the window's first sample and the same range of the frame's layout: window-relative maps, the streamed
-    copies, and the window as a sub-image for the tile compositor (``first_ray``, ``rows``, its rays' ``hit_count``, its
-    tiles' ``tile_base`` -- which counts from the FRAME's first sample: ``tile_base_offset = base``)."""
+    ``base`` = the window's first sample and the same range of the frame's layout (``inverse`` / ``order`` hold FRAME
+    positions: subtract ``base``)."""
 
     def __new__(cls, arrays, **meta):
         obj = super().__new__(cls, arrays)
@@ -635,23 +632,17 @@ class RayIntersector:
             index_tri = torch.empty((cap,), dtype=torch.int64, device=dev)
             depth = torch.empty((cap,), dtype=torch.float32, device=dev)
             if image:                         # the coherent order and its inverse
-                rel = None
-                if band_rows:                 # a loader item for generate_splits: window-relative maps, ids in tile order
-                    rel = (torch.empty((cap,), dtype=torch.int32, device=dev), torch.empty((cap,), dtype=torch.int32, device=dev))
-                    frame.tri_c = torch.empty((cap,), dtype=torch.int32, device=dev)
                 order, inverse = self.coherent_layout(hit_count, buf, cap, width, tile_base, want_order=True,
-                                                      band_rows=tile_band, rel=rel)
+                                                      band_rows=tile_band)
                 layout = (inverse, xyz_c, dirs_c)
-                frame.rel = rel
                 if tile_band:                 # a banded tile grid: not the geometry qf_composite_tiles walks
                     frame.band_rows = tile_band
             _C.check(_C.lib().qf_pack_samples(_C.ptr(o), _C.ptr(d), n, k, _C.ptr(hit_tri), _C.ptr(hit_t),
                                               _C.ptr(hit_count), _C.ptr(buf), _C.ptr(xyz), _C.ptr(dirs),
                                               _C.ptr(index_ray), _C.ptr(depth), _C.ptr(index_tri), _C.ptr(org),
                                               _C.ptr(inverse), _C.ptr(xyz_c), _C.ptr(dirs_c), _C.ptr(depth_c),
-                                              _C.ptr(keep[0]), _C.ptr(keep[1]), min_sep, flag,
-                                              _C.ptr(frame.tri_c) if (frame is not None and inverse is not None) else None,
-                                              _C.stream()), "qf_pack_samples")
+                                              _C.ptr(keep[0]), _C.ptr(keep[1]), min_sep, flag, _C.stream()),
+                     "qf_pack_samples")
         if optimistic:
             ev_flag.record()
         return (o, d, k, width, (lean, want_layout, band_rows), host, (ev, ev_flag if (optimistic or lean) else None),
@@ -689,8 +680,6 @@ class RayIntersector:
             frame.depth_c = frame.depth_c[:total]
             if frame.tri_c is not None:
                 frame.tri_c = frame.tri_c[:total]
-            if getattr(frame, "rel", None) is not None:
-                frame.rel = tuple(t[:total] for t in frame.rel)
             frame.total = total               # slots of the coherent arrays (what the field kernel streams)
             # a render-only frame's tile pack applied the re-origin rule itself: its samples are the slots minus the
             # hits that dropped (host[2], there once ev_flag has passed -- read on demand by frame_samples())
@@ -974,7 +963,7 @@ class RayIntersector:
         return r[0][r[1] % len(r[0])]
 
     def coherent_layout(self, hit_count, ray_offset, total: int, width: int, tile_base=None, want_order=True,
-                        band_rows: int = 0, rel=None):
+                        band_rows: int = 0):
         """``coherent_order`` and its inverse map (``inverse[sample] = position``).  Given the inverse,
         ``qf_pack_samples`` also writes ``xyz[order]`` / ``dirs[order]``, so ``field(xyz_c, dirs_c)`` reads and writes
         sequentially (the indirection through ``order`` costs it 10 %), and
@@ -991,9 +980,7 @@ class RayIntersector:
         order = torch.empty((total,), dtype=torch.int32, device=dev) if want_order else None
         inverse = torch.empty((total,), dtype=torch.int32, device=dev)
         _C.check(_C.lib().qf_coherent_layout(_C.ptr(hit_count), _C.ptr(ray_offset), _C.ptr(tile_base), width, height,
-                                             _C.ptr(order), _C.ptr(inverse), int(band_rows),
-                                             _C.ptr(rel[0]) if rel is not None else None,
-                                             _C.ptr(rel[1]) if rel is not None else None, _C.stream()),
+                                             _C.ptr(order), _C.ptr(inverse), int(band_rows), _C.stream()),
                  "qf_coherent_layout")
         return order, inverse
 
@@ -1100,13 +1087,10 @@ class MeshFinetune:
         if n == 0:
             return
         with torch.cuda.device(self.device):
-            if index_tri.dtype == torch.int32:          # the tile-ordered ids of a loader window (no int64 copy)
-                fn, ids = _C.lib().qf_mesh_update_d_i32, index_tri.reshape(-1).contiguous()
-            else:
-                fn, ids = _C.lib().qf_mesh_update_d, _C.i64c(index_tri.reshape(-1))
-            _C.check(fn(_C.ptr(_C.f32c(d.reshape(-1, 3))) if d is not None else None, _C.ptr(_C.f32c(w.reshape(-1))),
-                        _C.ptr(ids), n, int(self.faces.shape[0]), _C.ptr(self._cache), _C.ptr(self._skipped), _C.stream()),
-                     "qf_mesh_update_d")
+            _C.check(_C.lib().qf_mesh_update_d(
+                _C.ptr(_C.f32c(d.reshape(-1, 3))) if d is not None else None, _C.ptr(_C.f32c(w.reshape(-1))),
+                _C.ptr(_C.i64c(index_tri.reshape(-1))), n, int(self.faces.shape[0]), _C.ptr(self._cache),
+                _C.ptr(self._skipped), _C.stream()), "qf_mesh_update_d")
 
     def check_ids(self) -> None:
         """Raises if any ``update_d`` since the last check saw a triangle id outside ``[0, n_faces)`` (host wait)."""
@@ -1181,19 +1165,9 @@ class MeshIntersection:
             return data
         cuts_host, band_rays = ri.last_band_cuts
         inverse, xyz_c, dirs_c = ri.last_layout
-        frame = ri.last_frame
         n_rays = int(vectors.shape[0]) if hasattr(vectors, "shape") else int(len(vectors))
-        height = n_rays // width
-        tiles_x = (width + 7) // 8
-        tiles_w = tiles_x * ((min(band_rows, height) + 7) // 8)            # tiles of one window (its own tile grid)
-        if band_rows >= height:                  # one window = the frame: the maps count from sample 0 already
-            order_rel, inverse_rel = ri.last_order, inverse
-        else:
-            order_rel, inverse_rel = frame.rel
         return SampleSet(data, cuts=cuts_host.tolist(), window_rays=band_rays, num_rays=n_rays, inverse=inverse,
-                         order=ri.last_order, order_rel=order_rel, inverse_rel=inverse_rel, xyz_c=xyz_c, dirs_c=dirs_c,
-                         depth_c=frame.depth_c, tri_c=frame.tri_c, hit_count=frame.hit_count, tile_base=frame.tile_base,
-                         tiles_per_window=tiles_w, max_hits=frame.max_hits, width=width)
+                         order=ri.last_order, xyz_c=xyz_c, dirs_c=dirs_c, width=width)
 
     def sampling_raytrace_numpy(self, vectors, origins, random=0):
         """numpy 7-tuple (points, dirs, index_ray, depth, index_tri, 0, origins) sorted by (ray, depth), or None

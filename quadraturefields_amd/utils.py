@@ -10,7 +10,6 @@ Every tensor stays on the device; the reference's 160 000-sample Python batch lo
 the results do not depend on any chunk size.
 """
 import random
-from types import SimpleNamespace
 from typing import Optional
 
 import numpy as np
@@ -58,17 +57,12 @@ def generate_splits(data, num_rays, chunk_size=160000):
         # a loader item cut for exactly these windows (SubjectLoader -> sampling_raytrace_device(window_rays=)): the
         # windows' boundaries came back with the frame's own readback and the frame-wide coherent layout restarts at every
         # window -- views only, no launch, no host wait; empty windows are skipped as the reference does (:427-428)
-        rays_w, tiles_w = data.window_rays, data.tiles_per_window
-        for w, (a, b) in enumerate(zip(data.cuts[:-1], data.cuts[1:])):
+        for a, b in zip(data.cuts[:-1], data.cuts[1:]):
             if b > a:
-                r0 = w * rays_w
-                r1 = min(r0 + rays_w, data.num_rays)
-                chunks.append(SampleWindow(
-                    tuple(t[a:b] for t in (xyzs, dirs, index_ray, ts, index_tri, origins)), base=a, num_rays=data.num_rays,
-                    inverse_rel=data.inverse_rel[a:b], order_rel=data.order_rel[a:b], xyz_c=data.xyz_c[a:b],
-                    dirs_c=data.dirs_c[a:b], depth_c=data.depth_c[a:b], tri_c=data.tri_c[a:b], first_ray=r0,
-                    width=data.width, rows=(r1 - r0) // data.width, max_hits=data.max_hits,
-                    hit_count=data.hit_count[r0:r1], tile_base=data.tile_base[w * tiles_w:(w + 1) * tiles_w]))
+                chunks.append(SampleWindow(tuple(t[a:b] for t in (xyzs, dirs, index_ray, ts, index_tri, origins)),
+                                           base=a, inverse=data.inverse[a:b],
+                                           order=None if data.order is None else data.order[a:b],
+                                           xyz_c=data.xyz_c[a:b], dirs_c=data.dirs_c[a:b], num_rays=data.num_rays))
         return chunks
     if n > 0 and index_ray.is_cuda and index_ray.dim() == 1 and index_ray.dtype == torch.int64:
         edges = torch.arange(0, int(num_rays) + int(chunk_size), int(chunk_size), dtype=torch.int64, device=index_ray.device)
@@ -171,21 +165,19 @@ def derive_properties(color, density, depths, deltas, boundary, index_ray, rende
 
 @torch.no_grad()
 def composite_frame(color_c, density_c, frame, render_step_size: float, render_bkgd=None, bg_color="white",
-                    want_weights: bool = False, packed: bool = False, out=None, tile_base_offset: int = 0):
+                    want_weights: bool = False, packed: bool = False):
     """``derive_properties`` for a whole frame whose colours / densities come straight from the field kernel, i.e. in the
     intersector's coherent order: ``frame`` = ``RayIntersector.last_frame`` (depths in that order, per-pixel sample
     counts, tile bases, image size).  One launch (``qf_composite_tiles``), every load a contiguous run; the same
     values as ``derive_properties(..., sample_index=inverse)`` bit for bit.  Returns (rgb [N,3], alpha [N,1],
     depth [N,1], weights in the coherent order [S,1] or None).  ``packed``: ONE [N,5] array (rgb | alpha | depth per
     pixel, what a row band of a sharded frame sends) comes back in place of the three: (packed, None, None, weights).
-    ``out`` = (rgb [n_rays,3], alpha [n_rays,1], depth [n_rays,1]) to write into -- views of the frame's rows inside
-    full-image buffers -- and ``tile_base_offset``: a WINDOW of a banded frame (``frame`` = the window's sub-image: its
-    rows' counts, its tiles' bases, which count from the frame's first sample).  Inference only."""
+    Inference only."""
     color_c = _C.f32c(color_c.reshape(-1, 3))
     density_c = _C.f32c(density_c.reshape(-1))
     dev = color_c.device
     n = frame.depth_c.shape[0]
-    if getattr(frame, "band_rows", 0) and out is None:
+    if getattr(frame, "band_rows", 0):
         raise ValueError("composite_frame: this frame's layout is cut into row bands (a loader item for generate_splits); "
                          "composite it with derive_properties(sample_index=inverse)")
     if color_c.shape[0] != n or density_c.shape[0] != n:
@@ -194,11 +186,7 @@ def composite_frame(color_c, density_c, frame, render_step_size: float, render_b
     mode = _BG.get(bg_color, _C.BG_CUSTOM)
     bk = _C.f32c(render_bkgd.detach().reshape(3).to(dev)) if mode == _C.BG_CUSTOM else None
     rgb = alpha = depth = out5 = None
-    if out is not None:
-        rgb, alpha, depth = out
-        if rgb.shape[0] != n_rays or alpha.shape[0] != n_rays or depth.shape[0] != n_rays:
-            raise ValueError("composite_frame: out must hold the frame's width * height rays")
-    elif packed:
+    if packed:
         out5 = torch.empty((n_rays, 5), dtype=torch.float32, device=dev)
     else:
         rgb = torch.empty((n_rays, 3), dtype=torch.float32, device=dev)
@@ -208,7 +196,7 @@ def composite_frame(color_c, density_c, frame, render_step_size: float, render_b
     _C.check(_C.lib().qf_composite_tiles(
         _C.ptr(color_c), _C.ptr(density_c), _C.ptr(frame.depth_c), float(render_step_size), _C.ptr(frame.hit_count),
         frame.max_hits, _C.ptr(frame.tile_base), frame.width, frame.height, mode, _C.ptr(bk), _C.ptr(rgb), _C.ptr(alpha),
-        _C.ptr(depth), _C.ptr(weights), _C.ptr(out5), int(tile_base_offset), _C.stream()), "qf_composite_tiles")
+        _C.ptr(depth), _C.ptr(weights), _C.ptr(out5), _C.stream()), "qf_composite_tiles")
     if packed:
         return out5, None, None, weights
     return rgb, alpha, depth, weights
@@ -291,39 +279,24 @@ def render_image_finetune_with_occgrid(
                                                   or _module_trains(field_net)))
     auto_inverse = None
     window = data if (isinstance(data, SampleWindow) and inference and order is None and xyzs.shape[0] > 0
-                      and data.num_rays == num_rays and data.inverse_rel.device == device) else None
+                      and data.num_rays == num_rays and data.inverse.device == device) else None
     if window is not None:
-        # a window of a loader item that came with its frame-wide coherent layout (generate_splits): the layout maps
-        # count from the window's first sample already (qf_coherent_layout's *_rel outputs): no qf_split_layout
+        # a window of a loader item that came with its frame-wide coherent layout (generate_splits): positions relative
+        # to the window's first sample -- one subtraction instead of the four launches of qf_split_layout
         deforms = field_net is not None and scaling != 0
-        auto_inverse = window.inverse_rel
-        if deforms and isinstance(field_net, _Field):
-            order = window.order_rel
+        auto_inverse = window.inverse - window.base
+        if deforms and isinstance(field_net, _Field) and window.order is not None:
+            order = window.order - window.base
         if not deforms:
-            # No deformation: the samples ARE sorted by (ray, depth), the re-sort of sampling_indexing is the identity
-            # (what FrameRenderer.render relies on too) and the loader's pack has already written the streamed copies.
-            # The window is the sub-image of its rows, its tile grid starts at its first row: field on its slice of the
-            # copies, then the TILE compositor straight on the field's outputs (contiguous loads; derive_properties through
-            # the inverse map took four times as long), writing the window's rows of full-image buffers that carry the
-            # reference's initial values everywhere else (utils.py:863-898).  The weights come out in tile order, where a
-            # tile's rank-k samples share triangles: update_d merges them there; the returned weights are ray-major.
+            # no deformation: the samples ARE sorted by (ray, depth), the re-sort of sampling_indexing is the identity
+            # (what FrameRenderer.render relies on too) and the loader's pack has already written the streamed copies:
+            # field on the window's slice of them, compositing through the inverse map -- no resort launch at all
             rgbs, sigmas = radiance_field(window.xyz_c, window.dirs_c)
-            mode = _BG.get(bg_color, _C.BG_CUSTOM)
-            flat = torch.zeros((5 * num_rays,), dtype=torch.float32, device=device)
-            rgb, opacity, depth_img = (flat[:3 * num_rays].view(num_rays, 3), flat[3 * num_rays:4 * num_rays].view(num_rays, 1),
-                                       flat[4 * num_rays:].view(num_rays, 1))
-            if mode not in (_C.BG_BLACK, _C.BG_NONE):
-                flat[:3 * num_rays].fill_(1.0)
-            r0, r1 = window.first_ray, window.first_ray + window.rows * window.width
-            sub = SimpleNamespace(depth_c=window.depth_c, hit_count=window.hit_count, max_hits=window.max_hits,
-                                  tile_base=window.tile_base, width=window.width, height=window.rows)
-            _, _, _, weights_c = composite_frame(rgbs, sigmas, sub, float(mesh_intersect.render_step_size),
-                                                 render_bkgd=render_bkgd, bg_color=bg_color, want_weights=True,
-                                                 out=(rgb[r0:r1], opacity[r0:r1], depth_img[r0:r1]),
-                                                 tile_base_offset=window.base)
+            rgb, opacity, _, depth_img, weights = derive_properties(
+                rgbs, sigmas.reshape(-1), ts, float(mesh_intersect.render_step_size), None, index_ray, bg_color=bg_color,
+                render_bkgd=render_bkgd, N=num_rays, sample_index=auto_inverse)
             if mesh_finetune is not None:
-                mesh_finetune.update_d(None, weights_c[:, 0], window.tri_c)
-            weights = weights_c.index_select(0, auto_inverse)
+                mesh_finetune.update_d(None, weights[:, 0].detach(), index_tri)
             return (rgb.view((*rays_shape[:-1], -1)), opacity.view((*rays_shape[:-1], -1)),
                     depth_img.view((*rays_shape[:-1], -1)), xyzs.shape[0], weights, xyzs, index_ray, loss, index_tri)
     elif order is None and inference and xyzs.shape[0] > 0:

@@ -229,7 +229,7 @@ def test_tile_compositor_equals_the_chunked_kernel(device, bg, w, h):
     tile_base = (torch.cumsum(totals, 0) - totals).contiguous()
     inverse = torch.empty((n,), dtype=torch.int32, device=device)
     _C.check(_C.lib().qf_coherent_layout(_C.ptr(clamped), _C.ptr(offsets), _C.ptr(tile_base), w, h, None, _C.ptr(inverse),
-                                         0, None, None, _C.stream()), "qf_coherent_layout")
+                                         0, _C.stream()), "qf_coherent_layout")
     g = torch.Generator().manual_seed(4)
     color, density = torch.rand(n, 3, generator=g).to(device), (torch.rand(n, generator=g) * 300).to(device)
     depth = (torch.rand(n, generator=g) * 5).to(device)
