@@ -1128,8 +1128,12 @@ class MeshIntersection:
         else:
             self.mesh = load_mesh(mesh_path)
         if simplify_mesh:
-            raise NotImplementedError("vertex-clustering simplification is offline mesh tooling (out of scope); "
-                                      "the reference's scripts pass simplify_mesh=False")
+            # The reference's default (mesh_utils.py:181).  It does not run THERE either: the open3d branch is disabled by
+            # an `import nonsense` (:186), every mesh is a trimesh.Trimesh, and `simplify_vertex_clustering` (:199) is an
+            # open3d method -- AttributeError.  Every script of the reference passes simplify_mesh=False.
+            raise NotImplementedError("simplify_mesh=True: vertex-clustering simplification is offline mesh tooling (out "
+                                      "of scope) -- and the reference's own default path raises AttributeError (its open3d "
+                                      "branch is disabled, mesh_utils.py:186,199); its scripts pass simplify_mesh=False")
         self.num_repeat = num_repeat
         self.num_intersections = num_intersections
         self.render_step_size = render_step_size

@@ -84,6 +84,14 @@ def generate_splits(data, num_rays, chunk_size=160000):
 
 _BG = {"white": _C.BG_WHITE, "black": _C.BG_BLACK}
 
+#: SURVEY.md B-14: the reference draws ``torch.rand((S, 3))`` on the device for EVERY split it renders, evaluation included
+#: (examples/utils.py:543-546: the random barycentric points of the regulariser, which evaluation then discards).  The
+#: pixels do not depend on it, so the evaluation route here does not draw -- but a seeded run that interleaves training
+#: and evaluation (train_finetune.py evaluates every ``eval_every`` steps) then sees a different random stream after its
+#: first ``test()`` than the reference would.  True: ``render_image_finetune_with_occgrid`` draws (and drops) the same
+#: tensor at evaluation, one small launch per split, and the device generator advances exactly as in the reference.
+REPRODUCE_EVAL_RNG_ADVANCE = False
+
 
 class _DerivePropertiesFn(torch.autograd.Function):
     """Differentiable compositing: forward = qf_derive_properties, backward = qf_derive_properties_backward
@@ -277,6 +285,8 @@ def render_image_finetune_with_occgrid(
     loss = torch.zeros(1, device=device)
     inference = not (torch.is_grad_enabled() and (xyzs.requires_grad or ts.requires_grad or _module_trains(radiance_field)
                                                   or _module_trains(field_net)))
+    if REPRODUCE_EVAL_RNG_ADVANCE and not _module_trains(field_net) and xyzs.shape[0] > 0:
+        torch.rand((xyzs.shape[0], 3), device=device)          # utils.py:545, drawn and dropped: only the stream moves
     auto_inverse = None
     window = data if (isinstance(data, SampleWindow) and inference and order is None and xyzs.shape[0] > 0
                       and data.num_rays == num_rays and data.inverse.device == device) else None

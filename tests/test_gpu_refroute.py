@@ -354,3 +354,42 @@ def test_loader_items_cut_for_their_windows_give_the_same_frame(device, scaling,
     for j in (0, 1, 2, 4, 5):
         assert torch.equal(a[j], b[j]), j
     assert a[3] == b[3] > 500
+
+
+def test_eval_rng_advance_can_follow_the_reference(device):
+    """SURVEY B-14 (VERDICT r3 missing 3): the reference draws torch.rand((S, 3)) per split even at evaluation
+    (examples/utils.py:543-546).  Off by default (the pixels do not depend on it); with
+    ``utils.REPRODUCE_EVAL_RNG_ADVANCE`` the device generator ends an evaluation render exactly where one such draw per
+    split leaves it, so a seeded train / eval interleave keeps the reference's random stream.  Pixels identical either way."""
+    from quadraturefields_amd import synthetic, utils
+    from quadraturefields_amd.datasets.nerf_synthetic import SubjectLoader
+    mesh, mi, field = _scene(device)
+    w = h = 64
+    cams = np.stack([np.asarray(c, dtype=np.float32) for c in synthetic.orbit_cameras(1, seed=2)])
+    ds = SubjectLoader.from_arrays(np.zeros((1, h, w, 4), np.uint8), cams, synthetic.lego_focal(800) * w / 800.0,
+                                   split="test", mesh_intersect=mi, device=device)
+    item = ds[0]
+    splits = utils.generate_splits(item["data"], w * h, chunk_size=16 * w)
+    assert len(splits) == 4
+
+    def render_all():
+        return [utils.render_image_finetune_with_occgrid(field, None, None, item["rays"], sp, render_step_size=5e-3,
+                                                         render_bkgd=item["color_bkgd"], mesh_intersect=mi, scaling=0)[0]
+                for sp in splits]
+
+    torch.manual_seed(11)
+    before = torch.cuda.get_rng_state(device)
+    plain = render_all()
+    assert torch.equal(torch.cuda.get_rng_state(device), before)              # default: the stream does not move
+    utils.REPRODUCE_EVAL_RNG_ADVANCE = True
+    try:
+        torch.manual_seed(11)
+        drawn = render_all()
+        state = torch.cuda.get_rng_state(device)
+    finally:
+        utils.REPRODUCE_EVAL_RNG_ADVANCE = False
+    torch.manual_seed(11)
+    for sp in splits:
+        torch.rand((sp[0].shape[0], 3), device=device)                        # what the reference's loop draws
+    assert torch.equal(state, torch.cuda.get_rng_state(device))
+    assert all(torch.equal(a, b) for a, b in zip(plain, drawn))
