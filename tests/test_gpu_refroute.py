@@ -393,3 +393,45 @@ def test_eval_rng_advance_can_follow_the_reference(device):
         torch.rand((sp[0].shape[0], 3), device=device)                        # what the reference's loop draws
     assert torch.equal(state, torch.cuda.get_rng_state(device))
     assert all(torch.equal(a, b) for a, b in zip(plain, drawn))
+
+
+def test_reference_eval_loop_at_the_scripts_up_sample_2_size(device):
+    """The scripts' evaluation size (run_nerfsynthetic_finetune.sh:9: up_sample 2 -> 1600 x 1600 rays per item, 16 windows
+    of 160 000 rays = 100 rows: NOT a multiple of the 8-row tiles, so every window's tile grid ends in a partial row) on a
+    245 760-triangle scene at K = 25: loader item -> generate_splits -> render_image_finetune_with_occgrid per window ->
+    the harness's assembly equals the tile-order FrameRenderer frame BIT FOR BIT (~15 M quadrature points)."""
+    from quadraturefields_amd import synthetic, utils
+    from quadraturefields_amd.datasets.nerf_synthetic import SubjectLoader
+    from quadraturefields_amd.mesh_utils import MeshIntersection, SampleSet, SampleWindow
+    from quadraturefields_amd.radiance_fields.ngp import NGPRadianceField
+    from quadraturefields_amd.render import FrameRenderer
+    mesh = synthetic.shell_mesh(n_shells=12, subdivisions=5)
+    mi = MeshIntersection(mesh, simplify_mesh=False, scale=1.0, num_intersections=25, device=device)
+    field = NGPRadianceField(aabb=[-1.5] * 3 + [1.5] * 3, log2_hashmap_size=17)
+    field.load_state_dict(synthetic.seeded_ngp_state(17, field.mlp_base.grid.n_rows), strict=False)
+    field = field.to(device)
+    cams = np.stack([np.asarray(c, dtype=np.float32) for c in synthetic.orbit_cameras(1, seed=4)])
+    ds = SubjectLoader.from_arrays(np.zeros((1, 800, 800, 4), np.uint8), cams, synthetic.lego_focal(800), split="test",
+                                   mesh_intersect=mi, device=device, upsample=2)
+    item = ds[0]
+    data, rays = item["data"], item["rays"]
+    n = rays.origins.shape[0]
+    assert n == 1600 * 1600 and isinstance(data, SampleSet) and data.window_rays == 160000 and len(data.cuts) == 17
+    assert data[0].shape[0] > 8_000_000
+    rgb = torch.ones((n, 3), device=device)
+    depth = torch.zeros((n,), device=device)
+    splits = utils.generate_splits(data, n)
+    assert len(splits) >= 12 and all(isinstance(s, SampleWindow) for s in splits)
+    total = 0
+    for split in splits:
+        color, _, d, n_s, _, _, _, _, _ = utils.render_image_finetune_with_occgrid(
+            field, None, None, rays, split, render_step_size=5e-3, render_bkgd=item["color_bkgd"], mesh_intersect=mi,
+            scaling=0)
+        rgb[split[2]] = color[split[2]]
+        depth[split[2]] = d.squeeze()[split[2]]
+        total += n_s
+    assert total == data[0].shape[0]
+    rgb_f, _, dep_f, n_f = FrameRenderer(mi, field, render_step_size=5e-3).render(rays.origins, rays.viewdirs,
+                                                                                  camera=item["camera"])
+    assert n_f == total
+    assert torch.equal(rgb, rgb_f) and torch.equal(depth, dep_f.reshape(-1))
