@@ -569,18 +569,22 @@ def init_from_env(backend: str = "nccl"):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world > 1 and not dist.is_initialized():
+        import datetime
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # a collective that never completes should fail the run in minutes, with a message, not sit until the launcher's
+        # own limit (the default is 10 min for RCCL, 30 for gloo); everything exchanged here is a few MB
+        limit = datetime.timedelta(seconds=float(os.environ.get("QF_COLLECTIVE_TIMEOUT_S", "300")))
         if backend == "nccl" and torch.cuda.is_available():
             # bind the rank to its GPU before RCCL comes up, and tell the process group which device it owns
             torch.cuda.set_device(local_rank)
             try:
-                dist.init_process_group(backend=backend, rank=rank, world_size=world,
+                dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=limit,
                                         device_id=torch.device("cuda", local_rank))
             except TypeError:               # a torch without the device_id keyword: lazy communicator, same binding
-                dist.init_process_group(backend=backend, rank=rank, world_size=world)
+                dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=limit)
         else:
-            dist.init_process_group(backend=backend, rank=rank, world_size=world)
+            dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=limit)
     return rank, local_rank, world
 
 

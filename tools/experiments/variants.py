@@ -148,7 +148,12 @@ _B_XPAIR = (_B_GATHER, """            // EXPERIMENT bf16_xpair: corners c, c+1 a
 # (trav_unordered -- any hit child next instead of the nearest -- was measured here in round 4: frame 0.961 -> 0.917 ms,
 # 2^17 random rays 0.549 -> 0.528; it is in the product now: bvh8_traverse_kernel<kOrdered>, chosen per mesh)
 
+# the nearest-first traversal on every mesh (round 3's behaviour), to compare instruction counts with the product's choice
+_TRAV_ORDERED = ("    const bool ordered = bvh->depth_complexity >= 0.5f * (float)max_hits;\n",
+                 "    const bool ordered = true;       // EXPERIMENT trav_ordered\n")
+
 VARIANTS = {
+    "trav_ordered": ("exact.hip", [_TRAV_ORDERED], []),
     "bf16_no_mlp": ("field_eval_bf16.hip", [_B_NO_MLP], []),
     "bf16_no_gather": ("field_eval_bf16.hip", [_B_NO_GATHER], []),
     "bf16_xpair": ("field_eval_bf16.hip", [_B_XPAIR], []),
