@@ -115,7 +115,12 @@ def _band_worker(rank, world, port, w, h, q):
         cuts.append(list(sr.last_cuts))
     # per-row numbers ride in the same collective (the bands' sample counts): uneven bands, more rows than one padded
     # row of the payload holds
-    uneven = [0, 8 * (h // 24 + 1), h] if world == 2 else [0, 8, 8 * (h // 16), h]
+    if world == 2:
+        uneven = [0, 8 * (h // 24 + 1), h]
+    elif world == 3:
+        uneven = [0, 8, 8 * (h // 16), h]
+    else:                                    # ragged, one empty band in the middle, the rest to the last rank
+        uneven = [0, 8, 8, 32, 40, 56, 64, 72, h][:world] + [h]
     rows = uneven[rank + 1] - uneven[rank]
     local = torch.full((rows * w, 5), float(rank))
     for mode in ("exact", "padded"):         # all_to_all_single with split sizes; all_gather of padded bands
@@ -130,7 +135,7 @@ def _band_worker(rank, world, port, w, h, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("w,h,world", [(24, 64, 2), (17, 43, 2), (2, 80, 2), (24, 64, 3)])
+@pytest.mark.parametrize("w,h,world", [(24, 64, 2), (17, 43, 2), (2, 80, 2), (24, 64, 3), (16, 200, 8)])
 def test_two_rank_band_render_and_gather(w, h, world):
     port = _free_port()
     ctx = mp.get_context("spawn")
@@ -147,6 +152,7 @@ def test_two_rank_band_render_and_gather(w, h, world):
     cuts = results[0][2]
     assert cuts[0] == cuts[1] == parallel.band_cuts(h, world)    # uniform until the lagged profile arrives
     assert cuts[2][0] == 0 and cuts[2][-1] == h and cuts[2][1] % parallel.BAND_ALIGN == 0
+    assert len(cuts[2]) == world + 1
 
 
 def test_band_cuts_properties():
@@ -206,7 +212,7 @@ def _selftest_worker(rank, world, port, broken, q):
         info = parallel.selftest_collectives(rank, world)
         report = parallel.device_report(rank, world)
         # the selected modes are the ones the module now uses by default: a real exchange through them
-        cuts = [0, 8, 24] if world == 2 else [0, 8, 8, 24]
+        cuts = {2: [0, 8, 24], 3: [0, 8, 8, 24]}.get(world) or [8 * r for r in range(world)] + [8 * world + 16]
         w = 4
         local = torch.full(((cuts[rank + 1] - cuts[rank]) * w, 5), float(rank))
         frame = parallel.gather_bands(local, cuts, w, rank, world)
@@ -244,6 +250,8 @@ def _run_selftest(world, broken):
     (3, ("all_to_all_single",), "padded", "rank0"),
     (2, ("all_to_all_single", "all_gather_into_tensor"), "broadcast", "rank0"),
     (3, ("gather",), "exact", "all"),
+    (8, (), "exact", "rank0"),                       # the node the bench is meant for: eight ranks
+    (8, ("all_to_all_single",), "padded", "rank0"),
 ])
 def test_collective_selftest_picks_a_working_mode(world, broken, band, frame):
     results = _run_selftest(world, broken)
